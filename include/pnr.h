@@ -1,0 +1,170 @@
+/*
+ * pnr.h -- C ABI of the MI355X-native Point-NeRF render hot path (libpnr_hip.so).
+ *
+ * Drop-in boundary for SHUzhekiNg/pointnerf2studio (citations relative to the reference repo):
+ *
+ *   reference interface                                              replaced by
+ *   ---------------------------------------------------------------  -----------------------------
+ *   query_worldcoords.cpp:33-78  woord_query_grid_point_index(...)   pnr_scene_build + pnr_query_raypos
+ *     (pybind module JIT-loaded at studio_utils.py:77-82; called at  (same inputs, same three outputs in the
+ *      studio_utils.py:172-188)                                       same layouts, compacted over kept rays)
+ *   studio_utils.py:115-127      NeuralPoints.get_hyperparameters    host side (python), feeds pnr_grid_params_t
+ *   studio_utils.py:190-207      w2pers / index_select gathers       pnr_points_pack + gather inside pnr_render
+ *   studio_model.py:270-365      dists, weights, PE, 3 MLPs, K-agg   pnr_weights_pack + pnr_render (shade stage)
+ *   studio_model.py:368-399      ray_dist, composite, fill_invalid   pnr_render (composite stage)
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative pnr_status_t otherwise; the message of the
+ *     last failure on the calling thread is returned by pnr_last_error();
+ *   - all `d_` pointers are DEVICE pointers (HBM) owned by the caller and borrowed for the call;
+ *     nothing is retained after return except inside the opaque handles;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); pnr_render and
+ *     pnr_query_raypos only ENQUEUE work on it and never synchronise; pnr_scene_build,
+ *     pnr_points_pack and pnr_weights_pack may synchronise the stream (they run once per
+ *     point-cloud / weight version, not per ray batch);
+ *   - no torch types cross this boundary; the Python side passes tensor.data_ptr() and
+ *     torch.cuda.current_stream().cuda_stream.
+ */
+#ifndef PNR_H_
+#define PNR_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PNR_VERSION 100          /* 0.1.0 */
+#define PNR_FEAT_DIM 32          /* point_features_dim  (studio_model.py:79)            */
+#define PNR_MAX_K 32             /* neighbours per sample; the reference breaks at K>8 (cu:14) */
+#define PNR_MAX_D 512            /* coarse samples per ray (z_depth_dim, default 400)   */
+#define PNR_POINT_ROW_FLOATS 44  /* packed point row: xyz conf | emb[32] | color dir pad */
+
+typedef enum {
+    PNR_OK = 0,
+    PNR_ERR_INVALID = -1,   /* bad argument (null pointer, size out of range, ...)     */
+    PNR_ERR_HIP = -2,       /* a HIP runtime call failed                               */
+    PNR_ERR_STATE = -3,     /* handle not built / packed yet                           */
+    PNR_ERR_WORKSPACE = -4  /* workspace too small for the requested capacity          */
+} pnr_status_t;
+
+typedef struct pnr_scene pnr_scene_t;     /* voxel structure + packed point table           */
+typedef struct pnr_weights pnr_weights_t; /* MLP weights in MFMA operand order              */
+
+/* Voxel-grid hyper-parameters: exactly what NeuralPoints.get_hyperparameters + config produce
+ * (studio_utils.py:104-127) and what the reference op receives as tensors
+ * (query_worldcoords.cpp:33-50). */
+typedef struct {
+    float ranges[6];        /* ranges_tensor: padded bbox, [0:3] is the grid origin        */
+    float vox[3];           /* scaled_vsize = vsize * vscale                               */
+    int32_t dims[3];        /* scaled_vdim                                                 */
+    int32_t kernel_size[3]; /* neighbour-search extent: (kernel_size[0]+1)/2 layers, cu:256 */
+    int32_t query_size[3];  /* occupancy dilation extent, cu:101-103                       */
+    int32_t P;              /* max points kept per voxel                                   */
+    int32_t max_o;          /* max occupied voxels of the reference (only flagged here)    */
+    int32_t compat_drop_voxel0; /* reproduce `voxel_idx > 0` (cu:147): the voxel of the first
+                                   in-grid point holds no points                           */
+} pnr_grid_params_t;
+
+/* Camera of one ray bundle (studio_utils.py:148-155). */
+typedef struct {
+    float campos[3];    /* ray_bundle.origins[0]                                           */
+    float camrotc2w[9]; /* metadata["camrotc2w"], row-major 3x3                            */
+    float near_plane, far_plane;
+} pnr_camera_t;
+
+/* Render options. */
+typedef struct {
+    int32_t SR;            /* max shading samples per ray                                  */
+    int32_t K;             /* neighbours per sample                                        */
+    int32_t D;             /* coarse samples per ray; d_tmid has D entries                 */
+    float radius_limit;    /* neighbour radius (4 * vsize, studio_utils.py:110)            */
+    float vsize_z;         /* config.vsize[2], the fallback segment length                 */
+    int32_t eval_clamp;    /* 1: clamp rgb to [0,1] (nerfstudio RGBRenderer outside training) */
+    float bg[3];           /* background colour (white in the reference)                   */
+} pnr_render_opts_t;
+
+/* Counters written by pnr_render / pnr_query_raypos into d_counters[PNR_NUM_COUNTERS] (int64). */
+enum {
+    PNR_CNT_RAYS_HIT = 0,       /* R'  rays with >= 1 coarse sample in dilated occupancy     */
+    PNR_CNT_RAYS_KEPT = 1,      /* R'' rays with >= 1 neighbour                              */
+    PNR_CNT_SAMPLES_SELECTED = 2, /* shading samples selected (<= SR per ray)                */
+    PNR_CNT_SAMPLES_VALID = 3,  /* S   samples with >= 1 neighbour                           */
+    PNR_CNT_PAIRS_VALID = 4,    /* M   valid (sample, neighbour) pairs                       */
+    PNR_CNT_CANDIDATES = 5,     /* candidates distance-tested                                */
+    PNR_CNT_OVERFLOW = 6,       /* != 0: cap_samples was too small, output incomplete        */
+    PNR_CNT_RESERVED = 7,
+    PNR_NUM_COUNTERS = 8
+};
+
+const char *pnr_last_error(void);
+int pnr_version(void);
+
+/* ---- scene: built once per point-cloud version ------------------------------------------------ */
+int pnr_scene_create(pnr_scene_t **out);
+int pnr_scene_destroy(pnr_scene_t *scene);
+/* Builds the voxel structure over d_xyz [N,3] (replaces claim_occ / map_coor2occ / fill_occ2pnts,
+ * cu:18-162, which the reference re-runs for every ray chunk). Deterministic: per-voxel point lists
+ * are in ascending point index, first P kept. */
+int pnr_scene_build(pnr_scene_t *scene, const float *d_xyz, int64_t N, const pnr_grid_params_t *params,
+                    void *stream);
+/* info[0]=occupied voxels, [1]=(occupied > max_o), [2]=points kept in voxel lists, [3]=bricks,
+ * [4]=device bytes held, [5]=N, [6]=points inside the grid, [7]=voxel dropped by compat (-1 none) */
+int pnr_scene_info(const pnr_scene_t *scene, int64_t info[8]);
+/* Packs the per-point tensors (studio_utils.py:84-90 layouts: xyz [N,3], embedding [N,32], conf [N],
+ * dir [N,3], color [N,3]) into 176-byte rows so one neighbour costs one contiguous gather. */
+int pnr_points_pack(pnr_scene_t *scene, const float *d_xyz, const float *d_embedding, const float *d_conf,
+                    const float *d_dir, const float *d_color, int64_t N, void *stream);
+
+/* ---- MLP weights: packed once per weight version ------------------------------------------------ */
+int pnr_weights_create(pnr_weights_t **out);
+int pnr_weights_destroy(pnr_weights_t *w);
+/* d_w[i] / d_b[i], i = 0..8, PyTorch nn.Linear layouts ([out,in] row-major, [out]):
+ *   0 mlp_base.0 [256,284]  1 mlp_base.1 [256,256]  2 mlp_head.0 [256,263]  3 mlp_head.1 [256,256]
+ *   4 density    [1,256]    5 mlp_color.0 [128,280] 6 mlp_color.1 [128,128] 7 mlp_color.2 [128,128]
+ *   8 rgb        [3,128]                                    (modules: studio_model.py:193-221)
+ * d_Rw2c: points_Rw2c [3,3] (studio_utils.py:90). */
+int pnr_weights_pack(pnr_weights_t *w, const float *const d_w[9], const float *const d_b[9],
+                     const float *d_Rw2c, void *stream);
+
+/* ---- the drop-in op ----------------------------------------------------------------------------- */
+size_t pnr_query_workspace_bytes(int64_t R, int32_t D, int32_t SR, int32_t K);
+/* woord_query_grid_point_index with explicit ray positions d_raypos [R,D,3].
+ * Outputs (caller-allocated, worst case): d_sample_pidx [R,SR,K] int32, d_sample_loc [R,SR,3] f32,
+ * d_ray_mask [R] int8.  The first R'' = d_counters[PNR_CNT_RAYS_KEPT] rows of pidx/loc are valid
+ * (compacted over kept rays in ray order, -1 / 0 in unfilled slots), exactly the tensors the
+ * reference returns (cu:425-432) once sliced to R''. */
+int pnr_query_raypos(const pnr_scene_t *scene, const float *d_raypos, int64_t R, int32_t D, int32_t SR,
+                     int32_t K, float radius_limit, int32_t *d_sample_pidx, float *d_sample_loc,
+                     int8_t *d_ray_mask, int64_t *d_counters, void *d_workspace, size_t workspace_bytes,
+                     void *stream);
+
+/* ---- fused render: NeuralPoints.forward + PointNerf.get_outputs for one ray bundle -------------- */
+size_t pnr_render_workspace_bytes(int64_t R, int64_t cap_samples, int32_t K);
+/* d_dirs [R,3] ray directions, d_tmid [D] coarse-sample ray parameters (diff_ray_marching.py:307-323
+ * evaluated on the host).  Outputs: d_rgb [R,3] (coarse_raycolor, background-filled), d_depth [R],
+ * d_acc [R], d_ray_mask [R] int8, d_counters [PNR_NUM_COUNTERS] int64.  cap_samples bounds the number
+ * of selected shading samples held in the workspace; if exceeded PNR_CNT_OVERFLOW is set. */
+int pnr_render(const pnr_scene_t *scene, const pnr_weights_t *weights, const float *d_dirs, int64_t R,
+               const pnr_camera_t *cam, const float *d_tmid, const pnr_render_opts_t *opts,
+               float *d_rgb, float *d_depth, float *d_acc, int8_t *d_ray_mask, int64_t *d_counters,
+               void *d_workspace, size_t workspace_bytes, int64_t cap_samples, void *stream);
+
+/* Debug/test taps into the last pnr_render workspace (device pointers, valid until the workspace is
+ * reused): per selected sample s: loc+t float4, ray id, neighbour list [K], decoded (sigma,r,g,b). */
+typedef struct {
+    const float *smp_loc;      /* [S_sel,4] x y z t */
+    const int32_t *smp_ray;    /* [S_sel]           */
+    const int32_t *smp_pidx;   /* [S_sel,K]         */
+    const float *smp_out;      /* [S_sel,4] sigma r g b (zero where no neighbour) */
+    const int32_t *ray_cnt;    /* [R] selected samples per ray */
+    const int32_t *ray_off;    /* [R] first sample of ray      */
+} pnr_render_taps_t;
+int pnr_render_taps(void *d_workspace, size_t workspace_bytes, int64_t R, int64_t cap_samples, int32_t K,
+                    pnr_render_taps_t *taps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNR_H_ */

@@ -1,0 +1,96 @@
+"""ctypes binding of libpnr_hip.so (include/pnr.h).  Tensors in, tensors out; no torch C++ ABI.
+
+There is NO fallback: if the HIP library is missing or a call fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libpnr_hip.so")
+
+NUM_COUNTERS = 8
+COUNTER_NAMES = ["rays_hit", "rays_kept", "samples_selected", "samples_valid", "pairs_valid", "candidates",
+                 "overflow", "reserved"]
+POINT_ROW_FLOATS = 44
+MAX_K = 32
+MAX_D = 512
+
+# every symbol include/pnr.h declares (tests check that the library exports all of them)
+EXPORTED_SYMBOLS = [
+    "pnr_last_error", "pnr_version",
+    "pnr_scene_create", "pnr_scene_destroy", "pnr_scene_build", "pnr_scene_info", "pnr_points_pack",
+    "pnr_weights_create", "pnr_weights_destroy", "pnr_weights_pack",
+    "pnr_query_workspace_bytes", "pnr_query_raypos",
+    "pnr_render_workspace_bytes", "pnr_render", "pnr_render_taps",
+]
+
+
+class GridParams(C.Structure):
+    _fields_ = [("ranges", C.c_float * 6), ("vox", C.c_float * 3), ("dims", C.c_int32 * 3),
+                ("kernel_size", C.c_int32 * 3), ("query_size", C.c_int32 * 3), ("P", C.c_int32),
+                ("max_o", C.c_int32), ("compat_drop_voxel0", C.c_int32)]
+
+
+class CameraC(C.Structure):
+    _fields_ = [("campos", C.c_float * 3), ("camrotc2w", C.c_float * 9), ("near_plane", C.c_float),
+                ("far_plane", C.c_float)]
+
+
+class RenderOpts(C.Structure):
+    _fields_ = [("SR", C.c_int32), ("K", C.c_int32), ("D", C.c_int32), ("radius_limit", C.c_float),
+                ("vsize_z", C.c_float), ("eval_clamp", C.c_int32), ("bg", C.c_float * 3)]
+
+
+class RenderTaps(C.Structure):
+    _fields_ = [("smp_loc", C.c_void_p), ("smp_ray", C.c_void_p), ("smp_pidx", C.c_void_p),
+                ("smp_out", C.c_void_p), ("ray_cnt", C.c_void_p), ("ray_off", C.c_void_p)]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Loads libpnr_hip.so; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m pointnerf2studio_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU or PyTorch fallback for the render path.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i64, i32, f32, sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
+    lib.pnr_last_error.restype = C.c_char_p
+    lib.pnr_last_error.argtypes = []
+    lib.pnr_version.restype = C.c_int
+    lib.pnr_scene_create.argtypes = [C.POINTER(vp)]
+    lib.pnr_scene_destroy.argtypes = [vp]
+    lib.pnr_scene_build.argtypes = [vp, vp, i64, C.POINTER(GridParams), vp]
+    lib.pnr_scene_info.argtypes = [vp, C.POINTER(i64 * 8)]
+    lib.pnr_points_pack.argtypes = [vp, vp, vp, vp, vp, vp, i64, vp]
+    lib.pnr_weights_create.argtypes = [C.POINTER(vp)]
+    lib.pnr_weights_destroy.argtypes = [vp]
+    lib.pnr_weights_pack.argtypes = [vp, C.POINTER(vp * 9), C.POINTER(vp * 9), vp, vp]
+    lib.pnr_query_workspace_bytes.restype = sz
+    lib.pnr_query_workspace_bytes.argtypes = [i64, i32, i32, i32]
+    lib.pnr_query_raypos.argtypes = [vp, vp, i64, i32, i32, i32, f32, vp, vp, vp, vp, vp, sz, vp]
+    lib.pnr_render_workspace_bytes.restype = sz
+    lib.pnr_render_workspace_bytes.argtypes = [i64, i64, i32]
+    lib.pnr_render.argtypes = [vp, vp, vp, i64, C.POINTER(CameraC), vp, C.POINTER(RenderOpts), vp, vp, vp, vp, vp,
+                               vp, sz, i64, vp]
+    lib.pnr_render_taps.argtypes = [vp, sz, i64, i64, i32, C.POINTER(RenderTaps)]
+    for name in EXPORTED_SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ("pnr_last_error", "pnr_query_workspace_bytes", "pnr_render_workspace_bytes"):
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().pnr_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed with status {rc}: {msg}")

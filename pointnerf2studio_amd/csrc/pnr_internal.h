@@ -1,0 +1,173 @@
+// Internal declarations shared by the HIP translation units of libpnr_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "pnr.h"
+
+namespace pnr {
+
+void set_error(const char *fmt, ...);
+
+#define PNR_HIP_CHECK(expr)                                                                       \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            ::pnr::set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return PNR_ERR_HIP;                                                                   \
+        }                                                                                         \
+    } while (0)
+
+#define PNR_REQUIRE(cond, ...)                                                                    \
+    do {                                                                                          \
+        if (!(cond)) {                                                                            \
+            ::pnr::set_error(__VA_ARGS__);                                                        \
+            return PNR_ERR_INVALID;                                                               \
+        }                                                                                         \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// Voxel structure in HBM (built once per point cloud; read-only on the render path).
+//
+// The grid is cut into 4x4x4 bricks; one 64-bit word holds the occupancy of a brick
+// (bit = (x&3)<<4 | (y&3)<<2 | (z&3)), bricks are linear in (bx, by, bz).  A 16-byte record per
+// brick {bits, rank} turns "is cell c occupied, and which voxel is it" into ONE load plus a
+// popcount: voxel id = rank + popc(bits below c) -- a collision-free minimal perfect hash of the
+// occupied voxels that is ~1.5 bits per cell (1-2 MB for a nerf-synthetic scene: L2-resident),
+// against two dense int32 grids (2 x 33 MB) in the reference (cu:314-319).
+// Voxel v owns cand[vox_start[v] .. vox_start[v+1]): its first P points in ascending point index
+// as float4 {x, y, z, bits(point index)} -- the distance test reads contiguous 16-byte records
+// instead of the reference's occ_2_pnts -> in_data[pidx*3] double indirection (cu:266-270).
+// ------------------------------------------------------------------------------------------------
+struct BrickRec {
+    unsigned long long bits;  // cells of this brick that hold points (after the compat drop)
+    uint32_t rank;            // number of occupied cells in all earlier bricks
+    uint32_t pad;
+};
+
+struct GridView {
+    float shift[3];
+    float vox[3];
+    int dims[3];
+    int bdims[3];   // bricks per axis
+    int kernel_size[3];
+    int nbricks;
+    int nvox;
+    const unsigned long long *occ_dil;  // [nbricks] dilated occupancy (sample selection)
+    const BrickRec *rec;                // [nbricks]
+    const int *vox_start;               // [nvox + 1]
+    const float4 *cand;                 // [vox_start[nvox]]
+};
+
+// fp32 subtract, IEEE divide, floor -- the reference's voxel coordinate (cu:40-42); the library is
+// compiled with -ffp-contract=off so nothing here is fused.
+__device__ __forceinline__ bool cell_of(const GridView &g, float px, float py, float pz, int &cx, int &cy,
+                                        int &cz)
+{
+    cx = (int)floorf((px - g.shift[0]) / g.vox[0]);
+    cy = (int)floorf((py - g.shift[1]) / g.vox[1]);
+    cz = (int)floorf((pz - g.shift[2]) / g.vox[2]);
+    return !(cx < 0 || cx >= g.dims[0] || cy < 0 || cy >= g.dims[1] || cz < 0 || cz >= g.dims[2]);
+}
+
+__device__ __forceinline__ void brick_of(const GridView &g, int cx, int cy, int cz, int &brick, int &bit)
+{
+    brick = ((cx >> 2) * g.bdims[1] + (cy >> 2)) * g.bdims[2] + (cz >> 2);
+    bit = ((cx & 3) << 4) | ((cy & 3) << 2) | (cz & 3);
+}
+
+struct Camera {
+    float o[3];
+    float R[9];  // camrotc2w row-major
+};
+
+// ------------------------------------------------------------------------------------------------
+// device-wide exclusive scan of int32 (n read from device memory when n_dev != nullptr)
+// ------------------------------------------------------------------------------------------------
+size_t scan_temp_bytes(int64_t n_max);
+// out[i] = sum_{j<i} in[j] for i < n; out[n] = total (out has n_max + 1 entries); if total64 != nullptr
+// the total is also stored there as int64.  in == out is allowed.
+int scan_exclusive_i32(const int *in, int *out, int64_t n_max, const int *n_dev, int64_t *total64,
+                       void *temp, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------
+// handles
+// ------------------------------------------------------------------------------------------------
+}  // namespace pnr
+
+struct pnr_scene {
+    bool built = false;
+    bool packed = false;
+    pnr_grid_params_t params{};
+    pnr::GridView grid{};
+    int64_t N = 0;
+    int64_t info[8] = {0};
+    // owned device buffers
+    unsigned long long *occ_dil = nullptr;
+    pnr::BrickRec *rec = nullptr;
+    int *vox_start = nullptr;
+    float4 *cand = nullptr;
+    float *point_rows = nullptr;  // [N, PNR_POINT_ROW_FLOATS]
+    int64_t packed_N = 0;
+    size_t bytes = 0;
+};
+
+// Packed MLP weights.  Layer l, output tile m (32 features), k-step group g (4 k-steps), lane, 4 floats:
+// exactly the A operand of v_mfma_f32_32x32x2_f32 for 4 consecutive k-steps, so a wave streams its
+// weights with one coalesced 1-KiB dwordx4 load per 4 MFMAs.
+struct pnr_weights {
+    bool packed = false;
+    float *buf = nullptr;  // all packed tensors, offsets below (in floats)
+    size_t bytes = 0;
+    // offsets into buf
+    size_t w_off[9] = {0};
+    size_t b_off[9] = {0};
+    float Rw2c[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+};
+
+namespace pnr {
+
+// layer geometry (k-steps of 2 input features; padded to a multiple of 4 k-steps)
+constexpr int KS_BASE0 = 142;  // 284 / 2
+constexpr int KS_HID = 128;    // 256 / 2
+constexpr int KS_HEAD0 = 132;  // 264 / 2 (263 + 1 zero pad)
+constexpr int KS_COL0 = 140;   // 280 / 2
+constexpr int KS_COLH = 64;    // 128 / 2
+constexpr int kg_of(int ks) { return (ks + 3) / 4; }
+
+// workspace carving shared by pnr_render / taps
+struct RenderWs {
+    int *ray_cnt;
+    int *ray_off;   // [R+1]
+    int *ray_flag;
+    unsigned long long *ray_bits;  // [R, 8]
+    float4 *smp_loc;
+    int *smp_ray;
+    int *smp_pidx;   // [cap, K]
+    int *smp_valid;  // [cap]
+    int *smp_voff;   // [cap+1]
+    int *vs_list;    // [cap]
+    float *smp_sigma;  // [cap] by valid index
+    float *agg;        // [cap, 256] by valid index
+    float4 *smp_out;   // [cap]
+    int *n_sel;        // device ints: [0]=S_sel (clamped to cap), [1]=S_valid, [2]=R
+    void *scan_temp;
+    size_t total;
+};
+RenderWs carve_render_ws(void *base, int64_t R, int64_t cap, int K);
+
+int launch_select_expand(const GridView &g, const Camera &cam, const float *d_dirs, const float *d_raypos,
+                         int64_t R, int D, int SR, const float *d_tmid, int64_t cap, RenderWs &ws,
+                         int64_t *d_counters, hipStream_t stream);
+int launch_knn(const GridView &g, int K, float radius_limit, RenderWs &ws, int64_t cap, int64_t *d_counters,
+               hipStream_t stream);
+int launch_shade(const pnr_scene *scene, const pnr_weights *w, const Camera &cam, const float *d_dirs, int K,
+                 RenderWs &ws, int64_t cap, hipStream_t stream);
+int launch_composite(const Camera &cam, const pnr_render_opts_t &opts, int64_t R, RenderWs &ws, float *d_rgb,
+                     float *d_depth, float *d_acc, int8_t *d_ray_mask, int64_t *d_counters,
+                     hipStream_t stream);
+
+}  // namespace pnr

@@ -1,0 +1,396 @@
+// Query stage: coarse-sample occupancy masking, first-SR sample selection, fixed-K neighbour search.
+//
+// Replaces mask_raypos / host slotting / get_shadingloc / query_neigh_along_ray_layered / host
+// post-filter (query_worldcoords.cu:165-302,381-429).  What is different on MI355X:
+//   * one 64-lane wavefront walks one ray: the D coarse samples are probed 64 at a time against the
+//     L2-resident dilated-occupancy bitmask, `__ballot` + popcount give each hit its slot (the
+//     reference's cumsum over a [R,D] int tensor), and raypos[R,D,3] is never materialised: a sample
+//     position is campos + dir * t_mid[j], evaluated where needed (mul then add, unfused, as torch does);
+//   * shading samples of all rays live in ONE compact list (ray -> [off, off+cnt)), sized on the
+//     device by a scan -- no `.item()` syncs, no masked_select copies;
+//   * the neighbour search reads 16-byte {xyz, index} records that are contiguous per voxel.
+// The neighbour lists are bit-exact against the sequential oracle: same traversal order
+// (layer -> x -> y -> z -> slot), same replace-the-farthest rule, same fp32 distance expression.
+#include <algorithm>
+
+#include "pnr_internal.h"
+
+namespace pnr {
+
+constexpr int TPB = 256;
+
+static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+RenderWs carve_render_ws(void *base, int64_t R, int64_t cap, int K)
+{
+    RenderWs ws{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        void *p = (void *)((uintptr_t)base + off);
+        off += align_up(bytes);
+        return p;
+    };
+    ws.n_sel = (int *)take(64 * sizeof(int));
+    ws.ray_cnt = (int *)take((size_t)(R + 1) * sizeof(int));
+    ws.ray_off = (int *)take((size_t)(R + 1) * sizeof(int));
+    ws.ray_flag = (int *)take((size_t)(R + 1) * sizeof(int));
+    ws.ray_bits = (unsigned long long *)take((size_t)R * 8 * sizeof(unsigned long long));
+    ws.smp_loc = (float4 *)take((size_t)cap * sizeof(float4));
+    ws.smp_ray = (int *)take((size_t)cap * sizeof(int));
+    ws.smp_pidx = (int *)take((size_t)cap * K * sizeof(int));
+    ws.smp_valid = (int *)take((size_t)(cap + 1) * sizeof(int));
+    ws.smp_voff = (int *)take((size_t)(cap + 1) * sizeof(int));
+    ws.vs_list = (int *)take((size_t)cap * sizeof(int));
+    ws.smp_out = (float4 *)take((size_t)cap * sizeof(float4));
+    ws.scan_temp = take(scan_temp_bytes(std::max<int64_t>(R, cap) + 1));
+    // shade-only buffers last so that the query-only workspace is a prefix
+    ws.smp_sigma = (float *)take((size_t)cap * sizeof(float));
+    ws.agg = (float *)take((size_t)cap * 256 * sizeof(float));
+    ws.total = off;
+    return ws;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_select: one wavefront per ray.  bits[r][w] = occupancy of coarse samples 64w..64w+63,
+// cnt[r] = min(SR, hits).  Either explicit positions (d_raypos, the drop-in op) or o + d * t.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sample_pos(const float *__restrict__ raypos, const float *__restrict__ dirs,
+                                           const float *__restrict__ tmid, const Camera &cam, int64_t r, int D,
+                                           int j, float &px, float &py, float &pz, float &t)
+{
+    if (raypos) {
+        const float *p = raypos + ((int64_t)r * D + j) * 3;
+        px = p[0];
+        py = p[1];
+        pz = p[2];
+        t = 0.f;
+    } else {
+        t = tmid[j];
+        float dx = dirs[3 * r], dy = dirs[3 * r + 1], dz = dirs[3 * r + 2];
+        float mx = dx * t, my = dy * t, mz = dz * t;  // unfused: raydir * t, then campos + (.)
+        px = cam.o[0] + mx;
+        py = cam.o[1] + my;
+        pz = cam.o[2] + mz;
+    }
+}
+
+__global__ void __launch_bounds__(TPB) k_select(GridView g, Camera cam, const float *__restrict__ dirs,
+                                                 const float *__restrict__ raypos, const float *__restrict__ tmid,
+                                                 int64_t R, int D, int SR, int *__restrict__ ray_cnt,
+                                                 unsigned long long *__restrict__ ray_bits,
+                                                 unsigned long long *__restrict__ n_hit_rays)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+    if (r >= R) return;
+    int total = 0;
+    const int nwords = (D + 63) >> 6;
+    for (int w = 0; w < nwords; ++w) {
+        int j = w * 64 + lane;
+        bool hit = false;
+        if (j < D) {
+            float px, py, pz, t;
+            sample_pos(raypos, dirs, tmid, cam, r, D, j, px, py, pz, t);
+            int cx, cy, cz;
+            if (cell_of(g, px, py, pz, cx, cy, cz)) {
+                int brick, bit;
+                brick_of(g, cx, cy, cz, brick, bit);
+                hit = (g.occ_dil[brick] >> bit) & 1ull;
+            }
+        }
+        unsigned long long m = __ballot(hit);
+        if (lane == 0) ray_bits[r * 8 + w] = m;
+        total += __popcll(m);
+    }
+    if (lane == 0) {
+        ray_cnt[r] = min(total, SR);
+        if (total > 0) atomicAdd(n_hit_rays, 1ull);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_expand: one wavefront per ray; hit j with rank < SR becomes sample off[r] + rank.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TPB) k_expand(Camera cam, const float *__restrict__ dirs,
+                                                 const float *__restrict__ raypos, const float *__restrict__ tmid,
+                                                 int64_t R, int D, int SR, const int *__restrict__ ray_off,
+                                                 const unsigned long long *__restrict__ ray_bits, int64_t cap,
+                                                 float4 *__restrict__ smp_loc, int *__restrict__ smp_ray,
+                                                 int *__restrict__ n_sel, int64_t *__restrict__ counters)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+    if (r == 0 && lane == 0) {
+        // total selected samples, clamped to the workspace capacity
+        int total = ray_off[R];
+        n_sel[0] = (int)min((int64_t)total, cap);
+        counters[PNR_CNT_SAMPLES_SELECTED] = total;
+        if (total > cap) counters[PNR_CNT_OVERFLOW] = 1;
+    }
+    if (r >= R) return;
+    const int off = ray_off[r];
+    int base = 0;
+    const int nwords = (D + 63) >> 6;
+    for (int w = 0; w < nwords && base < SR; ++w) {
+        unsigned long long m = ray_bits[r * 8 + w];
+        if ((m >> lane) & 1ull) {
+            int rank = base + __popcll(m & ((1ull << lane) - 1ull));
+            int64_t s = (int64_t)off + rank;
+            if (rank < SR && s < cap) {
+                float px, py, pz, t;
+                sample_pos(raypos, dirs, tmid, cam, r, D, w * 64 + lane, px, py, pz, t);
+                smp_loc[s] = make_float4(px, py, pz, t);
+                smp_ray[s] = (int)r;
+            }
+        }
+        base += __popcll(m);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_knn: one thread per selected sample (query_neigh_along_ray_layered, cu:217-302).
+// ------------------------------------------------------------------------------------------------
+template <int KMAX>
+__global__ void __launch_bounds__(TPB) k_knn(GridView g, int K, float radius_limit2,
+                                              const float4 *__restrict__ smp_loc, const int *__restrict__ smp_ray,
+                                              const int *__restrict__ n_sel, int *__restrict__ smp_pidx,
+                                              int *__restrict__ smp_valid, int *__restrict__ ray_flag,
+                                              unsigned long long *__restrict__ n_pairs,
+                                              unsigned long long *__restrict__ n_cand)
+{
+    const int S = n_sel[0];
+    for (int64_t s = (int64_t)blockIdx.x * TPB + threadIdx.x; s < S; s += (int64_t)gridDim.x * TPB) {
+        const float4 c = smp_loc[s];
+        int fx, fy, fz;
+        cell_of(g, c.x, c.y, c.z, fx, fy, fz);  // selected samples are inside the grid by construction
+        int kid = 0, far_ind = 0;
+        float far2 = 0.0f;
+        float buf[KMAX];
+        int out[KMAX];
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) {
+            buf[i] = 0.f;
+            out[i] = -1;
+        }
+        unsigned tested = 0;
+        const int nlayers = (g.kernel_size[0] + 1) / 2;
+        for (int layer = 0; layer < nlayers; ++layer) {
+            for (int x = max(-fx, -layer); x < min(g.dims[0] - fx, layer + 1); ++x) {
+                for (int y = max(-fy, -layer); y < min(g.dims[1] - fy, layer + 1); ++y) {
+                    for (int z = max(-fz, -layer); z < min(g.dims[2] - fz, layer + 1); ++z) {
+                        if (max(abs(z), max(abs(x), abs(y))) != layer) continue;
+                        int brick, bit;
+                        brick_of(g, fx + x, fy + y, fz + z, brick, bit);
+                        const BrickRec rec = g.rec[brick];
+                        const unsigned long long mbit = 1ull << bit;
+                        if (!(rec.bits & mbit)) continue;
+                        const int v = (int)rec.rank + __popcll(rec.bits & (mbit - 1ull));
+                        const int vs = g.vox_start[v], ve = g.vox_start[v + 1];
+                        for (int q = vs; q < ve; ++q) {
+                            const float4 p = g.cand[q];
+                            const float xv = p.x - c.x, yv = p.y - c.y, zv = p.z - c.z;
+                            const float d2 = xv * xv + yv * yv + zv * zv;  // left-to-right, unfused
+                            ++tested;
+                            if (radius_limit2 == 0.0f || d2 <= radius_limit2) {
+                                const int pidx = __float_as_int(p.w);
+                                if (kid++ < K) {
+                                    const int slot = kid - 1;
+#pragma unroll
+                                    for (int i = 0; i < KMAX; ++i)
+                                        if (i == slot) {
+                                            out[i] = pidx;
+                                            buf[i] = d2;
+                                        }
+                                    if (d2 > far2) {
+                                        far2 = d2;
+                                        far_ind = slot;
+                                    }
+                                } else if (d2 < far2) {
+#pragma unroll
+                                    for (int i = 0; i < KMAX; ++i)
+                                        if (i == far_ind) {
+                                            out[i] = pidx;
+                                            buf[i] = d2;
+                                        }
+                                    far2 = d2;
+#pragma unroll
+                                    for (int i = 0; i < KMAX; ++i)
+                                        if (i < K && buf[i] > far2) {
+                                            far2 = buf[i];
+                                            far_ind = i;
+                                        }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (kid >= K) break;
+        }
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i)
+            if (i < K) smp_pidx[s * K + i] = out[i];
+        const int nn = min(kid, K);
+        smp_valid[s] = nn > 0;
+        if (nn > 0) {
+            ray_flag[smp_ray[s]] = 1;  // every writer stores the same value
+            atomicAdd(n_pairs, (unsigned long long)nn);
+        }
+        atomicAdd(n_cand, (unsigned long long)tested);
+    }
+}
+
+// vs_list[voff[s]] = s for samples with >= 1 neighbour; publishes S_valid
+__global__ void __launch_bounds__(TPB) k_compact_valid(const int *__restrict__ smp_valid,
+                                                        const int *__restrict__ smp_voff, int *__restrict__ n_sel,
+                                                        int *__restrict__ vs_list, int64_t *__restrict__ counters,
+                                                        const unsigned long long *__restrict__ acc)
+{
+    const int S = n_sel[0];
+    int64_t s0 = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (s0 == 0) {
+        n_sel[1] = smp_voff[S];
+        counters[PNR_CNT_SAMPLES_VALID] = smp_voff[S];
+        counters[PNR_CNT_RAYS_HIT] = (int64_t)acc[0];
+        counters[PNR_CNT_PAIRS_VALID] = (int64_t)acc[1];
+        counters[PNR_CNT_CANDIDATES] = (int64_t)acc[2];
+    }
+    for (int64_t s = s0; s < S; s += (int64_t)gridDim.x * TPB)
+        if (smp_valid[s]) vs_list[smp_voff[s]] = (int)s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// compat scatter: the reference's [R'',SR,K] / [R'',SR,3] / [R] int8 outputs (cu:425-432)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TPB) k_scatter_compat(int64_t R, int SR, int K, const int *__restrict__ ray_cnt,
+                                                         const int *__restrict__ ray_off,
+                                                         const int *__restrict__ ray_flag,
+                                                         const int *__restrict__ ray_rank,
+                                                         const float4 *__restrict__ smp_loc,
+                                                         const int *__restrict__ smp_pidx, int *__restrict__ out_pidx,
+                                                         float *__restrict__ out_loc, int8_t *__restrict__ out_mask,
+                                                         int64_t *__restrict__ counters)
+{
+    // one wavefront per ray; lanes stride over the SR*K (and SR*3) outputs of the ray's row
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+    if (r == 0 && lane == 0) counters[PNR_CNT_RAYS_KEPT] = ray_rank[R];
+    if (r >= R) return;
+    const int keep = ray_flag[r];
+    if (lane == 0) out_mask[r] = (int8_t)(keep ? 1 : 0);
+    if (!keep) return;
+    const int64_t row = ray_rank[r];
+    const int cnt = ray_cnt[r], off = ray_off[r];
+    for (int i = lane; i < SR * K; i += 64) {
+        int slot = i / K;
+        out_pidx[row * SR * K + i] = slot < cnt ? smp_pidx[((int64_t)off + slot) * K + (i - slot * K)] : -1;
+    }
+    for (int i = lane; i < SR * 3; i += 64) {
+        int slot = i / 3, c = i - slot * 3;
+        float v = 0.f;
+        if (slot < cnt) {
+            float4 p = smp_loc[(int64_t)off + slot];
+            v = c == 0 ? p.x : (c == 1 ? p.y : p.z);
+        }
+        out_loc[row * SR * 3 + i] = v;
+    }
+}
+
+static inline unsigned nblk(int64_t n, int per = TPB) { return (unsigned)std::max<int64_t>(1, (n + per - 1) / per); }
+
+// accumulators (unsigned long long) live behind n_sel: [8..13] as 64-bit words
+static inline unsigned long long *acc_ptr(RenderWs &ws) { return (unsigned long long *)(ws.n_sel + 16); }
+
+int launch_select_expand(const GridView &g, const Camera &cam, const float *d_dirs, const float *d_raypos,
+                         int64_t R, int D, int SR, const float *d_tmid, int64_t cap, RenderWs &ws,
+                         int64_t *d_counters, hipStream_t stream)
+{
+    PNR_HIP_CHECK(hipMemsetAsync(ws.n_sel, 0, 64 * sizeof(int), stream));
+    PNR_HIP_CHECK(hipMemsetAsync(d_counters, 0, PNR_NUM_COUNTERS * sizeof(int64_t), stream));
+    PNR_HIP_CHECK(hipMemsetAsync(ws.ray_flag, 0, (size_t)(R + 1) * sizeof(int), stream));
+    unsigned long long *acc = acc_ptr(ws);
+    hipLaunchKernelGGL(k_select, dim3(nblk(R, TPB / 64)), dim3(TPB), 0, stream, g, cam, d_dirs, d_raypos, d_tmid, R,
+                       D, SR, ws.ray_cnt, ws.ray_bits, acc + 0);
+    int rc = scan_exclusive_i32(ws.ray_cnt, ws.ray_off, R, nullptr, nullptr, ws.scan_temp, stream);
+    if (rc != PNR_OK) return rc;
+    hipLaunchKernelGGL(k_expand, dim3(nblk(R, TPB / 64)), dim3(TPB), 0, stream, cam, d_dirs, d_raypos, d_tmid, R, D,
+                       SR, ws.ray_off, ws.ray_bits, cap, ws.smp_loc, ws.smp_ray, ws.n_sel, d_counters);
+    PNR_HIP_CHECK(hipGetLastError());
+    return PNR_OK;
+}
+
+int launch_knn(const GridView &g, int K, float radius_limit, RenderWs &ws, int64_t cap, int64_t *d_counters,
+               hipStream_t stream)
+{
+    unsigned long long *acc = acc_ptr(ws);
+    const float r2 = radius_limit * radius_limit;  // fp32, as cu:410
+    // grid-stride over the device-side sample count; enough workgroups to fill the chip
+    const unsigned grid = (unsigned)std::min<int64_t>(nblk(cap), 256 * 32);
+    if (K <= 8)
+        hipLaunchKernelGGL(k_knn<8>, dim3(grid), dim3(TPB), 0, stream, g, K, r2, ws.smp_loc, ws.smp_ray, ws.n_sel,
+                           ws.smp_pidx, ws.smp_valid, ws.ray_flag, acc + 1, acc + 2);
+    else if (K <= 16)
+        hipLaunchKernelGGL(k_knn<16>, dim3(grid), dim3(TPB), 0, stream, g, K, r2, ws.smp_loc, ws.smp_ray, ws.n_sel,
+                           ws.smp_pidx, ws.smp_valid, ws.ray_flag, acc + 1, acc + 2);
+    else
+        hipLaunchKernelGGL(k_knn<32>, dim3(grid), dim3(TPB), 0, stream, g, K, r2, ws.smp_loc, ws.smp_ray, ws.n_sel,
+                           ws.smp_pidx, ws.smp_valid, ws.ray_flag, acc + 1, acc + 2);
+    int rc = scan_exclusive_i32(ws.smp_valid, ws.smp_voff, cap, ws.n_sel, nullptr, ws.scan_temp, stream);
+    if (rc != PNR_OK) return rc;
+    hipLaunchKernelGGL(k_compact_valid, dim3(grid), dim3(TPB), 0, stream, ws.smp_valid, ws.smp_voff, ws.n_sel,
+                       ws.vs_list, d_counters, acc);
+    PNR_HIP_CHECK(hipGetLastError());
+    return PNR_OK;
+}
+
+}  // namespace pnr
+
+using namespace pnr;
+
+extern "C" size_t pnr_query_workspace_bytes(int64_t R, int32_t D, int32_t SR, int32_t K)
+{
+    (void)D;
+    if (R < 1) R = 1;
+    RenderWs ws = carve_render_ws(nullptr, R, R * (int64_t)SR, K);
+    // the shade-only tail (sigma, agg) is not needed by the query
+    return (size_t)(uintptr_t)ws.smp_sigma;
+}
+
+extern "C" int pnr_query_raypos(const pnr_scene_t *scene, const float *d_raypos, int64_t R, int32_t D, int32_t SR,
+                                int32_t K, float radius_limit, int32_t *d_sample_pidx, float *d_sample_loc,
+                                int8_t *d_ray_mask, int64_t *d_counters, void *d_workspace, size_t workspace_bytes,
+                                void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    PNR_REQUIRE(scene && d_raypos && d_sample_pidx && d_sample_loc && d_ray_mask && d_counters && d_workspace,
+                "pnr_query_raypos: null argument");
+    if (!scene->built) {
+        set_error("pnr_query_raypos: scene not built");
+        return PNR_ERR_STATE;
+    }
+    PNR_REQUIRE(R >= 1 && R * (int64_t)SR < (int64_t)0x7FFFFFF0, "pnr_query_raypos: R=%lld out of range", (long long)R);
+    PNR_REQUIRE(D >= 1 && D <= PNR_MAX_D, "pnr_query_raypos: D=%d not in [1,%d]", D, PNR_MAX_D);
+    PNR_REQUIRE(K >= 1 && K <= PNR_MAX_K, "pnr_query_raypos: K=%d not in [1,%d]", K, PNR_MAX_K);
+    PNR_REQUIRE(SR >= 1, "pnr_query_raypos: SR=%d", SR);
+    if (workspace_bytes < pnr_query_workspace_bytes(R, D, SR, K)) {
+        set_error("pnr_query_raypos: workspace of %zu bytes < %zu required", workspace_bytes,
+                  pnr_query_workspace_bytes(R, D, SR, K));
+        return PNR_ERR_WORKSPACE;
+    }
+    const int64_t cap = R * (int64_t)SR;
+    RenderWs ws = carve_render_ws(d_workspace, R, cap, K);
+    Camera cam{};
+    int rc = launch_select_expand(scene->grid, cam, nullptr, d_raypos, R, D, SR, nullptr, cap, ws, d_counters, stream);
+    if (rc != PNR_OK) return rc;
+    rc = launch_knn(scene->grid, K, radius_limit, ws, cap, d_counters, stream);
+    if (rc != PNR_OK) return rc;
+    // rank of every kept ray = exclusive scan of the keep flags (reuses smp_voff as scratch: [R+1] <= [cap+1])
+    int *ray_rank = ws.smp_voff;
+    rc = scan_exclusive_i32(ws.ray_flag, ray_rank, R, nullptr, nullptr, ws.scan_temp, stream);
+    if (rc != PNR_OK) return rc;
+    hipLaunchKernelGGL(k_scatter_compat, dim3(nblk(R, TPB / 64)), dim3(TPB), 0, stream, R, SR, K, ws.ray_cnt,
+                       ws.ray_off, ws.ray_flag, ray_rank, ws.smp_loc, ws.smp_pidx, d_sample_pidx, d_sample_loc,
+                       d_ray_mask, d_counters);
+    PNR_HIP_CHECK(hipGetLastError());
+    return PNR_OK;
+}

@@ -1,0 +1,197 @@
+// Composite stage + the fused render entry point.
+// Replaces studio_model.py:368-399 (ray_dist via cummax, opacity, cumprod transmittance, RGBRenderer,
+// fill_invalid with its torch.nonzero sync) by one pass over each ray's compact sample list, and ties
+// the stages together behind pnr_render (NeuralPoints.forward + PointNerf.get_outputs).
+#include <stdarg.h>
+
+#include <algorithm>
+
+#include "pnr_internal.h"
+
+namespace pnr {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+constexpr int TPB = 256;
+
+// one thread per ray: its samples are contiguous in the compact list, at most SR of them.
+__global__ void __launch_bounds__(TPB) k_composite(Camera cam, pnr_render_opts_t opts, int64_t R,
+                                                    const int *__restrict__ ray_cnt, const int *__restrict__ ray_off,
+                                                    const int *__restrict__ ray_flag,
+                                                    const float4 *__restrict__ smp_loc,
+                                                    const float4 *__restrict__ smp_out, const int *__restrict__ n_sel,
+                                                    float *__restrict__ rgb, float *__restrict__ depth,
+                                                    float *__restrict__ acc_out, int8_t *__restrict__ ray_mask,
+                                                    unsigned long long *__restrict__ n_kept)
+{
+    const int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (r >= R) return;
+    const int S = n_sel[0];
+    const int off = ray_off[r];
+    int cnt = ray_cnt[r];
+    if ((int64_t)off + cnt > S) cnt = max(0, S - off);  // capacity overflow: drop what did not fit
+    const bool keep = ray_flag[r] != 0 && cnt > 0;
+    float cr = 0.f, cg = 0.f, cb = 0.f, acc = 0.f, dsum = 0.f;
+    if (keep) {
+        const float vs = opts.vsize_z;
+        const float two_vs = 2.0f * vs;
+        // camera-space z of a world point: sum_j (p - o)[j] * R[j][2]   (studio_utils.py:137-144)
+        auto zc = [&](float x, float y, float z) {
+            const float sx = x - cam.o[0], sy = y - cam.o[1], sz = z - cam.o[2];
+            return sx * cam.R[2] + sy * cam.R[5] + sz * cam.R[8];
+        };
+        // unfilled slots of the reference's [R,SR,3] tensor hold world (0,0,0) (cu:383): their z
+        const float z_unfilled = zc(0.f, 0.f, 0.f);
+        float4 p = smp_loc[off];
+        float cm = zc(p.x, p.y, p.z);  // running cummax
+        float T = 1.0f;
+        for (int i = 0; i < cnt; ++i) {
+            const float4 o = smp_out[off + i];
+            const float t_i = p.w;
+            float delta;
+            if (i == opts.SR - 1) {
+                delta = vs;  // last slot: torch.full(..., vsize[2])
+            } else {
+                float z_next;
+                if (i + 1 < cnt) {
+                    p = smp_loc[off + i + 1];
+                    z_next = zc(p.x, p.y, p.z);
+                } else {
+                    z_next = z_unfilled;
+                }
+                const float cm_next = fmaxf(cm, z_next);
+                delta = cm_next - cm;
+                cm = cm_next;
+                if (delta < 1e-8f || delta > two_vs) delta = vs;
+            }
+            // samples without neighbours have sigma = 0 (decoded features zero, ray_dist * valid = 0)
+            const float sigma = o.x;
+            const float opacity = 1.0f - expf(-sigma * delta);
+            const float w = opacity * T;
+            T = T * (1.0f - opacity + 1e-10f);
+            cr += w * o.y;
+            cg += w * o.z;
+            cb += w * o.w;
+            acc += w;
+            dsum += w * t_i;
+        }
+    }
+    float o0 = cr + opts.bg[0] * (1.0f - acc);
+    float o1 = cg + opts.bg[1] * (1.0f - acc);
+    float o2 = cb + opts.bg[2] * (1.0f - acc);
+    if (!keep) {
+        o0 = opts.bg[0];
+        o1 = opts.bg[1];
+        o2 = opts.bg[2];
+    } else if (opts.eval_clamp) {
+        o0 = fminf(fmaxf(o0, 0.f), 1.f);
+        o1 = fminf(fmaxf(o1, 0.f), 1.f);
+        o2 = fminf(fmaxf(o2, 0.f), 1.f);
+    }
+    rgb[3 * r] = o0;
+    rgb[3 * r + 1] = o1;
+    rgb[3 * r + 2] = o2;
+    if (depth) depth[r] = keep ? dsum / (acc + 1e-6f) : 0.f;
+    if (acc_out) acc_out[r] = keep ? acc : 0.f;
+    ray_mask[r] = (int8_t)(keep ? 1 : 0);
+    if (keep) atomicAdd(n_kept, 1ull);
+}
+
+__global__ void k_publish_kept(const unsigned long long *__restrict__ n_kept, int64_t *__restrict__ counters)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) counters[PNR_CNT_RAYS_KEPT] = (int64_t)*n_kept;
+}
+
+int launch_composite(const Camera &cam, const pnr_render_opts_t &opts, int64_t R, RenderWs &ws, float *d_rgb,
+                     float *d_depth, float *d_acc, int8_t *d_ray_mask, int64_t *d_counters, hipStream_t stream)
+{
+    unsigned long long *n_kept = (unsigned long long *)(ws.n_sel + 16) + 3;
+    hipLaunchKernelGGL(k_composite, dim3((unsigned)((R + TPB - 1) / TPB)), dim3(TPB), 0, stream, cam, opts, R,
+                       ws.ray_cnt, ws.ray_off, ws.ray_flag, ws.smp_loc, ws.smp_out, ws.n_sel, d_rgb, d_depth, d_acc,
+                       d_ray_mask, n_kept);
+    hipLaunchKernelGGL(k_publish_kept, dim3(1), dim3(64), 0, stream, n_kept, d_counters);
+    PNR_HIP_CHECK(hipGetLastError());
+    return PNR_OK;
+}
+
+}  // namespace pnr
+
+using namespace pnr;
+
+extern "C" const char *pnr_last_error(void) { return g_err; }
+extern "C" int pnr_version(void) { return PNR_VERSION; }
+
+extern "C" size_t pnr_render_workspace_bytes(int64_t R, int64_t cap_samples, int32_t K)
+{
+    if (R < 1) R = 1;
+    if (cap_samples < 1) cap_samples = 1;
+    return carve_render_ws(nullptr, R, cap_samples, K).total;
+}
+
+extern "C" int pnr_render(const pnr_scene_t *scene, const pnr_weights_t *weights, const float *d_dirs, int64_t R,
+                          const pnr_camera_t *cam_, const float *d_tmid, const pnr_render_opts_t *opts,
+                          float *d_rgb, float *d_depth, float *d_acc, int8_t *d_ray_mask, int64_t *d_counters,
+                          void *d_workspace, size_t workspace_bytes, int64_t cap_samples, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    PNR_REQUIRE(scene && weights && d_dirs && cam_ && d_tmid && opts && d_rgb && d_ray_mask && d_counters &&
+                    d_workspace,
+                "pnr_render: null argument");
+    if (!scene->built || !scene->packed) {
+        set_error("pnr_render: scene not built / points not packed");
+        return PNR_ERR_STATE;
+    }
+    if (!weights->packed) {
+        set_error("pnr_render: weights not packed");
+        return PNR_ERR_STATE;
+    }
+    PNR_REQUIRE(R >= 1 && R < (int64_t)0x7FFFFFF0, "pnr_render: R=%lld out of range", (long long)R);
+    PNR_REQUIRE(opts->D >= 1 && opts->D <= PNR_MAX_D, "pnr_render: D=%d not in [1,%d]", opts->D, PNR_MAX_D);
+    PNR_REQUIRE(opts->K >= 1 && opts->K <= PNR_MAX_K, "pnr_render: K=%d not in [1,%d]", opts->K, PNR_MAX_K);
+    PNR_REQUIRE(opts->SR >= 1, "pnr_render: SR=%d", opts->SR);
+    PNR_REQUIRE(cap_samples >= 1 && cap_samples < (int64_t)0x7FFFFFF0 / std::max(opts->K, 1),
+                "pnr_render: cap_samples=%lld out of range", (long long)cap_samples);
+    const size_t need = pnr_render_workspace_bytes(R, cap_samples, opts->K);
+    if (workspace_bytes < need) {
+        set_error("pnr_render: workspace of %zu bytes < %zu required", workspace_bytes, need);
+        return PNR_ERR_WORKSPACE;
+    }
+    RenderWs ws = carve_render_ws(d_workspace, R, cap_samples, opts->K);
+    Camera cam{};
+    for (int i = 0; i < 3; ++i) cam.o[i] = cam_->campos[i];
+    for (int i = 0; i < 9; ++i) cam.R[i] = cam_->camrotc2w[i];
+    int rc = launch_select_expand(scene->grid, cam, d_dirs, nullptr, R, opts->D, opts->SR, d_tmid, cap_samples, ws,
+                                  d_counters, stream);
+    if (rc != PNR_OK) return rc;
+    rc = launch_knn(scene->grid, opts->K, opts->radius_limit, ws, cap_samples, d_counters, stream);
+    if (rc != PNR_OK) return rc;
+    rc = launch_shade(scene, weights, cam, d_dirs, opts->K, ws, cap_samples, stream);
+    if (rc != PNR_OK) return rc;
+    return launch_composite(cam, *opts, R, ws, d_rgb, d_depth, d_acc, d_ray_mask, d_counters, stream);
+}
+
+extern "C" int pnr_render_taps(void *d_workspace, size_t workspace_bytes, int64_t R, int64_t cap_samples, int32_t K,
+                               pnr_render_taps_t *taps)
+{
+    PNR_REQUIRE(d_workspace && taps, "pnr_render_taps: null argument");
+    if (workspace_bytes < pnr_render_workspace_bytes(R, cap_samples, K)) {
+        set_error("pnr_render_taps: workspace too small");
+        return PNR_ERR_WORKSPACE;
+    }
+    RenderWs ws = carve_render_ws(d_workspace, R, cap_samples, K);
+    taps->smp_loc = reinterpret_cast<const float *>(ws.smp_loc);
+    taps->smp_ray = ws.smp_ray;
+    taps->smp_pidx = ws.smp_pidx;
+    taps->smp_out = reinterpret_cast<const float *>(ws.smp_out);
+    taps->ray_cnt = ws.ray_cnt;
+    taps->ray_off = ws.ray_off;
+    return PNR_OK;
+}

@@ -1,0 +1,136 @@
+// Device-wide exclusive scan of int32 (three launches: block reduce, scan of block sums, downsweep).
+// Used for ray -> sample offsets, sample -> valid-sample offsets, brick ranks and voxel starts; n may
+// live in device memory so the render path never returns to the host.
+#include "pnr_internal.h"
+
+namespace pnr {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 16;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;  // 4096 elements per workgroup
+
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// exclusive scan across the block of one value per thread; returns the exclusive prefix, total in *total
+__device__ __forceinline__ int block_excl_scan(int v, int *total, int *smem /* [SCAN_THREADS/64 + 1] */)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = wave_incl_scan(v);
+    if (lane == 63) smem[wave] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_THREADS / 64; ++w) {
+        int s = smem[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_reduce(const int *__restrict__ in, int64_t n_max,
+                                                               const int *__restrict__ n_dev,
+                                                               int *__restrict__ block_sums)
+{
+    __shared__ int smem[SCAN_THREADS / 64 + 1];
+    const int64_t n = n_dev ? min((int64_t)*n_dev, n_max) : n_max;
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i)
+        if (base + i < n) s += in[base + i];
+    int tot;
+    block_excl_scan(s, &tot, smem);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(1024) k_scan_sums(int *__restrict__ block_sums, int nblocks,
+                                                     int64_t *__restrict__ total64)
+{
+    __shared__ int smem[1024 / 64];
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int start = 0; start < nblocks; start += 1024) {
+        int i = start + threadIdx.x;
+        int v = i < nblocks ? block_sums[i] : 0;
+        int incl = wave_incl_scan(v);
+        if (lane == 63) smem[wave] = incl;
+        __syncthreads();
+        int base = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) {
+            int s = smem[w];
+            if (w < wave) base += s;
+            tot += s;
+        }
+        int carry = carry_s;
+        if (i < nblocks) block_sums[i] = carry + base + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        block_sums[nblocks] = carry_s;
+        if (total64) *total64 = carry_s;
+    }
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_down(const int *__restrict__ in, int *__restrict__ out,
+                                                             int64_t n_max, const int *__restrict__ n_dev,
+                                                             const int *__restrict__ block_sums, int nblocks)
+{
+    __shared__ int smem[SCAN_THREADS / 64 + 1];
+    const int64_t n = n_dev ? min((int64_t)*n_dev, n_max) : n_max;
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS];
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        v[i] = (base + i < n) ? in[base + i] : 0;
+        s += v[i];
+    }
+    int tot;
+    int excl = block_excl_scan(s, &tot, smem) + block_sums[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        if (base + i < n) out[base + i] = excl;
+        excl += v[i];
+    }
+    // out[n] = total, written by the thread that owns position n (or the last block when n is a tile multiple)
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = block_sums[nblocks];
+}
+
+size_t scan_temp_bytes(int64_t n_max)
+{
+    int64_t nblocks = (n_max + SCAN_TILE - 1) / SCAN_TILE;
+    if (nblocks < 1) nblocks = 1;
+    return ((size_t)(nblocks + 1) * sizeof(int) + 255) & ~(size_t)255;
+}
+
+int scan_exclusive_i32(const int *in, int *out, int64_t n_max, const int *n_dev, int64_t *total64, void *temp,
+                       hipStream_t stream)
+{
+    int64_t nb = (n_max + SCAN_TILE - 1) / SCAN_TILE;
+    if (nb < 1) nb = 1;
+    int *sums = (int *)temp;
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, stream, in, n_max, n_dev, sums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, sums, (int)nb, total64);
+    hipLaunchKernelGGL(k_scan_down, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, stream, in, out, n_max, n_dev,
+                       sums, (int)nb);
+    PNR_HIP_CHECK(hipGetLastError());
+    return PNR_OK;
+}
+
+}  // namespace pnr

@@ -1,0 +1,441 @@
+// Scene build: the persistent voxel structure + the packed point table.
+//
+// Replaces claim_occ / map_coor2occ / fill_occ2pnts (query_worldcoords.cu:18-162), which the reference
+// re-runs over all N points for EVERY 2304-ray chunk (cu:314-365, ~130 MB of fills per call), by one
+// build per point-cloud version.  Semantics are the canonical sequential ones of SURVEY.md 8a-note:
+// per-voxel lists in ascending point index, first P kept; the voxel of the first in-grid point is
+// emptied when compat_drop_voxel0 (the reference's `voxel_idx > 0`, cu:147); all occupied voxels are
+// kept even beyond max_o (flagged in info[1]).  Every step is order-independent (bit-OR, integer
+// counts, per-voxel selection of the P smallest indices), so the structure is bitwise deterministic.
+#include <algorithm>
+
+#include "pnr_internal.h"
+
+namespace pnr {
+
+constexpr int TPB = 256;
+
+// ---- B1: cell of every point, raw occupancy bits, first in-grid point -------------------------------
+__global__ void __launch_bounds__(TPB) k_point_cells(const float *__restrict__ xyz, int64_t N, GridView g,
+                                                      uint32_t *__restrict__ pt_cell,
+                                                      unsigned long long *__restrict__ occ_all,
+                                                      int *__restrict__ first_valid,
+                                                      unsigned long long *__restrict__ n_inside)
+{
+    int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= N) return;
+    int cx, cy, cz;
+    bool ok = cell_of(g, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], cx, cy, cz);
+    uint32_t code = 0xFFFFFFFFu;
+    if (ok) {
+        int brick, bit;
+        brick_of(g, cx, cy, cz, brick, bit);
+        code = ((uint32_t)brick << 6) | (uint32_t)bit;
+        atomicOr(&occ_all[brick], 1ull << bit);
+        atomicMin(first_valid, (int)i);
+        atomicAdd(n_inside, 1ull);
+    }
+    pt_cell[i] = code;
+}
+
+// ---- B2: occupancy used for point lookup = raw occupancy minus the compat-dropped voxel --------------
+__global__ void k_drop_voxel0(const uint32_t *__restrict__ pt_cell, const int *__restrict__ first_valid,
+                              int64_t N, int compat, unsigned long long *__restrict__ occ_pts,
+                              long long *__restrict__ dropped_code)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int fv = *first_valid;
+    *dropped_code = -1;
+    if (compat && fv >= 0 && fv < N) {
+        uint32_t code = pt_cell[fv];
+        occ_pts[code >> 6] &= ~(1ull << (code & 63));
+        *dropped_code = code;
+    }
+}
+
+// ---- B3: dilation of the raw occupancy over [c - k/2, c + (k+1)/2) per axis (cu:101-110) --------------
+__global__ void __launch_bounds__(TPB) k_dilate(const unsigned long long *__restrict__ occ_all, GridView g,
+                                                 int q0, int q1, int q2, unsigned long long *__restrict__ occ_dil)
+{
+    int b = blockIdx.x * TPB + threadIdx.x;
+    if (b >= g.nbricks) return;
+    unsigned long long bits = occ_all[b];
+    if (!bits) return;
+    int bz = b % g.bdims[2];
+    int by = (b / g.bdims[2]) % g.bdims[1];
+    int bx = b / (g.bdims[2] * g.bdims[1]);
+    while (bits) {
+        int bit = __builtin_ctzll(bits);
+        bits &= bits - 1;
+        int cx = bx * 4 + (bit >> 4), cy = by * 4 + ((bit >> 2) & 3), cz = bz * 4 + (bit & 3);
+        for (int x = max(0, cx - q0 / 2); x < min(g.dims[0], cx + (q0 + 1) / 2); ++x)
+            for (int y = max(0, cy - q1 / 2); y < min(g.dims[1], cy + (q1 + 1) / 2); ++y)
+                for (int z = max(0, cz - q2 / 2); z < min(g.dims[2], cz + (q2 + 1) / 2); ++z) {
+                    int nb, nbit;
+                    brick_of(g, x, y, z, nb, nbit);
+                    atomicOr(&occ_dil[nb], 1ull << nbit);
+                }
+    }
+}
+
+// ---- B4: per-brick popcount (scanned into ranks) and record assembly ----------------------------------
+__global__ void __launch_bounds__(TPB) k_brick_popc(const unsigned long long *__restrict__ occ_pts, int nbricks,
+                                                     int *__restrict__ popc)
+{
+    int b = blockIdx.x * TPB + threadIdx.x;
+    if (b < nbricks) popc[b] = __popcll(occ_pts[b]);
+}
+
+__global__ void __launch_bounds__(TPB) k_make_recs(const unsigned long long *__restrict__ occ_pts,
+                                                    const int *__restrict__ rank, int nbricks,
+                                                    BrickRec *__restrict__ rec)
+{
+    int b = blockIdx.x * TPB + threadIdx.x;
+    if (b >= nbricks) return;
+    BrickRec r;
+    r.bits = occ_pts[b];
+    r.rank = (uint32_t)rank[b];
+    r.pad = 0;
+    rec[b] = r;
+}
+
+__device__ __forceinline__ int voxel_of_code(const BrickRec *__restrict__ rec, uint32_t code)
+{
+    if (code == 0xFFFFFFFFu) return -1;
+    BrickRec r = rec[code >> 6];
+    unsigned long long m = 1ull << (code & 63);
+    if (!(r.bits & m)) return -1;
+    return (int)r.rank + __popcll(r.bits & (m - 1));
+}
+
+// ---- B5: points per voxel ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(TPB) k_count_points(const uint32_t *__restrict__ pt_cell, int64_t N,
+                                                       const BrickRec *__restrict__ rec, int *__restrict__ cnt)
+{
+    int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= N) return;
+    int v = voxel_of_code(rec, pt_cell[i]);
+    if (v >= 0) atomicAdd(&cnt[v], 1);
+}
+
+__global__ void __launch_bounds__(TPB) k_cap_counts(const int *__restrict__ cnt, int nvox, int P,
+                                                     int *__restrict__ capped)
+{
+    int v = blockIdx.x * TPB + threadIdx.x;
+    if (v < nvox) capped[v] = min(cnt[v], P);
+}
+
+// ---- B6: unordered fill of the full lists, then per-voxel selection of the P smallest indices ----------
+__global__ void __launch_bounds__(TPB) k_fill_lists(const uint32_t *__restrict__ pt_cell, int64_t N,
+                                                     const BrickRec *__restrict__ rec,
+                                                     const int *__restrict__ full_start, int *__restrict__ cursor,
+                                                     int *__restrict__ full_list)
+{
+    int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= N) return;
+    int v = voxel_of_code(rec, pt_cell[i]);
+    if (v < 0) return;
+    int slot = atomicAdd(&cursor[v], 1);
+    full_list[full_start[v] + slot] = (int)i;
+}
+
+// one thread per voxel: repeatedly extract the smallest index larger than the previous one (P passes over
+// the voxel's list).  Lists are short (a few to a few hundred entries) and this runs once per scene.
+__global__ void __launch_bounds__(TPB) k_select_first_p(const int *__restrict__ full_start,
+                                                         const int *__restrict__ full_list,
+                                                         const int *__restrict__ vox_start, int nvox,
+                                                         const float *__restrict__ xyz, float4 *__restrict__ cand)
+{
+    int v = blockIdx.x * TPB + threadIdx.x;
+    if (v >= nvox) return;
+    const int fs = full_start[v], fe = full_start[v + 1];
+    const int os = vox_start[v], oe = vox_start[v + 1];
+    int prev = -1;
+    for (int o = os; o < oe; ++o) {
+        int best = 0x7FFFFFFF;
+        for (int j = fs; j < fe; ++j) {
+            int p = full_list[j];
+            if (p > prev && p < best) best = p;
+        }
+        prev = best;
+        float4 c;
+        c.x = xyz[3 * (int64_t)best];
+        c.y = xyz[3 * (int64_t)best + 1];
+        c.z = xyz[3 * (int64_t)best + 2];
+        c.w = __int_as_float(best);
+        cand[o] = c;
+    }
+}
+
+// ---- packed point rows --------------------------------------------------------------------------------
+// row = [x y z conf | emb[0:32] | color[3] dir[3] 0 0]  (44 floats, 176 bytes, 16-byte aligned pieces)
+__global__ void __launch_bounds__(TPB) k_pack_points(const float *__restrict__ xyz, const float *__restrict__ emb,
+                                                      const float *__restrict__ conf, const float *__restrict__ dir,
+                                                      const float *__restrict__ color, int64_t N,
+                                                      float *__restrict__ rows)
+{
+    // one thread per (point, float4 chunk): 11 chunks per row, coalesced 16-byte stores
+    int64_t t = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    int64_t i = t / 11;
+    int c = (int)(t - i * 11);
+    if (i >= N) return;
+    float4 v;
+    if (c == 0) {
+        v = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], conf ? conf[i] : 1.0f);
+    } else if (c <= 8) {
+        const float *e = emb + i * PNR_FEAT_DIM + (c - 1) * 4;
+        v = make_float4(e[0], e[1], e[2], e[3]);
+    } else if (c == 9) {
+        v = make_float4(color[3 * i], color[3 * i + 1], color[3 * i + 2], dir[3 * i]);
+    } else {
+        v = make_float4(dir[3 * i + 1], dir[3 * i + 2], 0.f, 0.f);
+    }
+    reinterpret_cast<float4 *>(rows)[i * 11 + c] = v;
+}
+
+static inline unsigned nblk(int64_t n) { return (unsigned)((n + TPB - 1) / TPB); }
+
+template <typename T>
+static int dev_alloc(T **p, size_t count, size_t *bytes)
+{
+    size_t b = (count > 0 ? count : 1) * sizeof(T);
+    PNR_HIP_CHECK(hipMalloc((void **)p, b));
+    if (bytes) *bytes += b;
+    return PNR_OK;
+}
+
+static void scene_free_grid(pnr_scene *s)
+{
+    if (s->occ_dil) (void)hipFree(s->occ_dil);
+    if (s->rec) (void)hipFree(s->rec);
+    if (s->vox_start) (void)hipFree(s->vox_start);
+    if (s->cand) (void)hipFree(s->cand);
+    s->occ_dil = nullptr;
+    s->rec = nullptr;
+    s->vox_start = nullptr;
+    s->cand = nullptr;
+    s->built = false;
+}
+
+}  // namespace pnr
+
+using namespace pnr;
+
+extern "C" int pnr_scene_create(pnr_scene_t **out)
+{
+    PNR_REQUIRE(out != nullptr, "pnr_scene_create: out is null");
+    *out = new pnr_scene();
+    return PNR_OK;
+}
+
+extern "C" int pnr_scene_destroy(pnr_scene_t *scene)
+{
+    if (!scene) return PNR_OK;
+    scene_free_grid(scene);
+    if (scene->point_rows) (void)hipFree(scene->point_rows);
+    delete scene;
+    return PNR_OK;
+}
+
+extern "C" int pnr_scene_build(pnr_scene_t *scene, const float *d_xyz, int64_t N, const pnr_grid_params_t *p,
+                               void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    PNR_REQUIRE(scene && d_xyz && p, "pnr_scene_build: null argument");
+    PNR_REQUIRE(N > 0 && N < (int64_t)0x7FFFFFFF, "pnr_scene_build: N=%lld out of range", (long long)N);
+    PNR_REQUIRE(p->P >= 1 && p->P <= 1024, "pnr_scene_build: P=%d out of range", p->P);
+    for (int a = 0; a < 3; ++a) {
+        PNR_REQUIRE(p->dims[a] >= 1, "pnr_scene_build: dims[%d]=%d", a, p->dims[a]);
+        PNR_REQUIRE(p->vox[a] > 0.f, "pnr_scene_build: vox[%d]=%g", a, p->vox[a]);
+        PNR_REQUIRE(p->kernel_size[a] >= 1 && p->kernel_size[a] <= 9 && p->query_size[a] >= 1 &&
+                        p->query_size[a] <= 9,
+                    "pnr_scene_build: kernel/query size out of range");
+    }
+    scene_free_grid(scene);
+    scene->params = *p;
+    scene->N = N;
+    scene->bytes = scene->point_rows ? (size_t)scene->packed_N * PNR_POINT_ROW_FLOATS * sizeof(float) : 0;
+
+    GridView g{};
+    for (int a = 0; a < 3; ++a) {
+        g.shift[a] = p->ranges[a];
+        g.vox[a] = p->vox[a];
+        g.dims[a] = p->dims[a];
+        g.bdims[a] = (p->dims[a] + 3) / 4;
+        g.kernel_size[a] = p->kernel_size[a];
+    }
+    int64_t nbricks64 = (int64_t)g.bdims[0] * g.bdims[1] * g.bdims[2];
+    PNR_REQUIRE(nbricks64 < (1ll << 25), "pnr_scene_build: grid of %lld bricks is too large", (long long)nbricks64);
+    g.nbricks = (int)nbricks64;
+
+    // temporaries
+    uint32_t *pt_cell = nullptr;
+    unsigned long long *occ_all = nullptr, *occ_pts = nullptr, *n_inside = nullptr;
+    int *first_valid = nullptr, *popc = nullptr, *cnt = nullptr, *capped = nullptr, *full_start = nullptr,
+        *cursor = nullptr, *full_list = nullptr;
+    long long *dropped = nullptr;
+    void *scan_tmp = nullptr;
+    int rc = PNR_OK;
+#define TRY(x)                  \
+    do {                        \
+        rc = (x);               \
+        if (rc != PNR_OK) goto done; \
+    } while (0)
+#define TRYHIP(x)                                                                                   \
+    do {                                                                                            \
+        hipError_t _e = (x);                                                                        \
+        if (_e != hipSuccess) {                                                                     \
+            set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #x, hipGetErrorString(_e));        \
+            rc = PNR_ERR_HIP;                                                                       \
+            goto done;                                                                              \
+        }                                                                                           \
+    } while (0)
+    {
+        int64_t nvox64 = 0, total_capped = 0, total_full = 0;
+        long long h_dropped = -1;
+        unsigned long long h_inside = 0;
+        size_t scan_n = (size_t)std::max<int64_t>(nbricks64, N) + 1;
+
+        TRY(dev_alloc(&pt_cell, (size_t)N, nullptr));
+        TRY(dev_alloc(&occ_all, (size_t)g.nbricks, nullptr));
+        TRY(dev_alloc(&occ_pts, (size_t)g.nbricks, nullptr));
+        TRY(dev_alloc(&scene->occ_dil, (size_t)g.nbricks, &scene->bytes));
+        TRY(dev_alloc(&scene->rec, (size_t)g.nbricks, &scene->bytes));
+        TRY(dev_alloc(&first_valid, 1, nullptr));
+        TRY(dev_alloc(&n_inside, 1, nullptr));
+        TRY(dev_alloc(&dropped, 1, nullptr));
+        TRY(dev_alloc(&popc, (size_t)g.nbricks + 1, nullptr));
+        TRYHIP(hipMalloc(&scan_tmp, scan_temp_bytes((int64_t)scan_n)));
+        TRYHIP(hipMemsetAsync(occ_all, 0, sizeof(unsigned long long) * g.nbricks, stream));
+        TRYHIP(hipMemsetAsync(scene->occ_dil, 0, sizeof(unsigned long long) * g.nbricks, stream));
+        TRYHIP(hipMemsetAsync(first_valid, 0x7F, sizeof(int), stream));
+        TRYHIP(hipMemsetAsync(n_inside, 0, sizeof(unsigned long long), stream));
+
+        hipLaunchKernelGGL(k_point_cells, dim3(nblk(N)), dim3(TPB), 0, stream, d_xyz, N, g, pt_cell, occ_all,
+                           first_valid, n_inside);
+        TRYHIP(hipMemcpyAsync(occ_pts, occ_all, sizeof(unsigned long long) * g.nbricks, hipMemcpyDeviceToDevice,
+                              stream));
+        hipLaunchKernelGGL(k_drop_voxel0, dim3(1), dim3(64), 0, stream, pt_cell, first_valid, N,
+                           p->compat_drop_voxel0, occ_pts, dropped);
+        hipLaunchKernelGGL(k_dilate, dim3(nblk(g.nbricks)), dim3(TPB), 0, stream, occ_all, g, p->query_size[0],
+                           p->query_size[1], p->query_size[2], scene->occ_dil);
+        hipLaunchKernelGGL(k_brick_popc, dim3(nblk(g.nbricks)), dim3(TPB), 0, stream, occ_pts, g.nbricks, popc);
+        TRY(scan_exclusive_i32(popc, popc, g.nbricks, nullptr, nullptr, scan_tmp, stream));
+        hipLaunchKernelGGL(k_make_recs, dim3(nblk(g.nbricks)), dim3(TPB), 0, stream, occ_pts, popc, g.nbricks,
+                           scene->rec);
+        {
+            int h_nvox = 0;
+            TRYHIP(hipMemcpyAsync(&h_nvox, popc + g.nbricks, sizeof(int), hipMemcpyDeviceToHost, stream));
+            TRYHIP(hipMemcpyAsync(&h_dropped, dropped, sizeof(long long), hipMemcpyDeviceToHost, stream));
+            TRYHIP(hipMemcpyAsync(&h_inside, n_inside, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+            TRYHIP(hipStreamSynchronize(stream));
+            nvox64 = h_nvox;
+        }
+        g.nvox = (int)nvox64;
+
+        TRY(dev_alloc(&cnt, (size_t)nvox64 + 1, nullptr));
+        TRY(dev_alloc(&capped, (size_t)nvox64 + 1, nullptr));
+        TRY(dev_alloc(&full_start, (size_t)nvox64 + 1, nullptr));
+        TRY(dev_alloc(&cursor, (size_t)nvox64 + 1, nullptr));
+        TRY(dev_alloc(&scene->vox_start, (size_t)nvox64 + 1, &scene->bytes));
+        TRYHIP(hipMemsetAsync(cnt, 0, sizeof(int) * (nvox64 + 1), stream));
+        TRYHIP(hipMemsetAsync(cursor, 0, sizeof(int) * (nvox64 + 1), stream));
+        hipLaunchKernelGGL(k_count_points, dim3(nblk(N)), dim3(TPB), 0, stream, pt_cell, N, scene->rec, cnt);
+        if (nvox64 > 0)
+            hipLaunchKernelGGL(k_cap_counts, dim3(nblk(nvox64)), dim3(TPB), 0, stream, cnt, (int)nvox64, p->P,
+                               capped);
+        TRY(scan_exclusive_i32(cnt, full_start, nvox64, nullptr, nullptr, scan_tmp, stream));
+        TRY(scan_exclusive_i32(capped, scene->vox_start, nvox64, nullptr, nullptr, scan_tmp, stream));
+        {
+            int h_full = 0, h_cap = 0;
+            TRYHIP(hipMemcpyAsync(&h_full, full_start + nvox64, sizeof(int), hipMemcpyDeviceToHost, stream));
+            TRYHIP(hipMemcpyAsync(&h_cap, scene->vox_start + nvox64, sizeof(int), hipMemcpyDeviceToHost, stream));
+            TRYHIP(hipStreamSynchronize(stream));
+            total_full = h_full;
+            total_capped = h_cap;
+        }
+        TRY(dev_alloc(&full_list, (size_t)total_full, nullptr));
+        TRY(dev_alloc(&scene->cand, (size_t)total_capped, &scene->bytes));
+        hipLaunchKernelGGL(k_fill_lists, dim3(nblk(N)), dim3(TPB), 0, stream, pt_cell, N, scene->rec, full_start,
+                           cursor, full_list);
+        if (nvox64 > 0)
+            hipLaunchKernelGGL(k_select_first_p, dim3(nblk(nvox64)), dim3(TPB), 0, stream, full_start, full_list,
+                               scene->vox_start, (int)nvox64, d_xyz, scene->cand);
+        TRYHIP(hipGetLastError());
+        TRYHIP(hipStreamSynchronize(stream));
+
+        g.occ_dil = scene->occ_dil;
+        g.rec = scene->rec;
+        g.vox_start = scene->vox_start;
+        g.cand = scene->cand;
+        scene->grid = g;
+        scene->built = true;
+        // occupied voxels of the reference include the compat-dropped one
+        scene->info[0] = nvox64 + (h_dropped >= 0 ? 1 : 0);
+        scene->info[1] = scene->info[0] > p->max_o;
+        scene->info[2] = total_capped;
+        scene->info[3] = g.nbricks;
+        scene->info[4] = (int64_t)scene->bytes;
+        scene->info[5] = N;
+        scene->info[6] = (int64_t)h_inside;
+        scene->info[7] = h_dropped;
+    }
+done:
+#undef TRY
+#undef TRYHIP
+    (void)hipFree(pt_cell);
+    (void)hipFree(occ_all);
+    (void)hipFree(occ_pts);
+    (void)hipFree(first_valid);
+    (void)hipFree(n_inside);
+    (void)hipFree(dropped);
+    (void)hipFree(popc);
+    (void)hipFree(cnt);
+    (void)hipFree(capped);
+    (void)hipFree(full_start);
+    (void)hipFree(cursor);
+    (void)hipFree(full_list);
+    (void)hipFree(scan_tmp);
+    if (rc != PNR_OK) scene_free_grid(scene);
+    return rc;
+}
+
+extern "C" int pnr_scene_info(const pnr_scene_t *scene, int64_t info[8])
+{
+    PNR_REQUIRE(scene && info, "pnr_scene_info: null argument");
+    if (!scene->built) {
+        set_error("pnr_scene_info: scene not built");
+        return PNR_ERR_STATE;
+    }
+    for (int i = 0; i < 8; ++i) info[i] = scene->info[i];
+    info[4] = (int64_t)scene->bytes;
+    return PNR_OK;
+}
+
+extern "C" int pnr_points_pack(pnr_scene_t *scene, const float *d_xyz, const float *d_embedding,
+                               const float *d_conf, const float *d_dir, const float *d_color, int64_t N,
+                               void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    PNR_REQUIRE(scene && d_xyz && d_embedding && d_dir && d_color, "pnr_points_pack: null argument");
+    PNR_REQUIRE(N > 0 && N < (int64_t)0x7FFFFFFF, "pnr_points_pack: N=%lld out of range", (long long)N);
+    if (scene->built && scene->N != N) {
+        set_error("pnr_points_pack: N=%lld differs from the built scene (%lld)", (long long)N, (long long)scene->N);
+        return PNR_ERR_INVALID;
+    }
+    if (scene->packed_N != N) {
+        if (scene->point_rows) {
+            (void)hipFree(scene->point_rows);
+            scene->bytes -= (size_t)scene->packed_N * PNR_POINT_ROW_FLOATS * sizeof(float);
+            scene->point_rows = nullptr;
+        }
+        PNR_HIP_CHECK(hipMalloc((void **)&scene->point_rows, (size_t)N * PNR_POINT_ROW_FLOATS * sizeof(float)));
+        scene->bytes += (size_t)N * PNR_POINT_ROW_FLOATS * sizeof(float);
+        scene->packed_N = N;
+    }
+    hipLaunchKernelGGL(k_pack_points, dim3(nblk(N * 11)), dim3(TPB), 0, stream, d_xyz, d_embedding, d_conf, d_dir,
+                       d_color, N, scene->point_rows);
+    PNR_HIP_CHECK(hipGetLastError());
+    scene->packed = true;
+    return PNR_OK;
+}

@@ -1,0 +1,559 @@
+// Shade stage: neighbour gather -> dists / inverse-distance weights / positional encodings ->
+// mlp_base -> mlp_head -> density head -> weighted K-aggregation, then the colour MLP per sample.
+// Replaces studio_utils.py:190-207 (w2pers over ALL N points + five index_select gathers) and
+// studio_model.py:270-365 (boolean compactions, [M,284] / [M,263] materialisations, rocBLAS GEMMs).
+//
+// MI355X design (exact fp32: v_mfma_f32_32x32x2_f32 is bit-for-bit an fp32 fma chain):
+//   * The MLP is evaluated TRANSPOSED, H^T = W . X^T: the weights are the MFMA A operand (output
+//     features on the 32 tile rows), the (sample, neighbour) rows sit on the 32 tile COLUMNS = lanes.
+//     The 32x32 accumulator layout (col = lane&31, row = (r&3) + 8(r>>2) + 4(lane>>5)) is then
+//     exactly a B operand of the next layer (lane<32 supplies input feature F, lane>=32 feature F+4
+//     of one k-step), so a layer's output registers feed the next layer with NO data movement:
+//     no LDS round trip, no barrier, no transposition, activations never leave the VGPR file.
+//     The k-order this implies is baked into the packed weights (pnr_weights_pack).
+//   * One wavefront owns 32 rows (4 samples x K=8 neighbours) and all 256 features:
+//     128 accumulator VGPRs + 128..144 input VGPRs, one wave per SIMD, four waves per CU.
+//   * Weights (1.08 MB for the four 256-wide layers) are L2-resident and streamed straight into VGPRs:
+//     one coalesced 1-KiB dwordx4 load feeds 4 MFMAs (256 cycles); a rolling window of loads stays in flight.
+//   * The gather reads one 176-byte packed row per neighbour (three 16-byte-aligned pieces per lane);
+//     the two lanes that share a row (l and l+32) split its features, so no positional encoding is
+//     computed twice.
+//   * K-aggregation is a segmented butterfly over the 8 lanes of a sample (DPP/shuffle), in registers.
+#include <algorithm>
+
+#include "pnr_internal.h"
+
+namespace pnr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WAVES = 4;
+constexpr int TPB = WAVES * 64;
+constexpr int PF = 6;  // weight loads (1 KiB each per wave) kept in flight
+
+__device__ __forceinline__ float leaky(float x) { return x > 0.f ? x : 0.1f * x; }
+
+struct ShadeParams {
+    const float4 *point_rows;  // [N, 11] float4
+    const float *wbuf;         // packed weights
+    size_t wbytes;
+    size_t w_off[9];
+    size_t b_off[9];
+    float Rw2c[9];
+    Camera cam;
+    const float *dirs;
+    const float4 *smp_loc;
+    const int *smp_ray;
+    const int *smp_pidx;
+    const int *vs_list;
+    const int *n_sel;  // [1] = S_valid
+    float *smp_sigma;  // [S_valid]
+    float *agg;        // [S_valid, 256]
+    float4 *smp_out;   // [S_sel]
+    int K;
+};
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// 16 bytes per lane of packed weights: buffer load with the (wave-uniform) byte offset in an SGPR, so the
+// ~1000 loads of an unrolled layer share ONE address VGPR (lane * 16).  With 64-bit global addresses hipcc
+// hoists a distinct address pair per load out of the tile loop and spills ~2000 VGPRs.
+__device__ __forceinline__ float4 load_w(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+// One dense layer on the matrix cores.  in[KSP] are this lane's B-operand registers (k-step t: the lane
+// supplies one input feature of its row), out[MT*16] the accumulators.  The layer's packed A operands
+// ([MT][KSP/4][64 lanes] float4) start at byte offset wbase of the weight buffer.  Bias is pre-loaded into
+// the accumulators.
+template <int KSP, int MT>
+__device__ __forceinline__ void dense_layer(__amdgpu_buffer_rsrc_t rsrc, int wbase, const float *__restrict__ bias,
+                                            int lane, const float (&in)[KSP], float (&out)[MT * 16])
+{
+    static_assert(KSP % 4 == 0, "k-steps are packed in groups of 4");
+    constexpr int KG = KSP / 4;
+    constexpr int NG = MT * KG;
+    const int h = lane >> 5;
+    const int voff = lane * 16;
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 b = *reinterpret_cast<const float4 *>(bias + 32 * m + 8 * q + 4 * h);
+            acc[m][4 * q + 0] = b.x;
+            acc[m][4 * q + 1] = b.y;
+            acc[m][4 * q + 2] = b.z;
+            acc[m][4 * q + 3] = b.w;
+        }
+    }
+    float4 wq[PF];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) wq[p] = load_w(rsrc, voff, wbase + p * 1024);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int m = g / KG, kg = g % KG;
+        const float4 w = wq[g % PF];
+        if (g + PF < NG) wq[g % PF] = load_w(rsrc, voff, wbase + (g + PF) * 1024);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, in[4 * kg + 0], acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, in[4 * kg + 1], acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, in[4 * kg + 2], acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, in[4 * kg + 3], acc[m], 0, 0, 0);
+        // pin the schedule: keep the rolling window of PF loads in flight, nothing hoisted further
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[m * 16 + r] = acc[m][r];
+}
+
+__device__ __forceinline__ void rot_rows(const float (&M)[9], float x, float y, float z, float &ox, float &oy,
+                                         float &oz)
+{
+    // v @ M^T : out[i] = sum_j v[j] * M[i][j]
+    ox = x * M[0] + y * M[1] + z * M[2];
+    oy = x * M[3] + y * M[4] + z * M[5];
+    oz = x * M[6] + y * M[7] + z * M[8];
+}
+
+__device__ __forceinline__ void to_cam(const Camera &cam, float x, float y, float z, float &cx, float &cy, float &cz)
+{
+    // (p - o) @ Rc2w : out[i] = sum_j s[j] * R[j][i]      (studio_utils.py:129-144)
+    const float sx = x - cam.o[0], sy = y - cam.o[1], sz = z - cam.o[2];
+    cx = sx * cam.R[0] + sy * cam.R[3] + sz * cam.R[6];
+    cy = sx * cam.R[1] + sy * cam.R[4] + sz * cam.R[7];
+    cz = sx * cam.R[2] + sy * cam.R[5] + sz * cam.R[8];
+}
+
+// sum over the K lanes of one sample (lanes [g*K, g*K+K) inside each 32-lane half)
+template <bool POW2_8>
+__device__ __forceinline__ float seg_sum(float v, int K, int lane)
+{
+    if (POW2_8) {
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        return v;
+    } else {
+        const int j = lane & 31;
+        const int base = (lane & 32) + (j / K) * K;
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s += __shfl(v, min(base + k, 63), 64);
+        return s;
+    }
+}
+
+template <bool K8>
+__global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int K = K8 ? 8 : P.K;
+    const int SPW = 32 / K;          // samples per wave
+    const int SPT = SPW * WAVES;     // samples per workgroup tile
+    const int S_valid = P.n_sel[1];
+    const int ntiles = (S_valid + SPT - 1) / SPT;
+    // contiguous tile range per workgroup: neighbouring samples (same / adjacent rays) stay on one XCD's L2
+    const int t_begin = (int)(((int64_t)ntiles * blockIdx.x) / gridDim.x);
+    const int t_end = (int)(((int64_t)ntiles * (blockIdx.x + 1)) / gridDim.x);
+
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wbuf), 0, (int)P.wbytes, 0x00020000);
+    const int w0_ = (int)(P.w_off[0] * 4), w1_ = (int)(P.w_off[1] * 4), w2_ = (int)(P.w_off[2] * 4),
+              w3_ = (int)(P.w_off[3] * 4);
+    const float *b0 = P.wbuf + P.b_off[0], *b1 = P.wbuf + P.b_off[1], *b2 = P.wbuf + P.b_off[2],
+                *b3 = P.wbuf + P.b_off[3];
+    const float *w4 = P.wbuf + P.w_off[4];
+    const float b4 = P.wbuf[P.b_off[4]];
+
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        // opaque per iteration: otherwise the ~1000 scalar load offsets are hoisted out of this loop and
+        // spilled to VGPR lanes
+        int w0 = w0_, w1 = w1_, w2 = w2_, w3 = w3_;
+        asm volatile("" : "+s"(w0), "+s"(w1), "+s"(w2), "+s"(w3));
+        // ---- which (sample, neighbour) row does this lane carry --------------------------------------
+        const int sl = j / K;  // sample slot inside the wave
+        const int v_idx = tile * SPT + wave * SPW + sl;
+        const bool row_ok = (j < SPW * K) && (v_idx < S_valid);
+        const int s = row_ok ? P.vs_list[v_idx] : 0;
+        const int slot = j - sl * K;
+        int pidx = row_ok ? P.smp_pidx[(int64_t)s * K + slot] : -1;
+        const bool valid = pidx >= 0;
+        pidx = max(pidx, 0);
+        const float4 *row = P.point_rows + (int64_t)pidx * 11;
+        const float4 a0 = row[0];
+        const float4 e0 = row[1 + 4 * h], e1 = row[2 + 4 * h], e2 = row[3 + 4 * h], e3 = row[4 + 4 * h];
+        const float4 c0 = row[9], c1 = row[10];
+        const float4 loc = P.smp_loc[s];
+        const int ray = P.smp_ray[s];
+        const float dirx = P.dirs[3 * (int64_t)ray], diry = P.dirs[3 * (int64_t)ray + 1],
+                    dirz = P.dirs[3 * (int64_t)ray + 2];
+
+        // ---- dists + inverse-distance weight (studio_model.py:270-286,467-475) ------------------------
+        const float dwx = a0.x - loc.x, dwy = a0.y - loc.y, dwz = a0.z - loc.z;
+        const float nrm = sqrtf(dwx * dwx + dwy * dwy + dwz * dwz);
+        float wgt = valid ? 1.0f / fmaxf(nrm, 1e-6f) : 0.f;
+        const float wsum = seg_sum<K8>(wgt, K, lane);
+        wgt = wgt / fmaxf(wsum, 1e-8f);
+
+        float dd0, dd1, dd2;
+        if (h == 0) {
+            rot_rows(P.Rw2c, dwx, dwy, dwz, dd0, dd1, dd2);  // dists[:3] @ Rw2c^T   (studio_model.py:313)
+        } else {
+            float pcx, pcy, pcz, scx, scy, scz;
+            to_cam(P.cam, a0.x, a0.y, a0.z, pcx, pcy, pcz);
+            to_cam(P.cam, loc.x, loc.y, loc.z, scx, scy, scz);
+            const float ppx = pcx / pcz, ppy = pcy / pcz, spx = scx / scz, spy = scy / scz;
+            dd0 = ppx * pcz - spx * scz;
+            dd1 = ppy * pcz - spy * scz;
+            dd2 = pcz - scz;
+        }
+
+        // ---- layer-1 input: [emb | PE(emb,3) | PE(dists6,5)], 142 k-steps (+2 zero) --------------------
+        float x0[144];
+        {
+            const float e[16] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w,
+                                 e2.x, e2.y, e2.z, e2.w, e3.x, e3.y, e3.z, e3.w};
+#pragma unroll
+            for (int d = 0; d < 16; ++d) x0[d] = e[d];
+#pragma unroll
+            for (int d = 0; d < 16; ++d) {
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {
+                    float sn, cs;
+                    sincosf(e[d] * (float)(1 << f), &sn, &cs);
+                    x0[16 + (d * 3 + f) * 2 + 0] = sn;
+                    x0[16 + (d * 3 + f) * 2 + 1] = cs;
+                }
+            }
+            const float dd[3] = {dd0, dd1, dd2};
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+#pragma unroll
+                for (int f = 0; f < 5; ++f) {
+                    float sn, cs;
+                    sincosf(dd[d] * (float)(1 << f), &sn, &cs);
+                    x0[112 + (d * 5 + f) * 2 + 0] = sn;
+                    x0[112 + (d * 5 + f) * 2 + 1] = cs;
+                }
+            }
+            x0[142] = 0.f;
+            x0[143] = 0.f;
+        }
+
+        // ---- mlp_base (284 -> 256 -> 256), mlp_head (263 -> 256 -> 256) --------------------------------
+        float hA[128];
+        dense_layer<144, 8>(rsrc, w0, b0, lane, x0, hA);
+#pragma unroll
+        for (int i = 0; i < 128; ++i) hA[i] = leaky(hA[i]);
+        float hB[132];
+        {
+            float tmp[128];
+            dense_layer<128, 8>(rsrc, w1, b1, lane, hA, tmp);
+#pragma unroll
+            for (int i = 0; i < 128; ++i) hB[i] = leaky(tmp[i]);
+        }
+        {
+            // [color(3), dir @ Rw2c^T - view (3), <dir @ Rw2c^T, view> (1)]   (studio_model.py:322-335)
+            float sdx, sdy, sdz, vx, vy, vz;
+            rot_rows(P.Rw2c, c0.w, c1.x, c1.y, sdx, sdy, sdz);
+            rot_rows(P.Rw2c, dirx, diry, dirz, vx, vy, vz);
+            const float dv0 = sdx - vx, dv1 = sdy - vy, dv2 = sdz - vz;
+            const float dot = sdx * vx + sdy * vy + sdz * vz;
+            hB[128] = h ? c0.y : c0.x;
+            hB[129] = h ? dv0 : c0.z;
+            hB[130] = h ? dv2 : dv1;
+            hB[131] = h ? 0.f : dot;
+        }
+        dense_layer<132, 8>(rsrc, w2, b2, lane, hB, hA);
+#pragma unroll
+        for (int i = 0; i < 128; ++i) hA[i] = leaky(hA[i]);
+        float hC[128];
+        dense_layer<128, 8>(rsrc, w3, b3, lane, hA, hC);
+#pragma unroll
+        for (int i = 0; i < 128; ++i) hC[i] = leaky(hC[i]);
+
+        // ---- density head: alpha_k = relu(<w4, h> + b4) (studio_model.py:337) ---------------------------
+        float part = 0.f;
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 wv = *reinterpret_cast<const float4 *>(w4 + 32 * m + 8 * q + 4 * h);
+                part += hC[m * 16 + 4 * q + 0] * wv.x;
+                part += hC[m * 16 + 4 * q + 1] * wv.y;
+                part += hC[m * 16 + 4 * q + 2] * wv.z;
+                part += hC[m * 16 + 4 * q + 3] * wv.w;
+            }
+        part += __shfl_xor(part, 32, 64);
+        const float alpha = fmaxf(part + b4, 0.f);
+
+        // ---- weighted K-aggregation (studio_model.py:344,353) ------------------------------------------
+        const float sigma = seg_sum<K8>(alpha * wgt, K, lane);
+        const bool writer = row_ok && slot == 0;
+        if (writer && h == 0) P.smp_sigma[v_idx] = sigma;
+        float *dst = P.agg + (int64_t)v_idx * 256;
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 o;
+                o.x = seg_sum<K8>(hC[m * 16 + 4 * q + 0] * wgt, K, lane);
+                o.y = seg_sum<K8>(hC[m * 16 + 4 * q + 1] * wgt, K, lane);
+                o.z = seg_sum<K8>(hC[m * 16 + 4 * q + 2] * wgt, K, lane);
+                o.w = seg_sum<K8>(hC[m * 16 + 4 * q + 3] * wgt, K, lane);
+                if (writer) *reinterpret_cast<float4 *>(dst + 32 * m + 8 * q + 4 * h) = o;
+            }
+    }
+}
+
+// Colour MLP: one lane-column per valid sample, 32 samples per wavefront.
+// input 280 = [agg(256) | sin(view*2^f) (12) | cos(...) (12)] -> 128 -> 128 -> 128 -> 3, sigmoid, widen.
+__global__ void __launch_bounds__(TPB, 1) k_shade_color(ShadeParams P)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int S_valid = P.n_sel[1];
+    constexpr int SPT = 32 * WAVES;
+    const int ntiles = (S_valid + SPT - 1) / SPT;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wbuf), 0, (int)P.wbytes, 0x00020000);
+    const int w5_ = (int)(P.w_off[5] * 4), w6_ = (int)(P.w_off[6] * 4), w7_ = (int)(P.w_off[7] * 4);
+    const float *b5 = P.wbuf + P.b_off[5], *b6 = P.wbuf + P.b_off[6], *b7 = P.wbuf + P.b_off[7];
+    const float *w8 = P.wbuf + P.w_off[8];
+    const float *b8 = P.wbuf + P.b_off[8];
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int w5 = w5_, w6 = w6_, w7 = w7_;
+        asm volatile("" : "+s"(w5), "+s"(w6), "+s"(w7));
+        const int v_idx = tile * SPT + wave * 32 + j;
+        const bool ok = v_idx < S_valid;
+        const int s = ok ? P.vs_list[v_idx] : 0;
+        const int ray = P.smp_ray[s];
+        const float *src = P.agg + (int64_t)(ok ? v_idx : 0) * 256;
+        float x[140];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            const float4 a = *reinterpret_cast<const float4 *>(src + 8 * c + 4 * h);
+            x[4 * c + 0] = a.x;
+            x[4 * c + 1] = a.y;
+            x[4 * c + 2] = a.z;
+            x[4 * c + 3] = a.w;
+        }
+        float vx, vy, vz;
+        rot_rows(P.Rw2c, P.dirs[3 * (int64_t)ray], P.dirs[3 * (int64_t)ray + 1], P.dirs[3 * (int64_t)ray + 2], vx, vy,
+                 vz);
+        const float vv[3] = {vx, vy, vz};
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                float sn, cs;
+                sincosf(vv[d] * (float)(1 << f), &sn, &cs);
+                x[128 + d * 4 + f] = h ? cs : sn;
+            }
+        float hA[64], hB[64];
+        dense_layer<140, 4>(rsrc, w5, b5, lane, x, hA);
+#pragma unroll
+        for (int i = 0; i < 64; ++i) hA[i] = leaky(hA[i]);
+        dense_layer<64, 4>(rsrc, w6, b6, lane, hA, hB);
+#pragma unroll
+        for (int i = 0; i < 64; ++i) hB[i] = leaky(hB[i]);
+        dense_layer<64, 4>(rsrc, w7, b7, lane, hB, hA);
+#pragma unroll
+        for (int i = 0; i < 64; ++i) hA[i] = leaky(hA[i]);
+        float rgb[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float part = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 wv = *reinterpret_cast<const float4 *>(w8 + c * 128 + 32 * m + 8 * q + 4 * h);
+                    part += hA[m * 16 + 4 * q + 0] * wv.x;
+                    part += hA[m * 16 + 4 * q + 1] * wv.y;
+                    part += hA[m * 16 + 4 * q + 2] * wv.z;
+                    part += hA[m * 16 + 4 * q + 3] * wv.w;
+                }
+            part += __shfl_xor(part, 32, 64);
+            const float z = part + b8[c];
+            const float sg = 1.0f / (1.0f + expf(-z));
+            rgb[c] = sg * (1.0f + 2.0f * 0.001f) - 0.001f;  // studio_model.py:359
+        }
+        if (ok && h == 0) P.smp_out[s] = make_float4(P.smp_sigma[v_idx], rgb[0], rgb[1], rgb[2]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: PyTorch [out,in] -> MFMA A-operand order (see header comment)
+// ------------------------------------------------------------------------------------------------
+enum LayerKind { L_BASE0 = 0, L_HIDDEN = 1, L_HEAD0 = 2, L_COLOR0 = 3 };
+
+__device__ __forceinline__ int hidden_feat(int t, int h)
+{
+    const int m = t >> 4, r = t & 15;
+    return 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
+}
+
+__device__ int feat_of(int kind, int t, int h, int n_in_hidden)
+{
+    switch (kind) {
+    case L_BASE0:
+        if (t < 16) return 16 * h + t;
+        if (t < 112) {
+            const int u = t - 16, sc = u & 1, df = u >> 1, d = df / 3 + 16 * h, f = df % 3;
+            return 32 + 2 * (d * 3 + f) + sc;
+        }
+        if (t < 142) {
+            const int u = t - 112, sc = u & 1, df = u >> 1, d = df / 5 + 3 * h, f = df % 5;
+            return 224 + 2 * (d * 5 + f) + sc;
+        }
+        return -1;
+    case L_HIDDEN:
+        return t < n_in_hidden / 2 ? hidden_feat(t, h) : -1;
+    case L_HEAD0:
+        if (t < 128) return hidden_feat(t, h);
+        if (t == 128) return h ? 257 : 256;
+        if (t == 129) return h ? 259 : 258;
+        if (t == 130) return h ? 261 : 260;
+        if (t == 131) return h ? -1 : 262;
+        return -1;
+    case L_COLOR0:
+        if (t < 128) return 8 * (t >> 2) + 4 * h + (t & 3);
+        if (t < 140) return (h ? 268 : 256) + (t - 128);
+        return -1;
+    }
+    return -1;
+}
+
+__global__ void k_pack_layer(const float *__restrict__ W, int n_out, int n_in, int kind, int ksp,
+                             float *__restrict__ dst)
+{
+    // dst[((m*KG + g)*64 + lane)*4 + q] = W[32m + (lane&31)][feat(4g+q, lane>>5)]
+    const int kg = ksp / 4, mt = n_out / 32;
+    const int64_t total = (int64_t)mt * kg * 64 * 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i & 3), lane = (int)((i >> 2) & 63);
+        const int64_t mg = i >> 8;
+        const int g = (int)(mg % kg), m = (int)(mg / kg);
+        const int f = feat_of(kind, 4 * g + q, lane >> 5, n_in);
+        dst[i] = (f >= 0 && f < n_in) ? W[(int64_t)(32 * m + (lane & 31)) * n_in + f] : 0.f;
+    }
+}
+
+__global__ void k_copy(const float *__restrict__ src, int n, float *__restrict__ dst)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+int launch_shade(const pnr_scene *scene, const pnr_weights *w, const Camera &cam, const float *d_dirs, int K,
+                 RenderWs &ws, int64_t cap, hipStream_t stream)
+{
+    ShadeParams P{};
+    P.point_rows = reinterpret_cast<const float4 *>(scene->point_rows);
+    P.wbuf = w->buf;
+    P.wbytes = w->bytes;
+    for (int i = 0; i < 9; ++i) {
+        P.w_off[i] = w->w_off[i];
+        P.b_off[i] = w->b_off[i];
+        P.Rw2c[i] = w->Rw2c[i];
+    }
+    P.cam = cam;
+    P.dirs = d_dirs;
+    P.smp_loc = ws.smp_loc;
+    P.smp_ray = ws.smp_ray;
+    P.smp_pidx = ws.smp_pidx;
+    P.vs_list = ws.vs_list;
+    P.n_sel = ws.n_sel;
+    P.smp_sigma = ws.smp_sigma;
+    P.agg = ws.agg;
+    P.smp_out = ws.smp_out;
+    P.K = K;
+    int dev = 0, cus = 256;
+    PNR_HIP_CHECK(hipGetDevice(&dev));
+    PNR_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    // decoded features of samples without neighbours are zero (studio_model.py:361-362)
+    PNR_HIP_CHECK(hipMemsetAsync(ws.smp_out, 0, (size_t)cap * sizeof(float4), stream));
+    const int spt = (32 / K) * WAVES;
+    const int64_t max_tiles = (cap + spt - 1) / spt;
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cus, max_tiles));
+    if (K == 8)
+        hipLaunchKernelGGL(k_shade_pairs<true>, dim3(grid), dim3(TPB), 0, stream, P);
+    else
+        hipLaunchKernelGGL(k_shade_pairs<false>, dim3(grid), dim3(TPB), 0, stream, P);
+    const int64_t ctiles = (cap + 32 * WAVES - 1) / (32 * WAVES);
+    const unsigned cgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cus, ctiles));
+    hipLaunchKernelGGL(k_shade_color, dim3(cgrid), dim3(TPB), 0, stream, P);
+    PNR_HIP_CHECK(hipGetLastError());
+    return PNR_OK;
+}
+
+}  // namespace pnr
+
+using namespace pnr;
+
+extern "C" int pnr_weights_create(pnr_weights_t **out)
+{
+    PNR_REQUIRE(out != nullptr, "pnr_weights_create: out is null");
+    *out = new pnr_weights();
+    return PNR_OK;
+}
+
+extern "C" int pnr_weights_destroy(pnr_weights_t *w)
+{
+    if (!w) return PNR_OK;
+    if (w->buf) (void)hipFree(w->buf);
+    delete w;
+    return PNR_OK;
+}
+
+extern "C" int pnr_weights_pack(pnr_weights_t *w, const float *const d_w[9], const float *const d_b[9],
+                                const float *d_Rw2c, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    PNR_REQUIRE(w && d_w && d_b && d_Rw2c, "pnr_weights_pack: null argument");
+    for (int i = 0; i < 9; ++i) PNR_REQUIRE(d_w[i] && d_b[i], "pnr_weights_pack: tensor %d is null", i);
+    static const int n_out[9] = {256, 256, 256, 256, 1, 128, 128, 128, 3};
+    static const int n_in[9] = {284, 256, 263, 256, 256, 280, 128, 128, 128};
+    static const int ksp[9] = {144, 128, 132, 128, 0, 140, 64, 64, 0};
+    static const int kind[9] = {L_BASE0, L_HIDDEN, L_HEAD0, L_HIDDEN, -1, L_COLOR0, L_HIDDEN, L_HIDDEN, -1};
+    size_t off = 0;
+    for (int i = 0; i < 9; ++i) {
+        w->w_off[i] = off;
+        size_t n = ksp[i] ? (size_t)(n_out[i] / 32) * (ksp[i] / 4) * 256 : (size_t)n_out[i] * n_in[i];
+        off += (n + 63) / 64 * 64;
+    }
+    for (int i = 0; i < 9; ++i) {
+        w->b_off[i] = off;
+        off += ((size_t)n_out[i] + 63) / 64 * 64;
+    }
+    if (!w->buf || w->bytes != off * sizeof(float)) {
+        if (w->buf) (void)hipFree(w->buf);
+        w->buf = nullptr;
+        PNR_HIP_CHECK(hipMalloc((void **)&w->buf, off * sizeof(float)));
+        w->bytes = off * sizeof(float);
+    }
+    for (int i = 0; i < 9; ++i) {
+        if (ksp[i]) {
+            hipLaunchKernelGGL(k_pack_layer, dim3(256), dim3(256), 0, stream, d_w[i], n_out[i], n_in[i], kind[i],
+                               ksp[i], w->buf + w->w_off[i]);
+        } else {
+            int n = n_out[i] * n_in[i];
+            hipLaunchKernelGGL(k_copy, dim3((n + 255) / 256), dim3(256), 0, stream, d_w[i], n, w->buf + w->w_off[i]);
+        }
+        hipLaunchKernelGGL(k_copy, dim3((n_out[i] + 255) / 256), dim3(256), 0, stream, d_b[i], n_out[i],
+                           w->buf + w->b_off[i]);
+    }
+    PNR_HIP_CHECK(hipGetLastError());
+    PNR_HIP_CHECK(hipMemcpyAsync(w->Rw2c, d_Rw2c, 9 * sizeof(float), hipMemcpyDeviceToHost, stream));
+    PNR_HIP_CHECK(hipStreamSynchronize(stream));
+    w->packed = true;
+    return PNR_OK;
+}

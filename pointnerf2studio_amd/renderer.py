@@ -1,0 +1,304 @@
+"""Thin tensor-level wrapper over the C ABI (include/pnr.h): PyTorch-ROCm tensors in, tensors out.
+
+`SceneHIP`   -- persistent voxel structure + packed point table (pnr_scene_*)
+`WeightsHIP` -- MLP weights in MFMA operand order (pnr_weights_*)
+`query_raypos` -- the drop-in op behind `woord_query_grid_point_index`
+`RendererHIP.render` -- NeuralPoints.forward + PointNerf.get_outputs fused (pnr_render)
+
+PyTorch is plumbing here: device memory, streams, and nothing else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+
+MLP_TENSOR_ORDER = [
+    "mlp_base.layers.0", "mlp_base.layers.1", "mlp_head.layers.0", "mlp_head.layers.1",
+    "field_output_density.net",
+    "mlp_color.layers.0", "mlp_color.layers.1", "mlp_color.layers.2", "field_output_color.net",
+]
+MLP_SHAPES = [(256, 284), (256, 256), (256, 263), (256, 256), (1, 256), (128, 280), (128, 128), (128, 128), (3, 128)]
+
+
+def _stream_ptr(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _f32c(t: torch.Tensor, device) -> torch.Tensor:
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def coarse_t_table(D: int, near: float, far: float) -> torch.Tensor:
+    """Ray parameters of the D coarse mid-points at jitter 0, evaluated with the very torch ops of
+    near_far_linear_ray_generation (reference models/rendering/diff_ray_marching.py:307-323) on the host."""
+    tvals = torch.linspace(0, 1, D + 1).view(1, -1)
+    tvals = near * (1 - tvals) + far * tvals
+    seg = (tvals[..., 1:] - tvals[..., :-1]).view(1, 1, D)
+    end = torch.cumsum(seg, dim=2)
+    end = torch.cat([torch.zeros((1, 1, 1)), end], dim=2)
+    end = near + end
+    return ((end[:, :, :-1] + end[:, :, 1:]) / 2).reshape(D).contiguous()
+
+
+@dataclass
+class GridHyper:
+    """Output of NeuralPoints.get_hyperparameters (reference studio_utils.py:115-127)."""
+    ranges: np.ndarray        # float32 [6]
+    scaled_vsize: np.ndarray  # float32 [3]
+    scaled_vdim: np.ndarray   # int32 [3]
+
+
+def grid_hyperparameters(xyz: torch.Tensor, vsize: Sequence[float], vscale: Sequence[int],
+                         kernel_size: Sequence[int], ranges: Sequence[float]) -> GridHyper:
+    """Host-side mirror of get_hyperparameters, including the reference's numpy dtype promotions
+    (the padding and the grid dims are evaluated in float64 from float32 inputs)."""
+    vscale_np = np.array(vscale, dtype=np.int32)
+    scaled_vsize_np = (list(vsize) * vscale_np).astype(np.float32)
+    pts = xyz.detach().reshape(-1, 3)
+    min_xyz = torch.min(pts, dim=0)[0].float().cpu()
+    max_xyz = torch.max(pts, dim=0)[0].float().cpu()
+    rmin = torch.as_tensor(list(ranges[:3]), dtype=torch.float32)
+    rmax = torch.as_tensor(list(ranges[3:]), dtype=torch.float32)
+    min_xyz = torch.max(torch.stack([min_xyz, rmin], 0), 0)[0]
+    max_xyz = torch.min(torch.stack([max_xyz, rmax], 0), 0)[0]
+    pad = torch.as_tensor(scaled_vsize_np * list(kernel_size) / 2, dtype=torch.float32)
+    min_xyz = min_xyz - pad
+    max_xyz = max_xyz + pad
+    rng = torch.cat([min_xyz, max_xyz], dim=-1).numpy().astype(np.float32)
+    vdim = (max_xyz - min_xyz).numpy() / list(vsize)
+    scaled_vdim = np.ceil(vdim / vscale_np).astype(np.int32)
+    return GridHyper(rng, scaled_vsize_np, scaled_vdim)
+
+
+class SceneHIP:
+    """Owns a pnr_scene_t.  Built once per point-cloud version; the reference rebuilds the equivalent
+    structure for every ray chunk (query_worldcoords.cu:314-365)."""
+
+    def __init__(self):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self.lib.pnr_scene_create(C.byref(h)), "pnr_scene_create")
+        self.handle = h
+        self.device = None
+        self.N = 0
+        self.params = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.pnr_scene_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def build(self, xyz: torch.Tensor, ranges, scaled_vsize, scaled_vdim, kernel_size, query_size, P: int,
+              max_o: int, compat_drop_voxel0: bool = True) -> Dict[str, int]:
+        if not xyz.is_cuda:
+            raise RuntimeError("SceneHIP.build: xyz must be a GPU tensor (the HIP path has no CPU fallback)")
+        self.device = xyz.device
+        pts = _f32c(xyz.reshape(-1, 3), self.device)
+        self.N = pts.shape[0]
+        gp = _lib.GridParams()
+        gp.ranges[:] = [float(v) for v in np.asarray(ranges, dtype=np.float32)]
+        gp.vox[:] = [float(v) for v in np.asarray(scaled_vsize, dtype=np.float32)]
+        gp.dims[:] = [int(v) for v in scaled_vdim]
+        gp.kernel_size[:] = [int(v) for v in kernel_size]
+        gp.query_size[:] = [int(v) for v in query_size]
+        gp.P, gp.max_o, gp.compat_drop_voxel0 = int(P), int(max_o), int(bool(compat_drop_voxel0))
+        self.params = gp
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.pnr_scene_build(self.handle, _ptr(pts), self.N, C.byref(gp),
+                                                _stream_ptr(self.device)), "pnr_scene_build")
+        return self.info()
+
+    def info(self) -> Dict[str, int]:
+        arr = (C.c_int64 * 8)()
+        _lib.check(self.lib.pnr_scene_info(self.handle, C.byref(arr)), "pnr_scene_info")
+        names = ["occupied_voxels", "max_o_overflow", "points_in_lists", "bricks", "device_bytes", "N",
+                 "points_inside", "dropped_voxel_code"]
+        return dict(zip(names, [int(v) for v in arr]))
+
+    def pack_points(self, xyz, embedding, conf, direction, color) -> None:
+        """Layouts of the reference's parameters (studio_utils.py:84-90): xyz [N,3], embedding [1,N,32],
+        conf [1,N,1], dir [1,N,3], color [1,N,3]; leading singleton dims are ignored."""
+        dev = self.device if self.device is not None else xyz.device
+        if not xyz.is_cuda:
+            raise RuntimeError("SceneHIP.pack_points: tensors must live on the GPU")
+        self.device = dev
+        x = _f32c(xyz.reshape(-1, 3), dev)
+        N = x.shape[0]
+        e = _f32c(embedding.reshape(N, -1), dev)
+        if e.shape[1] != 32:
+            raise ValueError(f"point_features_dim must be 32, got {e.shape[1]}")
+        c = None if conf is None else _f32c(conf.reshape(N), dev)
+        d = _f32c(direction.reshape(N, 3), dev)
+        col = _f32c(color.reshape(N, 3), dev)
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.pnr_points_pack(self.handle, _ptr(x), _ptr(e), _ptr(c), _ptr(d), _ptr(col), N,
+                                                _stream_ptr(dev)), "pnr_points_pack")
+            torch.cuda.current_stream(dev).synchronize()  # inputs above may be temporaries
+
+
+class WeightsHIP:
+    def __init__(self):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self.lib.pnr_weights_create(C.byref(h)), "pnr_weights_create")
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.pnr_weights_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def pack(self, state: Dict[str, torch.Tensor], Rw2c: torch.Tensor, device) -> None:
+        """state: '<module>.weight' / '<module>.bias' for the nine Linear layers of MLP_TENSOR_ORDER
+        (nerfstudio MLP / FieldHead naming, studio_model.py:193-221)."""
+        ws, bs = [], []
+        for name, shape in zip(MLP_TENSOR_ORDER, MLP_SHAPES):
+            w = _f32c(state[name + ".weight"], device)
+            b = _f32c(state[name + ".bias"], device)
+            if tuple(w.shape) != shape or tuple(b.shape) != (shape[0],):
+                raise ValueError(f"{name}: expected weight {shape}, got {tuple(w.shape)} / bias {tuple(b.shape)}")
+            ws.append(w)
+            bs.append(b)
+        r = _f32c(Rw2c.reshape(3, 3), device)
+        wp = (C.c_void_p * 9)(*[w.data_ptr() for w in ws])
+        bp = (C.c_void_p * 9)(*[b.data_ptr() for b in bs])
+        with torch.cuda.device(device):
+            _lib.check(self.lib.pnr_weights_pack(self.handle, C.byref(wp), C.byref(bp), _ptr(r),
+                                                 _stream_ptr(device)), "pnr_weights_pack")
+
+
+def query_raypos(scene: SceneHIP, raypos: torch.Tensor, SR: int, K: int, radius_limit: float):
+    """woord_query_grid_point_index (reference query_worldcoords.cpp:33-78) on a built scene.
+    raypos [1,R,D,3] -> (sample_pidx int32 [1,R'',SR,K], sample_loc f32 [1,R'',SR,3], ray_mask int8 [1,R],
+    counters dict).  One host sync to learn R'' -- the reference has three (cu:310,382,426)."""
+    lib, dev = scene.lib, raypos.device
+    rp = _f32c(raypos, dev)
+    R, D = rp.shape[-3], rp.shape[-2]
+    pidx = torch.empty((max(R, 1), SR, K), dtype=torch.int32, device=dev)
+    loc = torch.empty((max(R, 1), SR, 3), dtype=torch.float32, device=dev)
+    mask = torch.zeros((max(R, 1),), dtype=torch.int8, device=dev)
+    counters = torch.zeros(_lib.NUM_COUNTERS, dtype=torch.int64, device=dev)
+    if R == 0:
+        return pidx[None, :0], loc[None, :0], mask[None, :0], dict(zip(_lib.COUNTER_NAMES, [0] * 8))
+    nbytes = lib.pnr_query_workspace_bytes(R, D, SR, K)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.pnr_query_raypos(scene.handle, _ptr(rp), R, D, SR, K, float(radius_limit), _ptr(pidx),
+                                        _ptr(loc), _ptr(mask), _ptr(counters), _ptr(ws), nbytes, _stream_ptr(dev)),
+                   "pnr_query_raypos")
+    cnt = counters.cpu().tolist()
+    n = cnt[1]
+    return pidx[None, :n], loc[None, :n], mask[None, :R], dict(zip(_lib.COUNTER_NAMES, cnt))
+
+
+class RendererHIP:
+    """Fused render of one ray bundle.  Owns a growable workspace; `cap_samples` (selected shading samples
+    the workspace can hold) grows automatically when a frame overflows it."""
+
+    def __init__(self, scene: SceneHIP, weights: WeightsHIP, SR: int = 80, K: int = 8, D: int = 400,
+                 radius_limit: float = 0.016, vsize_z: float = 0.004, eval_clamp: bool = True,
+                 bg=(1.0, 1.0, 1.0)):
+        self.lib = _lib.load()
+        self.scene, self.weights = scene, weights
+        self.opts = _lib.RenderOpts()
+        self.opts.SR, self.opts.K, self.opts.D = int(SR), int(K), int(D)
+        self.opts.radius_limit = float(np.float32(radius_limit))
+        self.opts.vsize_z = float(np.float32(vsize_z))
+        self.opts.eval_clamp = int(bool(eval_clamp))
+        self.opts.bg[:] = [float(b) for b in bg]
+        self._ws = None
+        self._ws_key = None
+        self._tmid = {}
+        self.cap_samples = 0
+
+    def _workspace(self, R: int, cap: int, dev):
+        key = (R, cap, self.opts.K)
+        if self._ws is None or self._ws_key != key:
+            nbytes = self.lib.pnr_render_workspace_bytes(R, cap, self.opts.K)
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self._ws_key = key
+            self.cap_samples = cap
+        return self._ws
+
+    def tmid(self, near: float, far: float, dev) -> torch.Tensor:
+        key = (self.opts.D, float(near), float(far), str(dev))
+        if key not in self._tmid:
+            self._tmid[key] = coarse_t_table(self.opts.D, float(near), float(far)).to(dev)
+        return self._tmid[key]
+
+    def render(self, directions: torch.Tensor, campos, camrotc2w, near: float, far: float,
+               cap_samples: Optional[int] = None, sync_counters: bool = True, out: Optional[dict] = None):
+        """directions [R,3] (GPU), campos [3], camrotc2w [3,3] (host or device).  Returns dict with
+        rgb [R,3], depth [R], acc [R], ray_mask [R] int8, counters (dict if sync_counters else tensor)."""
+        dev = directions.device
+        if not directions.is_cuda:
+            raise RuntimeError("RendererHIP.render: directions must be a GPU tensor (no CPU fallback)")
+        d = _f32c(directions.reshape(-1, 3), dev)
+        R = d.shape[0]
+        cam = _lib.CameraC()
+        cam.campos[:] = [float(v) for v in torch.as_tensor(campos).reshape(3).tolist()]
+        cam.camrotc2w[:] = [float(v) for v in torch.as_tensor(camrotc2w).reshape(9).tolist()]
+        cam.near_plane, cam.far_plane = float(near), float(far)
+        tm = self.tmid(near, far, dev)
+        cap = int(cap_samples or self.cap_samples or max(4096, min(R * self.opts.SR, R * 16)))
+        if out is None:
+            out = {
+                "rgb": torch.empty((R, 3), dtype=torch.float32, device=dev),
+                "depth": torch.empty((R,), dtype=torch.float32, device=dev),
+                "acc": torch.empty((R,), dtype=torch.float32, device=dev),
+                "ray_mask": torch.empty((R,), dtype=torch.int8, device=dev),
+                "counters_dev": torch.zeros(_lib.NUM_COUNTERS, dtype=torch.int64, device=dev),
+            }
+        while True:
+            ws = self._workspace(R, cap, dev)
+            with torch.cuda.device(dev):
+                _lib.check(self.lib.pnr_render(
+                    self.scene.handle, self.weights.handle, _ptr(d), R, C.byref(cam), _ptr(tm), C.byref(self.opts),
+                    _ptr(out["rgb"]), _ptr(out["depth"]), _ptr(out["acc"]), _ptr(out["ray_mask"]),
+                    _ptr(out["counters_dev"]), _ptr(ws), ws.numel(), cap, _stream_ptr(dev)), "pnr_render")
+            if not sync_counters:
+                return out
+            cnt = out["counters_dev"].cpu().tolist()
+            out["counters"] = dict(zip(_lib.COUNTER_NAMES, cnt))
+            if cnt[6] == 0:
+                return out
+            # overflow: grow to what the frame actually needs (+12 %) and render again
+            cap = int(cnt[2] * 1.125) + 1024
+
+    def taps(self, R: int):
+        """Views into the last frame's workspace (tests): per selected sample loc+t, ray, pidx, decoded."""
+        t = _lib.RenderTaps()
+        ws = self._ws
+        _lib.check(self.lib.pnr_render_taps(_ptr(ws), ws.numel(), R, self.cap_samples, self.opts.K, C.byref(t)),
+                   "pnr_render_taps")
+        base = ws.data_ptr()
+
+        def view(ptr, nbytes, dtype, shape):
+            off = ptr - base
+            return ws[off:off + nbytes].view(dtype).view(*shape)
+        cap, K = self.cap_samples, self.opts.K
+        return {
+            "smp_loc": view(t.smp_loc, cap * 16, torch.float32, (cap, 4)),
+            "smp_ray": view(t.smp_ray, cap * 4, torch.int32, (cap,)),
+            "smp_pidx": view(t.smp_pidx, cap * K * 4, torch.int32, (cap, K)),
+            "smp_out": view(t.smp_out, cap * 16, torch.float32, (cap, 4)),
+            "ray_cnt": view(t.ray_cnt, R * 4, torch.int32, (R,)),
+            "ray_off": view(t.ray_off, R * 4, torch.int32, (R,)),
+        }
