@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py -- rays/s of the full-image Point-NeRF render hot path on MI355X.
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): synthetic chair-bbox
+neural point cloud of ~6 M points, 800x800 image, D = 400 coarse samples, SR = 80 shading samples per ray,
+K = 8 neighbours, fp32, jitter 0; MLP weights Xavier-initialised (seed 0), density head scaled so that
+opacities are non-trivial.  Datasets / checkpoints are not reachable: data is synthetic, seeded.
+
+One step = N views (N = number of GPUs).  Every view is cut into 16x16-pixel tiles dealt round-robin to the
+N ranks; each rank renders its tiles of every view (N * 640000 / N = 640000 rays per rank per step: weak
+scaling) and ONE all_gather per view (RCCL over xGMI) puts the full RGB+depth image on every rank.
+Inputs (ray directions, point tensors, weights, voxel structure) are resident in HBM before the timed
+region; the timed region covers query + gather + MLPs + composite + all_gather for K steps.
+
+  python bench.py --gpus 1 --steps 8 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (k_shade_pairs, the fp32-MFMA MLP
+chain) against the 157.3 TFLOP/s dense fp32 matrix peak; `cpu_baseline` times the CPU oracle
+(oracle/pnr_oracle.py, the PyTorch-CPU restatement of the reference path) on a bounded sample of the same
+workload on this box's host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from pointnerf2studio_amd import _lib, synthetic  # noqa: E402
+from pointnerf2studio_amd.distributed import gather_image, make_shard  # noqa: E402
+from pointnerf2studio_amd.renderer import (RendererHIP, SceneHIP, WeightsHIP, grid_hyperparameters)  # noqa: E402
+
+FLOPS_PER_PAIR = 542_720       # 2 * (284*256 + 256*256 + 263*256 + 256*256 + 256)   SURVEY.md section 8d
+FLOPS_PER_SAMPLE = 137_984     # 2 * (280*128 + 2*128*128 + 128*3)
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+
+VSIZE = [0.004, 0.004, 0.004]
+VSCALE = [2, 2, 2]
+KSIZE = [3, 3, 3]
+
+
+def cpu_baseline(points, weights, cfgd, n_side, view):
+    """Times the CPU oracle (a port of the reference's PyTorch path) on an n_side x n_side centre window."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pnr_oracle as O
+    O.build_c_oracle()
+    cfg = O.OracleConfig()
+    cfg.SR, cfg.K, cfg.P, cfg.max_o = cfgd["SR"], cfgd["K"], cfgd["P"], cfgd["max_o"]
+    cfg.ranges = list(cfgd["ranges"])
+    H, W = cfgd["H"], cfgd["W"]
+    campos, camrot = synthetic.make_camera(view)
+    y0, x0 = (H - n_side) // 2, (W - n_side) // 2
+    dirs = synthetic.make_rays(H, W, campos, camrot, y0=y0, y1=y0 + n_side, x0=x0, x1=x0 + n_side)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    # warm-up on a sliver (thread pools, oneDNN primitives), then ONE timed pass over the sample
+    O.render(points, weights, cfg, campos[None].expand(64, 3), dirs[:64].contiguous(), 2.0, 6.0, camrot)
+    t0 = time.time()
+    ref = O.render(points, weights, cfg, campos[None].expand(dirs.shape[0], 3), dirs, 2.0, 6.0, camrot)
+    dt = time.time() - t0
+    return dict(value=dirs.shape[0] / dt, unit="rays/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n_side}x{n_side} centre window of view az={view:g} ({dirs.shape[0]} rays) against the full "
+                       f"{points['xyz'].shape[0]}-point cloud, voxel grid rebuilt once for the chunk as the "
+                       f"reference does per chunk, {dt:.1f} s wall",
+                seconds=dt), ref, dirs, campos, camrot
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="cfg1_chair_6m", choices=sorted(synthetic.SCENE_CONFIGS))
+    ap.add_argument("--points", type=int, default=None, help="override the number of points")
+    ap.add_argument("--cpu-rays-side", type=int, default=64, help="side of the CPU-baseline window (0 = skip)")
+    ap.add_argument("--sigma-scale", type=float, default=300.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path is HIP-only (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfgd = dict(synthetic.SCENE_CONFIGS[args.config])
+    if args.points:
+        cfgd["N"] = args.points
+    H, W, SR, K = cfgd["H"], cfgd["W"], cfgd["SR"], cfgd["K"]
+
+    # ---- scene resident in HBM (replicated on every rank) ----------------------------------------------
+    points = synthetic.make_points(cfgd["N"], seed=1234, ranges=cfgd["ranges"])
+    weights = synthetic.make_weights(0, sigma_scale=args.sigma_scale, bias_scale=0.1)
+    xyz = points["xyz"].to(dev)
+    hyp = grid_hyperparameters(xyz, VSIZE, VSCALE, KSIZE, cfgd["ranges"])
+    scene = SceneHIP()
+    t0 = time.time()
+    info = scene.build(xyz, hyp.ranges, hyp.scaled_vsize, hyp.scaled_vdim, KSIZE, KSIZE, cfgd["P"], cfgd["max_o"], True)
+    torch.cuda.synchronize()
+    build_s = time.time() - t0
+    scene.pack_points(xyz, points["embedding"].to(dev), points["conf"].to(dev), points["dir"].to(dev),
+                      points["color"].to(dev))
+    wh = WeightsHIP()
+    wh.pack(weights, points["Rw2c"], dev)
+    rnd = RendererHIP(scene, wh, SR=SR, K=K, D=400, radius_limit=4 * max(VSIZE[0], VSIZE[1]), vsize_z=VSIZE[2])
+
+    # ---- rays: `world` views per step, this rank's tiles of each ----------------------------------------
+    azimuths = [45.0 * i + 20.0 for i in range(8)]
+    shard = make_shard(H, W, world, rank).to(dev)
+    view_dirs, cams = [], []
+    for az in azimuths:
+        campos, camrot = synthetic.make_camera(az)
+        d = synthetic.make_rays(H, W, campos, camrot).to(dev)
+        view_dirs.append(d.index_select(0, shard.pixels).contiguous())
+        cams.append((campos, camrot))
+    n_local = shard.n_pad
+    outs = {
+        "rgb": torch.empty((n_local, 3), dtype=torch.float32, device=dev),
+        "depth": torch.empty((n_local,), dtype=torch.float32, device=dev),
+        "acc": torch.empty((n_local,), dtype=torch.float32, device=dev),
+        "ray_mask": torch.empty((n_local,), dtype=torch.int8, device=dev),
+        "counters_dev": torch.zeros(_lib.NUM_COUNTERS, dtype=torch.int64, device=dev),
+    }
+    local4 = torch.empty((n_local, 4), dtype=torch.float32, device=dev)
+    gathered = torch.empty((world * n_local, 4), dtype=torch.float32, device=dev)
+    image = torch.empty((H * W, 4), dtype=torch.float32, device=dev)
+
+    # capacity: size the workspace once from the heaviest view (untimed)
+    cap = 0
+    for v in range(len(azimuths)):
+        o = rnd.render(view_dirs[v], cams[v][0], cams[v][1], 2.0, 6.0, out=outs)
+        cap = max(cap, o["counters"]["samples_selected"])
+    cap = int(cap * 1.05) + 4096
+    rnd.render(view_dirs[0], cams[0][0], cams[0][1], 2.0, 6.0, cap_samples=cap, out=outs)
+
+    lib = _lib.load()
+    stage_ms = (C.c_float * _lib.NUM_STAGES)()
+    acc_ms = [0.0] * _lib.NUM_STAGES
+    acc_cnt = [0] * _lib.NUM_COUNTERS
+    n_launch = 0
+
+    def step(s, timed):
+        nonlocal n_launch
+        for i in range(world):
+            v = (s * world + i) % len(azimuths)
+            rnd.render(view_dirs[v], cams[v][0], cams[v][1], 2.0, 6.0, cap_samples=cap, sync_counters=False, out=outs)
+            local4[:, :3].copy_(outs["rgb"])
+            local4[:, 3].copy_(outs["depth"])
+            gather_image(local4, shard, out=image, gathered=gathered)
+            if timed:
+                # stage times come from HIP events recorded on the render stream (no extra kernels);
+                # reading them waits for this render only
+                _lib.check(lib.pnr_profile_last_ms(C.byref(stage_ms)), "pnr_profile_last_ms")
+                for k in range(_lib.NUM_STAGES):
+                    acc_ms[k] += stage_ms[k]
+                c = outs["counters_dev"].tolist()
+                for k in range(_lib.NUM_COUNTERS):
+                    acc_cnt[k] += c[k]
+                n_launch += 1
+
+    for s in range(args.warmup):
+        step(s, False)
+    _lib.check(lib.pnr_profile_enable(1), "pnr_profile_enable")
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        step(args.warmup + s, True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    lib.pnr_profile_enable(0)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    rays_per_step = world * H * W
+    value = rays_per_step * args.steps / elapsed
+
+    if rank == 0:
+        pairs, samples = acc_cnt[4], acc_cnt[3]
+        t_pairs = acc_ms[2] / 1e3
+        achieved = pairs * FLOPS_PER_PAIR / t_pairs / 1e12 if t_pairs > 0 else 0.0
+        result = {
+            "metric": "rays_per_sec", "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"{args.config}: chair-bbox synthetic cloud N={cfgd['N']}, {H}x{W} image, D=400, "
+                            f"SR={SR}, K={K}, P={cfgd['P']}, jitter=0, {world} view(s)/step",
+                "rays_per_step": rays_per_step, "global_batch": rays_per_step,
+                "parallelism": f"ray-tile shard x{world} (16x16 tiles round-robin) + all_gather per view",
+            },
+            "roofline": {
+                "bound": "mfma", "kernel": "k_shade_pairs",
+                "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                "traffic": None,
+                "avg_launch_ms": acc_ms[2] / max(n_launch, 1),
+                "valid_pairs_per_launch": pairs / max(n_launch, 1),
+                "flops_per_pair": FLOPS_PER_PAIR,
+            },
+            "stages_ms_per_launch": {n: acc_ms[i] / max(n_launch, 1) for i, n in enumerate(_lib.STAGE_NAMES)},
+            "counters_per_launch": {n: acc_cnt[i] / max(n_launch, 1) for i, n in enumerate(_lib.COUNTER_NAMES)},
+            "color_mlp_tflops": (samples * FLOPS_PER_SAMPLE / (acc_ms[3] / 1e3) / 1e12) if acc_ms[3] > 0 else None,
+            "scene": {"occupied_voxels": info["occupied_voxels"], "points_in_voxel_lists": info["points_in_lists"],
+                      "structure_bytes": info["device_bytes"], "build_s": build_s, "cap_samples": cap},
+        }
+        if world == 1 and args.cpu_rays_side > 0:
+            cb, ref, dirs, campos, camrot = cpu_baseline(points, weights, cfgd, args.cpu_rays_side, azimuths[0])
+            # parity on the very same rays: HIP render vs the oracle that was just timed
+            out = RendererHIP(scene, wh, SR=SR, K=K, D=400, radius_limit=4 * max(VSIZE[0], VSIZE[1]),
+                              vsize_z=VSIZE[2]).render(dirs.to(dev), campos, camrot, 2.0, 6.0)
+            err = (out["rgb"].cpu() - ref["coarse_raycolor"]).abs().max().item()
+            result["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample")}
+            result["parity_on_cpu_sample"] = {
+                "max_abs_rgb_err": err, "ray_mask_equal": bool(torch.equal(out["ray_mask"].cpu(), ref["ray_mask"])),
+                "psnr_vs_oracle_db": float(-10 * torch.log10(((out["rgb"].cpu() - ref["coarse_raycolor"]) ** 2).mean()
+                                                             + 1e-20))}
+            result["speedup_vs_cpu_baseline"] = value / cb["value"]
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -164,6 +164,21 @@ typedef struct {
 int pnr_render_taps(void *d_workspace, size_t workspace_bytes, int64_t R, int64_t cap_samples, int32_t K,
                     pnr_render_taps_t *taps);
 
+/* ---- per-stage device timing (bench / roofline) ------------------------------------------------- */
+/* When enabled, pnr_render records hipEvents on `stream` between its stages (no host sync is added);
+ * pnr_profile_last_ms synchronises on the last event of the most recent pnr_render of this thread's
+ * process and returns the elapsed device time of each stage in milliseconds. */
+enum {
+    PNR_STAGE_SELECT = 0,      /* occupancy masking + sample selection + scan + expand     */
+    PNR_STAGE_KNN = 1,         /* neighbour search + valid-sample compaction               */
+    PNR_STAGE_SHADE_PAIRS = 2, /* gather + mlp_base + mlp_head + density + K-aggregation   */
+    PNR_STAGE_SHADE_COLOR = 3, /* colour MLP                                               */
+    PNR_STAGE_COMPOSITE = 4,   /* ray_dist + alpha composite + background fill             */
+    PNR_NUM_STAGES = 5
+};
+int pnr_profile_enable(int enable);
+int pnr_profile_last_ms(float ms[PNR_NUM_STAGES]);
+
 #ifdef __cplusplus
 }
 #endif

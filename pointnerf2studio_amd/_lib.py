@@ -25,7 +25,10 @@ EXPORTED_SYMBOLS = [
     "pnr_weights_create", "pnr_weights_destroy", "pnr_weights_pack",
     "pnr_query_workspace_bytes", "pnr_query_raypos",
     "pnr_render_workspace_bytes", "pnr_render", "pnr_render_taps",
+    "pnr_profile_enable", "pnr_profile_last_ms",
 ]
+NUM_STAGES = 5
+STAGE_NAMES = ["select", "knn", "shade_pairs", "shade_color", "composite"]
 
 
 class GridParams(C.Structure):
@@ -82,6 +85,8 @@ def load() -> C.CDLL:
     lib.pnr_render.argtypes = [vp, vp, vp, i64, C.POINTER(CameraC), vp, C.POINTER(RenderOpts), vp, vp, vp, vp, vp,
                                vp, sz, i64, vp]
     lib.pnr_render_taps.argtypes = [vp, sz, i64, i64, i32, C.POINTER(RenderTaps)]
+    lib.pnr_profile_enable.argtypes = [C.c_int]
+    lib.pnr_profile_last_ms.argtypes = [C.POINTER(C.c_float * 5)]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("pnr_last_error", "pnr_query_workspace_bytes", "pnr_render_workspace_bytes"):

@@ -165,7 +165,7 @@ int launch_select_expand(const GridView &g, const Camera &cam, const float *d_di
 int launch_knn(const GridView &g, int K, float radius_limit, RenderWs &ws, int64_t cap, int64_t *d_counters,
                hipStream_t stream);
 int launch_shade(const pnr_scene *scene, const pnr_weights *w, const Camera &cam, const float *d_dirs, int K,
-                 RenderWs &ws, int64_t cap, hipStream_t stream);
+                 RenderWs &ws, int64_t cap, hipStream_t stream, hipEvent_t ev_between);
 int launch_composite(const Camera &cam, const pnr_render_opts_t &opts, int64_t R, RenderWs &ws, float *d_rgb,
                      float *d_depth, float *d_acc, int8_t *d_ray_mask, int64_t *d_counters,
                      hipStream_t stream);

@@ -22,6 +22,11 @@ void set_error(const char *fmt, ...)
 
 constexpr int TPB = 256;
 
+// per-stage timing: events recorded on the caller's stream, read back on request
+static bool g_prof = false;
+static hipEvent_t g_ev[PNR_NUM_STAGES + 1] = {nullptr};
+static bool g_prof_valid = false;
+
 // one thread per ray: its samples are contiguous in the compact list, at most SR of them.
 __global__ void __launch_bounds__(TPB) k_composite(Camera cam, pnr_render_opts_t opts, int64_t R,
                                                     const int *__restrict__ ray_cnt, const int *__restrict__ ray_off,
@@ -168,14 +173,47 @@ extern "C" int pnr_render(const pnr_scene_t *scene, const pnr_weights_t *weights
     Camera cam{};
     for (int i = 0; i < 3; ++i) cam.o[i] = cam_->campos[i];
     for (int i = 0; i < 9; ++i) cam.R[i] = cam_->camrotc2w[i];
+    const bool prof = g_prof;
+    g_prof_valid = false;
+    if (prof) PNR_HIP_CHECK(hipEventRecord(g_ev[0], stream));
     int rc = launch_select_expand(scene->grid, cam, d_dirs, nullptr, R, opts->D, opts->SR, d_tmid, cap_samples, ws,
                                   d_counters, stream);
     if (rc != PNR_OK) return rc;
+    if (prof) PNR_HIP_CHECK(hipEventRecord(g_ev[1], stream));
     rc = launch_knn(scene->grid, opts->K, opts->radius_limit, ws, cap_samples, d_counters, stream);
     if (rc != PNR_OK) return rc;
-    rc = launch_shade(scene, weights, cam, d_dirs, opts->K, ws, cap_samples, stream);
+    if (prof) PNR_HIP_CHECK(hipEventRecord(g_ev[2], stream));
+    rc = launch_shade(scene, weights, cam, d_dirs, opts->K, ws, cap_samples, stream, prof ? g_ev[3] : nullptr);
     if (rc != PNR_OK) return rc;
-    return launch_composite(cam, *opts, R, ws, d_rgb, d_depth, d_acc, d_ray_mask, d_counters, stream);
+    if (prof) PNR_HIP_CHECK(hipEventRecord(g_ev[4], stream));
+    rc = launch_composite(cam, *opts, R, ws, d_rgb, d_depth, d_acc, d_ray_mask, d_counters, stream);
+    if (rc != PNR_OK) return rc;
+    if (prof) {
+        PNR_HIP_CHECK(hipEventRecord(g_ev[5], stream));
+        g_prof_valid = true;
+    }
+    return PNR_OK;
+}
+
+extern "C" int pnr_profile_enable(int enable)
+{
+    if (enable && !g_ev[0])
+        for (int i = 0; i <= PNR_NUM_STAGES; ++i) PNR_HIP_CHECK(hipEventCreate(&g_ev[i]));
+    g_prof = enable != 0;
+    g_prof_valid = false;
+    return PNR_OK;
+}
+
+extern "C" int pnr_profile_last_ms(float ms[PNR_NUM_STAGES])
+{
+    PNR_REQUIRE(ms != nullptr, "pnr_profile_last_ms: null argument");
+    if (!g_prof || !g_prof_valid) {
+        set_error("pnr_profile_last_ms: profiling not enabled or no pnr_render recorded");
+        return PNR_ERR_STATE;
+    }
+    PNR_HIP_CHECK(hipEventSynchronize(g_ev[PNR_NUM_STAGES]));
+    for (int i = 0; i < PNR_NUM_STAGES; ++i) PNR_HIP_CHECK(hipEventElapsedTime(&ms[i], g_ev[i], g_ev[i + 1]));
+    return PNR_OK;
 }
 
 extern "C" int pnr_render_taps(void *d_workspace, size_t workspace_bytes, int64_t R, int64_t cap_samples, int32_t K,

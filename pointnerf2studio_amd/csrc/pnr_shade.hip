@@ -454,7 +454,7 @@ __global__ void k_copy(const float *__restrict__ src, int n, float *__restrict__
 }
 
 int launch_shade(const pnr_scene *scene, const pnr_weights *w, const Camera &cam, const float *d_dirs, int K,
-                 RenderWs &ws, int64_t cap, hipStream_t stream)
+                 RenderWs &ws, int64_t cap, hipStream_t stream, hipEvent_t ev_between)
 {
     ShadeParams P{};
     P.point_rows = reinterpret_cast<const float4 *>(scene->point_rows);
@@ -488,6 +488,7 @@ int launch_shade(const pnr_scene *scene, const pnr_weights *w, const Camera &cam
         hipLaunchKernelGGL(k_shade_pairs<true>, dim3(grid), dim3(TPB), 0, stream, P);
     else
         hipLaunchKernelGGL(k_shade_pairs<false>, dim3(grid), dim3(TPB), 0, stream, P);
+    if (ev_between) PNR_HIP_CHECK(hipEventRecord(ev_between, stream));
     const int64_t ctiles = (cap + 32 * WAVES - 1) / (32 * WAVES);
     const unsigned cgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cus, ctiles));
     hipLaunchKernelGGL(k_shade_color, dim3(cgrid), dim3(TPB), 0, stream, P);
