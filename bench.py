@@ -75,6 +75,17 @@ def cpu_baseline(points, weights, cfgd, n_side, view):
                 seconds=dt), ref, dirs, campos, camrot
 
 
+def pmc_traffic_bytes():
+    """HBM bytes per k_shade_pairs launch from the committed PMC passes (bench.py cannot collect PMC counters
+    itself); None when the summary is absent."""
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["kernels"]["pnr::k_shade_pairs<true>"]["hbm_bytes_per_launch_corrected"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -214,7 +225,10 @@ def main():
                 "bound": "mfma", "kernel": "k_shade_pairs",
                 "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                "traffic": None,
+                "traffic": pmc_traffic_bytes(),
+                "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                                "profiles/r01/pmc_hbm_traffic.json; algorithmic bytes = pairs*164 + samples*1028)",
+                "algorithmic_bytes_per_launch": (pairs * 164 + samples * 1028) / max(n_launch, 1),
                 "avg_launch_ms": acc_ms[2] / max(n_launch, 1),
                 "valid_pairs_per_launch": pairs / max(n_launch, 1),
                 "flops_per_pair": FLOPS_PER_PAIR,
