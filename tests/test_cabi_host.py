@@ -1,0 +1,125 @@
+"""C-ABI and host-side logic that must work WITHOUT a GPU: the library loads and exports every symbol
+include/pnr.h declares, argument validation fails loudly, the host mirrors of the reference's hyper-parameter
+code agree with the oracle, and the product package never reaches into oracle/."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from pointnerf2studio_amd import build, _lib
+    build.build_library()
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from pointnerf2studio_amd import _lib
+    header = open(os.path.join(ROOT, "include", "pnr.h")).read()
+    declared = set(re.findall(r"\b(pnr_[a-z0-9_]+)\s*\(", header))
+    declared -= {"pnr_scene", "pnr_weights"}
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.pnr_version() == 100
+
+
+def test_struct_layouts_match_header(lib):
+    from pointnerf2studio_amd import _lib
+    assert C.sizeof(_lib.GridParams) == 6 * 4 + 3 * 4 + 3 * 4 + 3 * 4 + 3 * 4 + 3 * 4
+    assert C.sizeof(_lib.CameraC) == (3 + 9 + 2) * 4
+    assert C.sizeof(_lib.RenderOpts) == 9 * 4
+
+
+def test_argument_validation_fails_loudly(lib):
+    from pointnerf2studio_amd import _lib
+    rc = lib.pnr_scene_build(None, None, 10, None, None)
+    assert rc == -1 and b"null" in lib.pnr_last_error()
+    with pytest.raises(RuntimeError, match="null"):
+        _lib.check(rc, "pnr_scene_build")
+    assert lib.pnr_render(None, None, None, 1, None, None, None, None, None, None, None, None, None, 0, 1, None) == -1
+    assert lib.pnr_query_raypos(None, None, 1, 400, 80, 8, 0.016, None, None, None, None, None, 0, None) == -1
+
+
+def test_workspace_sizes_are_monotonic(lib):
+    a = lib.pnr_render_workspace_bytes(1000, 10000, 8)
+    b = lib.pnr_render_workspace_bytes(1000, 20000, 8)
+    c = lib.pnr_render_workspace_bytes(2000, 20000, 8)
+    d = lib.pnr_render_workspace_bytes(2000, 20000, 12)
+    assert 0 < a < b < c < d
+    # the aggregated-feature buffer (1 KiB per sample) dominates
+    assert b - a >= 10000 * 1024
+    q = lib.pnr_query_workspace_bytes(1000, 400, 80, 8)
+    assert 0 < q < lib.pnr_render_workspace_bytes(1000, 80000, 8)
+
+
+def test_host_tensors_are_rejected_not_silently_computed():
+    """No CPU fallback: handing the product path a CPU tensor raises."""
+    from pointnerf2studio_amd.renderer import SceneHIP
+    with pytest.raises(RuntimeError, match="GPU"):
+        SceneHIP().build(torch.zeros(10, 3), np.zeros(6), np.ones(3), [4, 4, 4], [3, 3, 3], [3, 3, 3], 12, 100)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from pointnerf2studio_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libpnr_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU or PyTorch fallback"):
+        _lib.load()
+
+
+def test_grid_hyperparameters_mirror_reference(oracle):
+    from pointnerf2studio_amd.renderer import coarse_t_table, grid_hyperparameters
+    from pointnerf2studio_amd import synthetic
+    for seed, ranges in [(1, synthetic.CHAIR_RANGES), (2, [-1.2] * 3 + [1.2] * 3), (3, [-0.3, -0.3, -0.3, 0.2, 0.4, 0.3])]:
+        xyz = synthetic.make_points(5000, seed=seed)["xyz"]
+        cfg = oracle.OracleConfig()
+        cfg.ranges = list(ranges)
+        r, s, d = oracle.get_hyperparameters(cfg, xyz)
+        h = grid_hyperparameters(xyz, cfg.vsize, cfg.vscale, cfg.kernel_size, ranges)
+        assert np.array_equal(h.ranges, r.numpy()) and np.array_equal(h.scaled_vsize, s)
+        assert np.array_equal(h.scaled_vdim, d)
+    for D, n, f in [(400, 2.0, 6.0), (400, 0.1, 8.0), (64, 2.0, 6.0)]:
+        assert torch.equal(coarse_t_table(D, n, f), oracle.coarse_t_table(D, n, f))
+
+
+def test_synthetic_weights_match_oracle_generator(oracle):
+    from pointnerf2studio_amd import synthetic
+    a, b = synthetic.make_weights(0, 40.0, 0.1), oracle.make_weights(0, 40.0, 0.1)
+    assert set(a) == set(b) and all(torch.equal(a[k], b[k]) for k in a)
+    assert {k: tuple(v.shape) for k, v in a.items() if k.endswith("weight")} == \
+        {k + ".weight": v for k, v in oracle.MLP_SHAPES.items()}
+
+
+def test_synthetic_scene_and_rays():
+    from pointnerf2studio_amd import synthetic
+    p = synthetic.make_points(20000, seed=5)
+    lo, hi = torch.tensor(synthetic.CHAIR_RANGES[:3]), torch.tensor(synthetic.CHAIR_RANGES[3:])
+    assert p["xyz"].shape == (20000, 3) and torch.all(p["xyz"] >= lo) and torch.all(p["xyz"] <= hi)
+    assert p["embedding"].shape == (1, 20000, 32) and p["conf"].shape == (1, 20000, 1)
+    assert torch.allclose(p["dir"].norm(dim=-1), torch.ones(1, 20000), atol=1e-5)
+    campos, rot = synthetic.make_camera(30.0)
+    assert torch.allclose(rot.T @ rot, torch.eye(3), atol=1e-6) and abs(campos.norm().item() - 4.0) < 1e-5
+    d = synthetic.make_rays(8, 8, campos, rot)
+    assert d.shape == (64, 3) and torch.allclose(d.norm(dim=-1), torch.ones(64), atol=1e-6)
+    centre = synthetic.make_rays(800, 800, campos, rot, y0=400, y1=401, x0=400, x1=401)
+    assert torch.allclose(centre[0], -campos / campos.norm(), atol=2e-3)   # the camera looks at the origin
+    win = synthetic.make_rays(800, 800, campos, rot, y0=10, y1=12, x0=20, x1=23)
+    full = synthetic.make_rays(800, 800, campos, rot).view(800, 800, 3)
+    assert torch.allclose(win.view(2, 3, 3), full[10:12, 20:23], atol=1e-6)
+
+
+def test_product_package_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "pointnerf2studio_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "pnr_oracle" not in src and "oracle/" not in src and "import oracle" not in src, f
+                assert "/root/reference" not in src, f
