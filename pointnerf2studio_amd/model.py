@@ -1,0 +1,335 @@
+"""Host-side mirror of the reference's nerfstudio Model (pointnerf/nerfstudio/studio_model.py):
+`PointNerfConfig` with the same fields and defaults, `PointNerf` with the same module names (so state
+dicts and optimiser groups carry over), `get_outputs` / `get_param_groups` / `get_loss_dict` /
+`get_training_callbacks` / `fill_invalid` / `linear`.
+
+get_outputs has two bodies:
+  * outside training (the path the metric times, `get_outputs_for_camera_ray_bundle`): ONE call into the
+    fused HIP renderer (pnr_render) -- query, gather, MLPs on fp32 MFMA, composite;
+  * in training mode: the reference's own op sequence on PyTorch-ROCm tensors (autograd needs it until the
+    backward kernels of SURVEY.md 8f-1 exist), with the HIP drop-in op doing the query.
+There is no CPU path in either.
+"""
+from __future__ import annotations
+
+import dataclasses
+import glob
+import os
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Any, Dict, List, Optional
+
+import torch
+from torch import nn
+from torch.nn import Parameter
+
+from .neural_points import NeuralPoints, PointNeRFEncoding
+from .ns_compat import (MLP, DensityFieldHead, Model, ModelConfig, MSELoss, RGBFieldHead, RGBRenderer,
+                        TrainingCallback, TrainingCallbackAttributes, TrainingCallbackLocation, WHITE)
+from .renderer import MLP_TENSOR_ORDER, RendererHIP, WeightsHIP
+
+
+def get_latest_epoch(resume_dir):
+    """studio_model.py:55-59."""
+    os.makedirs(resume_dir, exist_ok=True)
+    str_epoch = [f.split("_")[0] for f in os.listdir(resume_dir) if f.endswith("_states.pth")]
+    int_epoch = [int(i) for i in str_epoch]
+    return None if len(int_epoch) == 0 else str_epoch[int_epoch.index(max(int_epoch))]
+
+
+@dataclass
+class PointNerfConfig(ModelConfig):
+    """Field-for-field the reference's PointNerfConfig (studio_model.py:61-118)."""
+    _target: Any = dataclasses.field(default_factory=lambda: PointNerf)
+    path_point_cloud: Optional[Path] = None
+    eval_num_rays_per_chunk: int = 4096
+
+    feat_grad: bool = True
+    conf_grad: bool = True
+    dir_grad: bool = True
+    color_grad: bool = True
+
+    num_pos_freqs: Optional[int] = 10
+    num_viewdir_freqs: Optional[int] = 4
+    num_feat_freqs: Optional[int] = 3
+    num_dist_freqs: Optional[int] = 5
+
+    agg_dist_pers: Optional[int] = 20
+    point_features_dim: Optional[int] = 32
+
+    point_color_mode: Optional[bool] = True
+    point_dir_mode: Optional[bool] = True
+
+    num_samples: int = 80
+    use_biased_sampler: bool = False
+    field_dim: int = 64
+
+    num_mlp_base_layers: Optional[int] = 2
+    num_mlp_head_layers: Optional[int] = 2
+    num_color_layers: Optional[int] = 3
+    num_alpha_layers: Optional[int] = 1
+    hidden_size: int = 256
+    hidden_size_color: int = 128
+
+    apply_pnt_mask: bool = True
+    act_super: bool = False
+    axis_weight: List[float] = dataclasses.field(default_factory=lambda: [1., 1., 1.])
+    kernel_size: List[int] = dataclasses.field(default_factory=lambda: [3, 3, 3])
+    vscale: List[float] = dataclasses.field(default_factory=lambda: [2, 2, 2])
+    vsize: List[float] = dataclasses.field(default_factory=lambda: [0.004, 0.004, 0.004])
+    query_size: List[float] = dataclasses.field(default_factory=lambda: [3, 3, 3])
+    ranges: List[float] = dataclasses.field(default_factory=lambda: [-1.200, -1.200, -1.200, 1.200, 1.200, 1.200])
+    z_depth_dim: int = 400
+
+    SR: int = 80
+    K: int = 8
+    max_o: int = 1000000
+    P: int = 12
+    NN: int = 2
+    gpu_maxthr: int = 1024
+
+    zero_epsilon: float = 1e-3
+    zero_one_loss_weights: float = 0.0001
+
+    def __post_init__(self):
+        if self.path_point_cloud is not None:
+            if not Path(self.path_point_cloud).exists():
+                raise RuntimeError(f"PointCloud path {self.path_point_cloud} does not exist")
+
+
+class PointNerf(Model):
+    """studio_model.py:121-505."""
+    config: PointNerfConfig
+
+    def __init__(self, config: PointNerfConfig, cameras=None, point_state_dict: Optional[Dict] = None,
+                 **kwargs) -> None:
+        self._point_state_dict = point_state_dict   # lets tests / benches hand the cloud over in memory
+        super().__init__(config=config, **kwargs)
+        self._point_initialized = False
+        self.cameras = cameras
+        self._device = "cuda"
+        self._renderer: Optional[RendererHIP] = None
+        self._weights: Optional[WeightsHIP] = None
+        self._weights_key = None
+        self._init_pointnerf()
+
+    def _init_pointnerf(self):
+        """studio_model.py:147-166: newest `{iter}_net_ray_marching.pth` of path_point_cloud; only the
+        `neural_points.*` keys are consumed (studio_utils.py:84-90)."""
+        if self._point_state_dict is not None:
+            state_dict = self._point_state_dict
+        elif self.config.path_point_cloud is not None:
+            path = str(self.config.path_point_cloud)
+            if not os.path.exists(path):
+                raise RuntimeError(f"Specified point_cloud path {path} does not exist")
+            if len([n for n in glob.glob(path + "/*_net_ray_marching.pth") if os.path.isfile(n)]) == 0:
+                raise RuntimeError(f"Cannot find any _net_ray_marching.pth in {path}")
+            load_path = os.path.join(path, '{}_net_ray_marching.pth'.format(get_latest_epoch(path)))
+            if not os.path.isfile(load_path):
+                raise RuntimeError(f'cannot load {load_path}')
+            state_dict = torch.load(load_path, map_location="cpu")
+        else:
+            raise RuntimeError("The point_cloud_path must be specified.")
+        self.neural_points = NeuralPoints(state_dict, self._device, self.config)
+        self._point_initialized = True
+
+    def populate_modules(self):
+        """studio_model.py:169-237 (metrics modules are outside the hot path and omitted)."""
+        super().populate_modules()
+        cfg = self.config
+        self.direction_encoding = PointNeRFEncoding(in_dim=2, num_frequencies=cfg.num_viewdir_freqs, ori=True)
+        self.feature_encoding = PointNeRFEncoding(in_dim=2, num_frequencies=cfg.num_feat_freqs, ori=False)
+        self.dists_encoding = PointNeRFEncoding(in_dim=2, num_frequencies=cfg.num_dist_freqs, ori=False)
+        dist_dim = (4 if cfg.agg_dist_pers == 30 else 6) if cfg.agg_dist_pers > 9 else 3
+        dist_xyz_dim = dist_dim if cfg.num_dist_freqs == 0 else 2 * abs(cfg.num_dist_freqs) * dist_dim
+        mlp_in_dim = 2 * cfg.num_feat_freqs * cfg.point_features_dim + dist_xyz_dim + cfg.point_features_dim
+        act = lambda: nn.LeakyReLU(0.1, True)
+        self.mlp_base = MLP(in_dim=mlp_in_dim, num_layers=cfg.num_mlp_base_layers, layer_width=cfg.hidden_size,
+                            activation=act(), out_activation=act())
+        mlp_in_dim = self.mlp_base.get_out_dim() + (3 if cfg.point_color_mode else 0) + (4 if cfg.point_dir_mode else 0)
+        self.mlp_head = MLP(in_dim=mlp_in_dim, num_layers=cfg.num_mlp_head_layers, layer_width=cfg.hidden_size,
+                            activation=act(), out_activation=act())
+        color_in_dim = self.mlp_head.get_out_dim() + 2 * cfg.num_viewdir_freqs * 3
+        self.mlp_color = MLP(in_dim=color_in_dim, num_layers=cfg.num_color_layers, layer_width=cfg.hidden_size_color,
+                             activation=act(), out_activation=act())
+        self.field_output_color = RGBFieldHead(in_dim=self.mlp_color.get_out_dim(), activation=torch.nn.Sigmoid())
+        self.field_output_density = DensityFieldHead(in_dim=self.mlp_head.get_out_dim(), activation=torch.nn.ReLU())
+        self._background_color = WHITE
+        self.rgb_renderer = RGBRenderer(background_color=self._background_color)
+        self.mask_loss = MSELoss()
+        self.rgb_loss = MSELoss()
+
+    # ---- fused HIP path ---------------------------------------------------------------------------------
+    def _fusable(self) -> bool:
+        c = self.config
+        return (c.point_features_dim == 32 and c.num_feat_freqs == 3 and c.num_dist_freqs == 5 and
+                c.num_viewdir_freqs == 4 and c.agg_dist_pers == 20 and c.hidden_size == 256 and
+                c.hidden_size_color == 128 and c.num_mlp_base_layers == 2 and c.num_mlp_head_layers == 2 and
+                c.num_color_layers == 3 and bool(c.point_color_mode) and bool(c.point_dir_mode) and
+                list(c.axis_weight) == [1., 1., 1.] and bool(c.apply_pnt_mask))
+
+    def _mlp_state(self) -> Dict[str, torch.Tensor]:
+        sd = {}
+        for name in MLP_TENSOR_ORDER:
+            mod = self.get_submodule(name)
+            sd[name + ".weight"], sd[name + ".bias"] = mod.weight, mod.bias
+        return sd
+
+    def _fused_renderer(self) -> RendererHIP:
+        scene = self.neural_points.fused_scene()
+        sd = self._mlp_state()
+        key = tuple((t.data_ptr(), t._version) for t in sd.values()) + (self.neural_points.points_Rw2c._version,)
+        if self._weights is None or key != self._weights_key:
+            if self._weights is None:
+                self._weights = WeightsHIP()
+            self._weights.pack(sd, self.neural_points.points_Rw2c.detach(), self.neural_points.points_xyz.device)
+            self._weights_key = key
+        if self._renderer is None or self._renderer.scene is not scene:
+            c = self.config
+            self._renderer = RendererHIP(scene, self._weights, SR=c.SR, K=c.K, D=c.z_depth_dim,
+                                         radius_limit=float(self.neural_points.radius_limit_np),
+                                         vsize_z=c.vsize[2], eval_clamp=True, bg=self._background_color.tolist())
+        return self._renderer
+
+    def _get_outputs_fused(self, ray_bundle):
+        """Jitter: the reference draws torch.rand jitter even at eval (studio_utils.py:166); the fused path
+        renders the jitter-free mid-points (deterministic; DESIGN.md 'jitter')."""
+        rot, pos = self.neural_points._camera(ray_bundle)
+        out = self._fused_renderer().render(ray_bundle.directions.to(self._device), pos[0], rot[0],
+                                            ray_bundle.nears[0].item(), ray_bundle.fars[0].item())
+        return {"coarse_raycolor": out["rgb"], "ray_mask": out["ray_mask"], "depth": out["depth"],
+                "accumulation": out["acc"]}
+
+    def get_outputs(self, ray_bundle):
+        if self.mlp_base is None:
+            raise ValueError("populate_fields() must be called before get_outputs")
+        if not self.training and not torch.is_grad_enabled() and self._fusable():
+            return self._get_outputs_fused(ray_bundle)
+        return self._get_outputs_autograd(ray_bundle)
+
+    # ---- the reference's op sequence (training) -----------------------------------------------------------
+    def _get_outputs_autograd(self, ray_bundle):
+        """studio_model.py:263-399 on device tensors; the query inside neural_points() is the HIP op."""
+        (sampled_color, sampled_Rw2c, sampled_dir, sampled_embedding, sampled_xyz_pers, sampled_xyz, sampled_conf,
+         sample_loc_tensor, sample_loc_w_tensor, sample_pnt_mask, sample_ray_dirs_tensor, vsize_np,
+         ray_mask_tensor) = self.neural_points(ray_bundle)
+        dev = sample_loc_w_tensor.device
+        sample_valid = torch.any(sample_pnt_mask, dim=-1).view(-1)
+        total_len = len(sample_valid)
+        in_shape = sample_loc_w_tensor.shape
+        B, R, SR, K = sample_pnt_mask.shape
+        if R > 0:
+            xdist = sampled_xyz_pers[..., 0] * sampled_xyz_pers[..., 2] - (sample_loc_tensor[..., 0] * sample_loc_tensor[..., 2])[..., None]
+            ydist = sampled_xyz_pers[..., 1] * sampled_xyz_pers[..., 2] - (sample_loc_tensor[..., 1] * sample_loc_tensor[..., 2])[..., None]
+            zdist = sampled_xyz_pers[..., 2] - sample_loc_tensor[..., 2][..., None]
+            dists = torch.cat([sampled_xyz - sample_loc_w_tensor[..., None, :], torch.stack([xdist, ydist, zdist], -1)], -1)
+        else:
+            dists = torch.zeros([B, R, SR, K, 6], device=dev)
+        axis_weight = torch.as_tensor(self.config.axis_weight, dtype=torch.float32, device=dev)[None, None, None, None, :]
+        weight = self.linear(dists, sample_pnt_mask, axis_weight=axis_weight)
+        weight = weight / torch.clamp(torch.sum(weight, dim=-1, keepdim=True), min=1e-8)
+        conf_coefficient = None
+        if self.training:
+            conf = sampled_conf[..., 0]
+            conf_coefficient = conf - (conf - torch.clamp(conf, min=0.0001, max=1)).detach()
+
+        flat = sample_pnt_mask.view(-1)
+        Rt = sampled_Rw2c.transpose(-1, -2)
+        viewdirs = self.direction_encoding(sample_ray_dirs_tensor.reshape(-1, 3) @ Rt)
+        ori_viewdirs, viewdirs = viewdirs[..., :3], viewdirs[..., 3:]
+        viewdirs = viewdirs[sample_valid, :]
+        d = dists.view(-1, 6)[flat, :]
+        d = torch.cat([d[..., :3] @ Rt, d[..., 3:]], dim=-1)
+        feat = sampled_embedding.reshape(-1, sampled_embedding.shape[-1])[flat, :]
+        feat = torch.cat([feat, self.feature_encoding(feat), self.dists_encoding(d)], dim=-1)
+        weight = weight.view(B * R * SR, K, 1)
+        feat = self.mlp_base(feat)
+        col = sampled_color.reshape(-1, 3)[flat, :]
+        sdir = sampled_dir.reshape(-1, 3)[flat, :] @ Rt
+        ov = ori_viewdirs[..., None, :].repeat(1, K, 1).view(-1, 3)[flat, :]
+        feat = torch.cat([feat, col, sdir - ov, torch.sum(sdir * ov, dim=-1, keepdim=True)], dim=-1)
+        feat = self.mlp_head(feat)
+        alpha = self.field_output_density(feat)
+        holder = torch.zeros([B * R * SR * K, 1], dtype=torch.float32, device=dev)
+        holder[flat, :] = alpha
+        alpha = torch.sum(holder.view(B * R * SR, K, 1) * weight, dim=-2).view(-1, 1)[sample_valid, :]
+        holder = torch.zeros([B * R * SR * K, feat.shape[-1]], dtype=torch.float32, device=dev)
+        holder[flat, :] = feat
+        feat = torch.sum(holder.view(B * R * SR, K, -1) * weight, dim=-2).view(-1, feat.shape[-1])[sample_valid, :]
+        color = self.field_output_color(self.mlp_color(torch.cat([feat, viewdirs], dim=-1)))
+        color = color * (1 + 2 * 0.001) - 0.001
+        decoded = torch.zeros([total_len, 4], dtype=torch.float32, device=dev)
+        decoded[sample_valid] = torch.cat([alpha, color], dim=-1)
+        decoded = decoded.view(in_shape[:-1] + (4,))
+        sample_valid = sample_valid.view(in_shape[:-1])
+
+        ray_dist = torch.cummax(sample_loc_tensor[..., 2], dim=-1)[0]
+        ray_dist = torch.cat([ray_dist[..., 1:] - ray_dist[..., :-1],
+                              torch.full((B, R, 1), vsize_np[2], device=dev)], dim=-1)
+        m = torch.logical_or(ray_dist < 1e-8, ray_dist > 2 * vsize_np[2]).to(torch.float32)
+        ray_dist = (ray_dist * (1.0 - m) + m * vsize_np[2]) * sample_valid.float()
+        sigma = decoded[..., 0] * sample_valid.float()
+        opacity = 1 - torch.exp(-sigma * ray_dist)
+        acc_t = torch.cumprod(1. - opacity + 1e-10, dim=-1)
+        acc_t = torch.cat([torch.ones((B, R, 1), device=dev), acc_t[:, :, :-1]], dim=-1)
+        blend_weight = (opacity * acc_t).unsqueeze(-1)
+        output = {"coarse_raycolor": self.rgb_renderer(rgb=decoded[..., 1:4], weights=blend_weight),
+                  "ray_mask": ray_mask_tensor}
+        output = self.fill_invalid(output)
+        output["ray_mask"] = output["ray_mask"].squeeze(0)
+        if self.training:
+            output["conf_coefficient"] = conf_coefficient
+        return output
+
+    # ---- the rest of the plugin surface ---------------------------------------------------------------------
+    def get_param_groups(self) -> Dict[str, List[Parameter]]:
+        """studio_model.py:401-413: `neural_points` = parameters named neural_points.points*, `fields` = the rest."""
+        if self.mlp_base is None:
+            raise ValueError("populate_fields() must be called before get_param_groups")
+        named = list(self.named_parameters())
+        return {"neural_points": [p for n, p in named if n.startswith("neural_points.points")],
+                "fields": [p for n, p in named if not n.startswith("neural_points.points")]}
+
+    def get_training_callbacks(self, training_callback_attributes: TrainingCallbackAttributes) -> List[TrainingCallback]:
+        """The reference inherits nerfstudio's empty list.  Here one callback runs after every optimiser step:
+        point features and MLP weights changed, so the packed HIP copies used by the fused eval path are
+        invalidated (they are re-packed lazily, on the next eval render)."""
+        def _invalidate(step: int = 0):
+            self.neural_points.invalidate()
+            self._weights_key = None
+        return [TrainingCallback(where_to_run=[TrainingCallbackLocation.AFTER_TRAIN_ITERATION], func=_invalidate)]
+
+    def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, torch.Tensor]:
+        """studio_model.py:415-431."""
+        device = outputs["coarse_raycolor"].device
+        image = batch["image"].to(device)
+        keep = (outputs["ray_mask"] > 0)[..., None].expand(-1, 3)
+        masked_output = torch.masked_select(outputs["coarse_raycolor"], keep).reshape(-1, 3)
+        masked_gt = torch.masked_select(image, keep).reshape(-1, 3)
+        loss_dict = {"ray_masked_coarse_raycolor_loss": self.mask_loss(masked_gt, masked_output) + 1e-6}
+        if self.training:
+            val = torch.clamp(outputs["conf_coefficient"], self.config.zero_epsilon, 1 - self.config.zero_epsilon)
+            loss_dict["conf_coefficient_loss"] = \
+                torch.mean(torch.log(val) + torch.log(1 - val)) * self.config.zero_one_loss_weights
+        coeff = getattr(self.config, "loss_coefficients", None) or {}
+        return {k: v * coeff.get(k, 1.0) for k, v in loss_dict.items()}
+
+    def linear(self, dists, pnt_mask, axis_weight=None):
+        """studio_model.py:467-475."""
+        if axis_weight is None or (axis_weight[..., 0] == 1 and axis_weight[..., 2] == 1):
+            weights = 1. / torch.clamp(torch.norm(dists[..., :3], dim=-1), min=1e-6)
+        else:
+            weights = 1. / torch.clamp(
+                torch.sqrt(torch.sum(torch.square(dists[..., :2]), dim=-1)) * axis_weight[..., 0] +
+                torch.abs(dists[..., 2]) * axis_weight[..., 1], min=1e-6)
+        return pnt_mask * weights
+
+    def fill_invalid(self, output):
+        """studio_model.py:491-504, without the torch.nonzero host sync."""
+        ray_mask = output["ray_mask"]
+        B, OR = ray_mask.shape
+        rgb = output["coarse_raycolor"]
+        full = torch.ones([B, OR, 3], dtype=rgb.dtype, device=rgb.device) * self._background_color.to(rgb.device)
+        full[ray_mask > 0] = rgb.reshape(-1, 3)
+        output["coarse_raycolor"] = full.squeeze(0)
+        return output

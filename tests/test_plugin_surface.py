@@ -1,0 +1,127 @@
+"""The plugin surface of the reference (outer surface) reproduced by the host-side mirror:
+config fields/defaults, module and parameter names, optimiser groups, callbacks, loss keys.  CPU-only checks of
+structure; the GPU behaviour is in test_gpu_plugin.py."""
+import dataclasses
+
+import pytest
+import torch
+
+from pointnerf2studio_amd import synthetic
+from pointnerf2studio_amd.model import PointNerf, PointNerfConfig
+from pointnerf2studio_amd.neural_points import PointNeRFEncoding, near_far_linear_ray_generation
+from pointnerf2studio_amd.renderer import MLP_SHAPES, MLP_TENSOR_ORDER
+from pointnerf2studio_amd import studio_config
+
+
+def _state_dict(N=500):
+    p = synthetic.make_points(N)
+    return {"neural_points.xyz": p["xyz"], "neural_points.points_embeding": p["embedding"],
+            "neural_points.points_conf": p["conf"], "neural_points.points_dir": p["dir"],
+            "neural_points.points_color": p["color"], "neural_points.Rw2c": p["Rw2c"]}
+
+
+def _cpu_model():
+    cfg = PointNerfConfig()
+    m = PointNerf.__new__(PointNerf)
+    # construct on the CPU for structure checks: same code path with the device overridden
+    PointNerf._init_pointnerf_orig = PointNerf._init_pointnerf
+
+    def _init(self):
+        self._device = "cpu"
+        PointNerf._init_pointnerf_orig(self)
+    PointNerf._init_pointnerf = _init
+    try:
+        m.__init__(cfg, point_state_dict=_state_dict())
+    finally:
+        PointNerf._init_pointnerf = PointNerf._init_pointnerf_orig
+    return m
+
+
+def test_config_fields_and_defaults_match_reference():
+    expect = dict(path_point_cloud=None, eval_num_rays_per_chunk=4096, feat_grad=True, conf_grad=True, dir_grad=True,
+                  color_grad=True, num_pos_freqs=10, num_viewdir_freqs=4, num_feat_freqs=3, num_dist_freqs=5,
+                  agg_dist_pers=20, point_features_dim=32, point_color_mode=True, point_dir_mode=True, num_samples=80,
+                  use_biased_sampler=False, field_dim=64, num_mlp_base_layers=2, num_mlp_head_layers=2,
+                  num_color_layers=3, num_alpha_layers=1, hidden_size=256, hidden_size_color=128, apply_pnt_mask=True,
+                  act_super=False, axis_weight=[1., 1., 1.], kernel_size=[3, 3, 3], vscale=[2, 2, 2],
+                  vsize=[0.004, 0.004, 0.004], query_size=[3, 3, 3], ranges=[-1.2, -1.2, -1.2, 1.2, 1.2, 1.2],
+                  z_depth_dim=400, SR=80, K=8, max_o=1000000, P=12, NN=2, gpu_maxthr=1024, zero_epsilon=1e-3,
+                  zero_one_loss_weights=0.0001)
+    cfg = PointNerfConfig()
+    for k, v in expect.items():
+        assert getattr(cfg, k) == v, k
+    names = {f.name for f in dataclasses.fields(cfg)}
+    assert set(expect) <= names
+
+
+def test_missing_point_cloud_raises_like_reference(tmp_path):
+    with pytest.raises(RuntimeError, match="does not exist"):
+        PointNerfConfig(path_point_cloud=tmp_path / "nope")
+    with pytest.raises(RuntimeError, match="must be specified"):
+        PointNerf(PointNerfConfig())
+    (tmp_path / "empty").mkdir()
+    with pytest.raises(RuntimeError, match="Cannot find any _net_ray_marching.pth"):
+        PointNerf(PointNerfConfig(path_point_cloud=tmp_path / "empty"))
+
+
+def test_module_names_shapes_and_param_groups():
+    m = _cpu_model()
+    sd = m.state_dict()
+    for name, shape in zip(MLP_TENSOR_ORDER, MLP_SHAPES):
+        assert tuple(sd[name + ".weight"].shape) == shape and tuple(sd[name + ".bias"].shape) == (shape[0],)
+    for k, shape in {"neural_points.points_xyz": (500, 3), "neural_points.points_embeding": (1, 500, 32),
+                     "neural_points.points_conf": (1, 500, 1), "neural_points.points_dir": (1, 500, 3),
+                     "neural_points.points_color": (1, 500, 3), "neural_points.points_Rw2c": (3, 3)}.items():
+        assert tuple(sd[k].shape) == shape
+    groups = m.get_param_groups()
+    assert set(groups) == {"neural_points", "fields"} == set(studio_config.OPTIMIZER_GROUPS)
+    named = dict(m.named_parameters())
+    np_ids = {id(p) for p in groups["neural_points"]}
+    assert np_ids == {id(p) for n, p in named.items() if n.startswith("neural_points.points")}
+    assert not m.neural_points.points_xyz.requires_grad and not m.neural_points.points_Rw2c.requires_grad
+    assert m.neural_points.points_embeding.requires_grad and m.neural_points.points_color.requires_grad
+    assert m.mlp_base.layers[0].in_features == 284 and m.mlp_head.layers[0].in_features == 263
+    assert m.mlp_color.layers[0].in_features == 280
+
+
+def test_training_callbacks_invalidate_packed_copies():
+    m = _cpu_model()
+    cbs = m.get_training_callbacks(None)
+    assert len(cbs) == 1
+    m.neural_points._fused_key, m.neural_points._packed_key, m._weights_key = "a", "b", "c"
+    cbs[0].run_callback(step=3)
+    assert m.neural_points._fused_key is None and m.neural_points._packed_key is None and m._weights_key is None
+
+
+def test_loss_dict_keys_and_values():
+    m = _cpu_model()
+    m.train()
+    out = {"coarse_raycolor": torch.rand(10, 3), "ray_mask": torch.tensor([1, 0, 1, 1, 0, 0, 1, 1, 1, 0], dtype=torch.int8),
+           "conf_coefficient": torch.rand(1, 4, 5, 8)}
+    batch = {"image": torch.rand(10, 3)}
+    ld = m.get_loss_dict(out, batch)
+    assert set(ld) == {"ray_masked_coarse_raycolor_loss", "conf_coefficient_loss"}
+    keep = out["ray_mask"] > 0
+    assert torch.allclose(ld["ray_masked_coarse_raycolor_loss"],
+                          torch.nn.functional.mse_loss(batch["image"][keep], out["coarse_raycolor"][keep]) + 1e-6)
+    m.eval()
+    assert set(m.get_loss_dict(out, batch)) == {"ray_masked_coarse_raycolor_loss"}
+
+
+def test_encoding_and_ray_generation_mirrors_match_oracle(oracle):
+    x = torch.rand(7, 5) - 0.5
+    for F, ori in [(3, False), (5, False), (4, True)]:
+        assert torch.equal(PointNeRFEncoding(5, F, ori)(x), oracle.positional_encoding(x, F, ori))
+    campos = torch.tensor([[1.0, 2.0, 3.0]])
+    raydir = torch.nn.functional.normalize(torch.rand(1, 6, 3) - 0.5, dim=-1)
+    rp, _, _, tm = near_far_linear_ray_generation(campos, raydir, 400, near=2.0, far=6.0, jitter=0.0)
+    rp_o, tm_o = oracle.ray_generation(campos, raydir, 400, 2.0, 6.0)
+    assert torch.equal(rp, rp_o) and torch.equal(tm, tm_o)
+
+
+def test_method_registration_constants():
+    assert studio_config.METHOD_NAME == "pointnerf-original"
+    assert studio_config.OPTIMIZER_GROUPS == {"fields": 0.0005, "neural_points": 0.002}
+    assert studio_config.EVAL_NUM_RAYS_PER_CHUNK == 2304
+    f = studio_config.pointnerf_lr_lambda()
+    assert f(0) == 1.0 and abs(f(1000000) - 0.1) < 1e-12
