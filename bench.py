@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--points", type=int, default=None, help="override the number of points")
     ap.add_argument("--cpu-rays-side", type=int, default=64, help="side of the CPU-baseline window (0 = skip)")
     ap.add_argument("--sigma-scale", type=float, default=300.0)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
+                    help="MLP arithmetic: exact fp32 MFMA, or 3 bf16 MFMAs per fp32 product (hi/lo split)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -129,7 +131,8 @@ def main():
                       points["color"].to(dev))
     wh = WeightsHIP()
     wh.pack(weights, points["Rw2c"], dev)
-    rnd = RendererHIP(scene, wh, SR=SR, K=K, D=400, radius_limit=4 * max(VSIZE[0], VSIZE[1]), vsize_z=VSIZE[2])
+    rnd = RendererHIP(scene, wh, SR=SR, K=K, D=400, radius_limit=4 * max(VSIZE[0], VSIZE[1]), vsize_z=VSIZE[2],
+                      precision=args.precision)
 
     # ---- rays: `world` views per step, this rank's tiles of each ----------------------------------------
     azimuths = [45.0 * i + 20.0 for i in range(8)]
@@ -243,7 +246,7 @@ def main():
             cb, ref, dirs, campos, camrot = cpu_baseline(points, weights, cfgd, args.cpu_rays_side, azimuths[0])
             # parity on the very same rays: HIP render vs the oracle that was just timed
             out = RendererHIP(scene, wh, SR=SR, K=K, D=400, radius_limit=4 * max(VSIZE[0], VSIZE[1]),
-                              vsize_z=VSIZE[2]).render(dirs.to(dev), campos, camrot, 2.0, 6.0)
+                              vsize_z=VSIZE[2], precision=args.precision).render(dirs.to(dev), campos, camrot, 2.0, 6.0)
             err = (out["rgb"].cpu() - ref["coarse_raycolor"]).abs().max().item()
             result["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample")}
             result["parity_on_cpu_sample"] = {

@@ -83,7 +83,14 @@ typedef struct {
     float vsize_z;         /* config.vsize[2], the fallback segment length                 */
     int32_t eval_clamp;    /* 1: clamp rgb to [0,1] (nerfstudio RGBRenderer outside training) */
     float bg[3];           /* background colour (white in the reference)                   */
+    int32_t precision;     /* PNR_PRECISION_FP32 (exact fp32 MFMA) or PNR_PRECISION_BF16X3 */
 } pnr_render_opts_t;
+
+/* MLP arithmetic.  FP32: v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fma chain.  BF16X3: every fp32 product is
+ * evaluated as ah*bh + ah*bl + al*bh on bf16 hi/lo splits with fp32 accumulation (relative error ~2^-16 per
+ * product; RGB stays within 1e-5 of the fp32 mode on the parity scenes, inside the 1e-4 budget). */
+#define PNR_PRECISION_FP32 0
+#define PNR_PRECISION_BF16X3 1
 
 /* Counters written by pnr_render / pnr_query_raypos into d_counters[PNR_NUM_COUNTERS] (int64). */
 enum {

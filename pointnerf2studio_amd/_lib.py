@@ -44,7 +44,10 @@ class CameraC(C.Structure):
 
 class RenderOpts(C.Structure):
     _fields_ = [("SR", C.c_int32), ("K", C.c_int32), ("D", C.c_int32), ("radius_limit", C.c_float),
-                ("vsize_z", C.c_float), ("eval_clamp", C.c_int32), ("bg", C.c_float * 3)]
+                ("vsize_z", C.c_float), ("eval_clamp", C.c_int32), ("bg", C.c_float * 3), ("precision", C.c_int32)]
+
+
+PRECISION = {"fp32": 0, "bf16x3": 1}
 
 
 class RenderTaps(C.Structure):

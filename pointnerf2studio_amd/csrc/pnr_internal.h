@@ -123,7 +123,8 @@ struct pnr_weights {
     float *buf = nullptr;  // all packed tensors, offsets below (in floats)
     size_t bytes = 0;
     // offsets into buf
-    size_t w_off[9] = {0};
+    size_t w_off[9] = {0};    // fp32 A-operand order (layers) / plain (heads)
+    size_t w16_off[9] = {0};  // bf16 hi/lo tiles (layers)
     size_t b_off[9] = {0};
     float Rw2c[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
 };
@@ -165,7 +166,7 @@ int launch_select_expand(const GridView &g, const Camera &cam, const float *d_di
 int launch_knn(const GridView &g, int K, float radius_limit, RenderWs &ws, int64_t cap, int64_t *d_counters,
                hipStream_t stream);
 int launch_shade(const pnr_scene *scene, const pnr_weights *w, const Camera &cam, const float *d_dirs, int K,
-                 RenderWs &ws, int64_t cap, hipStream_t stream, hipEvent_t ev_between);
+                 int precision, RenderWs &ws, int64_t cap, hipStream_t stream, hipEvent_t ev_between);
 int launch_composite(const Camera &cam, const pnr_render_opts_t &opts, int64_t R, RenderWs &ws, float *d_rgb,
                      float *d_depth, float *d_acc, int8_t *d_ray_mask, int64_t *d_counters,
                      hipStream_t stream);

@@ -162,6 +162,8 @@ extern "C" int pnr_render(const pnr_scene_t *scene, const pnr_weights_t *weights
     PNR_REQUIRE(opts->D >= 1 && opts->D <= PNR_MAX_D, "pnr_render: D=%d not in [1,%d]", opts->D, PNR_MAX_D);
     PNR_REQUIRE(opts->K >= 1 && opts->K <= PNR_MAX_K, "pnr_render: K=%d not in [1,%d]", opts->K, PNR_MAX_K);
     PNR_REQUIRE(opts->SR >= 1, "pnr_render: SR=%d", opts->SR);
+    PNR_REQUIRE(opts->precision == PNR_PRECISION_FP32 || opts->precision == PNR_PRECISION_BF16X3,
+                "pnr_render: unknown precision %d", opts->precision);
     PNR_REQUIRE(cap_samples >= 1 && cap_samples < (int64_t)0x7FFFFFF0 / std::max(opts->K, 1),
                 "pnr_render: cap_samples=%lld out of range", (long long)cap_samples);
     const size_t need = pnr_render_workspace_bytes(R, cap_samples, opts->K);
@@ -183,7 +185,8 @@ extern "C" int pnr_render(const pnr_scene_t *scene, const pnr_weights_t *weights
     rc = launch_knn(scene->grid, opts->K, opts->radius_limit, ws, cap_samples, d_counters, stream);
     if (rc != PNR_OK) return rc;
     if (prof) PNR_HIP_CHECK(hipEventRecord(g_ev[2], stream));
-    rc = launch_shade(scene, weights, cam, d_dirs, opts->K, ws, cap_samples, stream, prof ? g_ev[3] : nullptr);
+    rc = launch_shade(scene, weights, cam, d_dirs, opts->K, opts->precision, ws, cap_samples, stream,
+                      prof ? g_ev[3] : nullptr);
     if (rc != PNR_OK) return rc;
     if (prof) PNR_HIP_CHECK(hipEventRecord(g_ev[4], stream));
     rc = launch_composite(cam, *opts, R, ws, d_rgb, d_depth, d_acc, d_ray_mask, d_counters, stream);

@@ -3,22 +3,26 @@
 // Replaces studio_utils.py:190-207 (w2pers over ALL N points + five index_select gathers) and
 // studio_model.py:270-365 (boolean compactions, [M,284] / [M,263] materialisations, rocBLAS GEMMs).
 //
-// MI355X design (exact fp32: v_mfma_f32_32x32x2_f32 is bit-for-bit an fp32 fma chain):
+// MI355X design:
 //   * The MLP is evaluated TRANSPOSED, H^T = W . X^T: the weights are the MFMA A operand (output
 //     features on the 32 tile rows), the (sample, neighbour) rows sit on the 32 tile COLUMNS = lanes.
 //     The 32x32 accumulator layout (col = lane&31, row = (r&3) + 8(r>>2) + 4(lane>>5)) is then
-//     exactly a B operand of the next layer (lane<32 supplies input feature F, lane>=32 feature F+4
-//     of one k-step), so a layer's output registers feed the next layer with NO data movement:
-//     no LDS round trip, no barrier, no transposition, activations never leave the VGPR file.
-//     The k-order this implies is baked into the packed weights (pnr_weights_pack).
-//   * One wavefront owns 32 rows (4 samples x K=8 neighbours) and all 256 features:
-//     128 accumulator VGPRs + 128..144 input VGPRs, one wave per SIMD, four waves per CU.
-//   * Weights (1.08 MB for the four 256-wide layers) are L2-resident and streamed straight into VGPRs:
-//     one coalesced 1-KiB dwordx4 load feeds 4 MFMAs (256 cycles); a rolling window of loads stays in flight.
-//   * The gather reads one 176-byte packed row per neighbour (three 16-byte-aligned pieces per lane);
-//     the two lanes that share a row (l and l+32) split its features, so no positional encoding is
-//     computed twice.
-//   * K-aggregation is a segmented butterfly over the 8 lanes of a sample (DPP/shuffle), in registers.
+//     exactly a B operand of the next layer, so a layer's output registers feed the next layer with
+//     NO data movement: no LDS round trip for activations, no transposition; activations never leave
+//     the VGPR file.  The k-order this implies is baked into the packed weights (pnr_weights_pack).
+//   * One wavefront owns 32 rows (4 samples x K=8 neighbours) and all 256 features; one wave per SIMD,
+//     four waves per CU, persistent grid over contiguous tile ranges.
+//   * The gather reads one 176-byte packed row per neighbour; the two lanes that share a row (l, l+32)
+//     split its features, so no positional encoding is computed twice.
+//   * K-aggregation is a segmented butterfly over the 8 lanes of a sample, in registers.
+// Two arithmetic modes (pnr_render_opts_t.precision):
+//   PNR_PRECISION_FP32   v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 fma chain.  Weights stream
+//                        L2 -> VGPR through a buffer descriptor (one 1-KiB load per 4 MFMAs).
+//   PNR_PRECISION_BF16X3 v_mfma_f32_32x32x16_bf16 on hi/lo splits: a*b ~ ah*bh + ah*bl + al*bh with fp32
+//                        accumulation (relative error ~2^-16 per product; RGB within 1e-5 of the fp32
+//                        path on the parity scenes).  3 MFMAs of 32 cycles replace 8 of 64: the weights
+//                        are consumed ~5x faster, so the four waves share them through LDS (double-
+//                        buffered 32..36 KiB tiles, one barrier per output tile).
 #include <algorithm>
 
 #include "pnr_internal.h"
@@ -26,18 +30,21 @@
 namespace pnr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int WAVES = 4;
 constexpr int TPB = WAVES * 64;
-constexpr int PF = 6;  // weight loads (1 KiB each per wave) kept in flight
+constexpr int PF = 6;  // fp32 path: weight loads (1 KiB each per wave) kept in flight
 
 __device__ __forceinline__ float leaky(float x) { return x > 0.f ? x : 0.1f * x; }
 
 struct ShadeParams {
     const float4 *point_rows;  // [N, 11] float4
-    const float *wbuf;         // packed weights
+    const float *wbuf;         // packed weights (fp32 A-operand order, bf16x3 tiles, plain heads, biases)
     size_t wbytes;
-    size_t w_off[9];
+    size_t w_off[9];    // float offsets: fp32-packed layers / plain heads
+    size_t w16_off[9];  // float offsets: bf16x3-packed layers (0 for the heads)
     size_t b_off[9];
     float Rw2c[9];
     Camera cam;
@@ -53,21 +60,218 @@ struct ShadeParams {
     int K;
 };
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// 16 bytes per lane of packed weights: buffer load with the (wave-uniform) byte offset in an SGPR, so the
-// ~1000 loads of an unrolled layer share ONE address VGPR (lane * 16).  With 64-bit global addresses hipcc
-// hoists a distinct address pair per load out of the tile loop and spills ~2000 VGPRs.
 __device__ __forceinline__ float4 load_w(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff)
 {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-// One dense layer on the matrix cores.  in[KSP] are this lane's B-operand registers (k-step t: the lane
-// supplies one input feature of its row), out[MT*16] the accumulators.  The layer's packed A operands
-// ([MT][KSP/4][64 lanes] float4) start at byte offset wbase of the weight buffer.  Bias is pre-loaded into
-// the accumulators.
+__device__ __forceinline__ void rot_rows(const float (&M)[9], float x, float y, float z, float &ox, float &oy,
+                                         float &oz)
+{
+    // v @ M^T : out[i] = sum_j v[j] * M[i][j]
+    ox = x * M[0] + y * M[1] + z * M[2];
+    oy = x * M[3] + y * M[4] + z * M[5];
+    oz = x * M[6] + y * M[7] + z * M[8];
+}
+
+__device__ __forceinline__ void to_cam(const Camera &cam, float x, float y, float z, float &cx, float &cy, float &cz)
+{
+    // (p - o) @ Rc2w : out[i] = sum_j s[j] * R[j][i]      (studio_utils.py:129-144)
+    const float sx = x - cam.o[0], sy = y - cam.o[1], sz = z - cam.o[2];
+    cx = sx * cam.R[0] + sy * cam.R[3] + sz * cam.R[6];
+    cy = sx * cam.R[1] + sy * cam.R[4] + sz * cam.R[7];
+    cz = sx * cam.R[2] + sy * cam.R[5] + sz * cam.R[8];
+}
+
+// sum over the K lanes of one sample (lanes [g*K, g*K+K) inside each 32-lane half)
+template <bool POW2_8>
+__device__ __forceinline__ float seg_sum(float v, int K, int lane)
+{
+    if (POW2_8) {
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        return v;
+    } else {
+        const int j = lane & 31;
+        const int base = (lane & 32) + (j / K) * K;
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s += __shfl(v, min(base + k, 63), 64);
+        return s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// rows of a tile: gather + per-row features (shared by both arithmetic modes)
+// ------------------------------------------------------------------------------------------------
+struct RowCtx {
+    int v_idx;    // valid-sample index of this lane's row
+    int slot;     // neighbour slot of the row
+    bool row_ok;  // the row maps to a real (sample, slot)
+    float wgt;    // normalised inverse-distance weight (0 for unfilled slots)
+    float ex[4];  // this lane half's share of [color(3), dir - view (3), <dir, view>, 0]
+};
+
+// x0: the lane's 144 layer-1 input values; value i = 8s + j is element j of k-step s in the bf16 path and
+// k-step t = i in the fp32 path.  Lane half h = 0 carries emb[0:16], their encodings and the rotated world
+// distances, h = 1 carries emb[16:32], their encodings and the camera-space distances.
+template <bool K8>
+__device__ __forceinline__ void load_rows(const ShadeParams &P, int tile, int lane, int wave, int S_valid,
+                                          float (&x0)[144], RowCtx &ctx)
+{
+    const int j = lane & 31, h = lane >> 5;
+    const int K = K8 ? 8 : P.K;
+    const int SPW = 32 / K;
+    const int SPT = SPW * WAVES;
+    const int sl = j / K;
+    ctx.v_idx = tile * SPT + wave * SPW + sl;
+    ctx.row_ok = (j < SPW * K) && (ctx.v_idx < S_valid);
+    ctx.slot = j - sl * K;
+    const int s = ctx.row_ok ? P.vs_list[ctx.v_idx] : 0;
+    int pidx = ctx.row_ok ? P.smp_pidx[(int64_t)s * K + ctx.slot] : -1;
+    const bool valid = pidx >= 0;
+    pidx = max(pidx, 0);
+    const float4 *row = P.point_rows + (int64_t)pidx * 11;
+    const float4 a0 = row[0];
+    const float4 e0 = row[1 + 4 * h], e1 = row[2 + 4 * h], e2 = row[3 + 4 * h], e3 = row[4 + 4 * h];
+    const float4 c0 = row[9], c1 = row[10];
+    const float4 loc = P.smp_loc[s];
+    const int ray = P.smp_ray[s];
+    const float dirx = P.dirs[3 * (int64_t)ray], diry = P.dirs[3 * (int64_t)ray + 1],
+                dirz = P.dirs[3 * (int64_t)ray + 2];
+
+    // dists + inverse-distance weight (studio_model.py:270-286,467-475)
+    const float dwx = a0.x - loc.x, dwy = a0.y - loc.y, dwz = a0.z - loc.z;
+    const float nrm = sqrtf(dwx * dwx + dwy * dwy + dwz * dwz);
+    float wgt = valid ? 1.0f / fmaxf(nrm, 1e-6f) : 0.f;
+    const float wsum = seg_sum<K8>(wgt, K, lane);
+    ctx.wgt = wgt / fmaxf(wsum, 1e-8f);
+
+    float dd[3];
+    if (h == 0) {
+        rot_rows(P.Rw2c, dwx, dwy, dwz, dd[0], dd[1], dd[2]);  // dists[:3] @ Rw2c^T   (studio_model.py:313)
+    } else {
+        float pcx, pcy, pcz, scx, scy, scz;
+        to_cam(P.cam, a0.x, a0.y, a0.z, pcx, pcy, pcz);
+        to_cam(P.cam, loc.x, loc.y, loc.z, scx, scy, scz);
+        const float ppx = pcx / pcz, ppy = pcy / pcz, spx = scx / scz, spy = scy / scz;
+        dd[0] = ppx * pcz - spx * scz;
+        dd[1] = ppy * pcz - spy * scz;
+        dd[2] = pcz - scz;
+    }
+    const float e[16] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w,
+                         e2.x, e2.y, e2.z, e2.w, e3.x, e3.y, e3.z, e3.w};
+#pragma unroll
+    for (int d = 0; d < 16; ++d) x0[d] = e[d];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            float sn, cs;
+            sincosf(e[d] * (float)(1 << f), &sn, &cs);
+            x0[16 + (d * 3 + f) * 2 + 0] = sn;
+            x0[16 + (d * 3 + f) * 2 + 1] = cs;
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+#pragma unroll
+        for (int f = 0; f < 5; ++f) {
+            float sn, cs;
+            sincosf(dd[d] * (float)(1 << f), &sn, &cs);
+            x0[112 + (d * 5 + f) * 2 + 0] = sn;
+            x0[112 + (d * 5 + f) * 2 + 1] = cs;
+        }
+    }
+    x0[142] = 0.f;
+    x0[143] = 0.f;
+
+    // [color(3), dir @ Rw2c^T - view (3), <dir @ Rw2c^T, view> (1)]   (studio_model.py:322-335)
+    float sdx, sdy, sdz, vx, vy, vz;
+    rot_rows(P.Rw2c, c0.w, c1.x, c1.y, sdx, sdy, sdz);
+    rot_rows(P.Rw2c, dirx, diry, dirz, vx, vy, vz);
+    const float dv0 = sdx - vx, dv1 = sdy - vy, dv2 = sdz - vz;
+    const float dot = sdx * vx + sdy * vy + sdz * vz;
+    ctx.ex[0] = h ? c0.y : c0.x;
+    ctx.ex[1] = h ? dv0 : c0.z;
+    ctx.ex[2] = h ? dv2 : dv1;
+    ctx.ex[3] = h ? 0.f : dot;
+}
+
+// density head + weighted K-aggregation + stores (studio_model.py:337-353)
+template <bool K8>
+__device__ __forceinline__ void finish_rows(const ShadeParams &P, int lane, const float (&hC)[128],
+                                            const RowCtx &ctx)
+{
+    const int h = lane >> 5;
+    const int K = K8 ? 8 : P.K;
+    const float *w4 = P.wbuf + P.w_off[4];
+    const float b4 = P.wbuf[P.b_off[4]];
+    float part = 0.f;
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 wv = *reinterpret_cast<const float4 *>(w4 + 32 * m + 8 * q + 4 * h);
+            part += hC[m * 16 + 4 * q + 0] * wv.x;
+            part += hC[m * 16 + 4 * q + 1] * wv.y;
+            part += hC[m * 16 + 4 * q + 2] * wv.z;
+            part += hC[m * 16 + 4 * q + 3] * wv.w;
+        }
+    part += __shfl_xor(part, 32, 64);
+    const float alpha = fmaxf(part + b4, 0.f);
+    const float sigma = seg_sum<K8>(alpha * ctx.wgt, K, lane);
+    const bool writer = ctx.row_ok && ctx.slot == 0;
+    if (writer && h == 0) P.smp_sigma[ctx.v_idx] = sigma;
+    float *dst = P.agg + (int64_t)ctx.v_idx * 256;
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 o;
+            o.x = seg_sum<K8>(hC[m * 16 + 4 * q + 0] * ctx.wgt, K, lane);
+            o.y = seg_sum<K8>(hC[m * 16 + 4 * q + 1] * ctx.wgt, K, lane);
+            o.z = seg_sum<K8>(hC[m * 16 + 4 * q + 2] * ctx.wgt, K, lane);
+            o.w = seg_sum<K8>(hC[m * 16 + 4 * q + 3] * ctx.wgt, K, lane);
+            if (writer) *reinterpret_cast<float4 *>(dst + 32 * m + 8 * q + 4 * h) = o;
+        }
+}
+
+// colour head on the last hidden layer: 128 -> 3, sigmoid, widen (studio_model.py:357-359)
+__device__ __forceinline__ void color_head(const ShadeParams &P, int lane, const float (&hA)[64], float (&rgb)[3])
+{
+    const int h = lane >> 5;
+    const float *w8 = P.wbuf + P.w_off[8];
+    const float *b8 = P.wbuf + P.b_off[8];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float part = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 wv = *reinterpret_cast<const float4 *>(w8 + c * 128 + 32 * m + 8 * q + 4 * h);
+                part += hA[m * 16 + 4 * q + 0] * wv.x;
+                part += hA[m * 16 + 4 * q + 1] * wv.y;
+                part += hA[m * 16 + 4 * q + 2] * wv.z;
+                part += hA[m * 16 + 4 * q + 3] * wv.w;
+            }
+        part += __shfl_xor(part, 32, 64);
+        const float z = part + b8[c];
+        const float sg = 1.0f / (1.0f + expf(-z));
+        rgb[c] = sg * (1.0f + 2.0f * 0.001f) - 0.001f;
+    }
+}
+
+// ================================================================================================
+// fp32 mode
+// ================================================================================================
+// One dense layer.  in[KSP] are this lane's B-operand registers (k-step t: the lane supplies one input
+// feature of its row), out[MT*16] the accumulators.  The layer's packed A operands ([MT][KSP/4][64 lanes]
+// float4) start at byte offset wbase of the weight buffer: buffer loads with the wave-uniform offset in an
+// SGPR, so the ~1000 loads of an unrolled layer share ONE address VGPR (with 64-bit global addresses hipcc
+// hoists a distinct address pair per load out of the tile loop and spills ~2000 VGPRs).
 template <int KSP, int MT>
 __device__ __forceinline__ void dense_layer(__amdgpu_buffer_rsrc_t rsrc, int wbase, const float *__restrict__ bias,
                                             int lane, const float (&in)[KSP], float (&out)[MT * 16])
@@ -110,51 +314,13 @@ __device__ __forceinline__ void dense_layer(__amdgpu_buffer_rsrc_t rsrc, int wba
         for (int r = 0; r < 16; ++r) out[m * 16 + r] = acc[m][r];
 }
 
-__device__ __forceinline__ void rot_rows(const float (&M)[9], float x, float y, float z, float &ox, float &oy,
-                                         float &oz)
-{
-    // v @ M^T : out[i] = sum_j v[j] * M[i][j]
-    ox = x * M[0] + y * M[1] + z * M[2];
-    oy = x * M[3] + y * M[4] + z * M[5];
-    oz = x * M[6] + y * M[7] + z * M[8];
-}
-
-__device__ __forceinline__ void to_cam(const Camera &cam, float x, float y, float z, float &cx, float &cy, float &cz)
-{
-    // (p - o) @ Rc2w : out[i] = sum_j s[j] * R[j][i]      (studio_utils.py:129-144)
-    const float sx = x - cam.o[0], sy = y - cam.o[1], sz = z - cam.o[2];
-    cx = sx * cam.R[0] + sy * cam.R[3] + sz * cam.R[6];
-    cy = sx * cam.R[1] + sy * cam.R[4] + sz * cam.R[7];
-    cz = sx * cam.R[2] + sy * cam.R[5] + sz * cam.R[8];
-}
-
-// sum over the K lanes of one sample (lanes [g*K, g*K+K) inside each 32-lane half)
-template <bool POW2_8>
-__device__ __forceinline__ float seg_sum(float v, int K, int lane)
-{
-    if (POW2_8) {
-        v += __shfl_xor(v, 1, 64);
-        v += __shfl_xor(v, 2, 64);
-        v += __shfl_xor(v, 4, 64);
-        return v;
-    } else {
-        const int j = lane & 31;
-        const int base = (lane & 32) + (j / K) * K;
-        float s = 0.f;
-        for (int k = 0; k < K; ++k) s += __shfl(v, min(base + k, 63), 64);
-        return s;
-    }
-}
-
 template <bool K8>
 __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
 {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int j = lane & 31, h = lane >> 5;
     const int K = K8 ? 8 : P.K;
-    const int SPW = 32 / K;          // samples per wave
-    const int SPT = SPW * WAVES;     // samples per workgroup tile
+    const int SPT = (32 / K) * WAVES;  // samples per workgroup tile
     const int S_valid = P.n_sel[1];
     const int ntiles = (S_valid + SPT - 1) / SPT;
     // contiguous tile range per workgroup: neighbouring samples (same / adjacent rays) stay on one XCD's L2
@@ -167,85 +333,16 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
               w3_ = (int)(P.w_off[3] * 4);
     const float *b0 = P.wbuf + P.b_off[0], *b1 = P.wbuf + P.b_off[1], *b2 = P.wbuf + P.b_off[2],
                 *b3 = P.wbuf + P.b_off[3];
-    const float *w4 = P.wbuf + P.w_off[4];
-    const float b4 = P.wbuf[P.b_off[4]];
 
     for (int tile = t_begin; tile < t_end; ++tile) {
         // opaque per iteration: otherwise the ~1000 scalar load offsets are hoisted out of this loop and
         // spilled to VGPR lanes
         int w0 = w0_, w1 = w1_, w2 = w2_, w3 = w3_;
         asm volatile("" : "+s"(w0), "+s"(w1), "+s"(w2), "+s"(w3));
-        // ---- which (sample, neighbour) row does this lane carry --------------------------------------
-        const int sl = j / K;  // sample slot inside the wave
-        const int v_idx = tile * SPT + wave * SPW + sl;
-        const bool row_ok = (j < SPW * K) && (v_idx < S_valid);
-        const int s = row_ok ? P.vs_list[v_idx] : 0;
-        const int slot = j - sl * K;
-        int pidx = row_ok ? P.smp_pidx[(int64_t)s * K + slot] : -1;
-        const bool valid = pidx >= 0;
-        pidx = max(pidx, 0);
-        const float4 *row = P.point_rows + (int64_t)pidx * 11;
-        const float4 a0 = row[0];
-        const float4 e0 = row[1 + 4 * h], e1 = row[2 + 4 * h], e2 = row[3 + 4 * h], e3 = row[4 + 4 * h];
-        const float4 c0 = row[9], c1 = row[10];
-        const float4 loc = P.smp_loc[s];
-        const int ray = P.smp_ray[s];
-        const float dirx = P.dirs[3 * (int64_t)ray], diry = P.dirs[3 * (int64_t)ray + 1],
-                    dirz = P.dirs[3 * (int64_t)ray + 2];
-
-        // ---- dists + inverse-distance weight (studio_model.py:270-286,467-475) ------------------------
-        const float dwx = a0.x - loc.x, dwy = a0.y - loc.y, dwz = a0.z - loc.z;
-        const float nrm = sqrtf(dwx * dwx + dwy * dwy + dwz * dwz);
-        float wgt = valid ? 1.0f / fmaxf(nrm, 1e-6f) : 0.f;
-        const float wsum = seg_sum<K8>(wgt, K, lane);
-        wgt = wgt / fmaxf(wsum, 1e-8f);
-
-        float dd0, dd1, dd2;
-        if (h == 0) {
-            rot_rows(P.Rw2c, dwx, dwy, dwz, dd0, dd1, dd2);  // dists[:3] @ Rw2c^T   (studio_model.py:313)
-        } else {
-            float pcx, pcy, pcz, scx, scy, scz;
-            to_cam(P.cam, a0.x, a0.y, a0.z, pcx, pcy, pcz);
-            to_cam(P.cam, loc.x, loc.y, loc.z, scx, scy, scz);
-            const float ppx = pcx / pcz, ppy = pcy / pcz, spx = scx / scz, spy = scy / scz;
-            dd0 = ppx * pcz - spx * scz;
-            dd1 = ppy * pcz - spy * scz;
-            dd2 = pcz - scz;
-        }
-
-        // ---- layer-1 input: [emb | PE(emb,3) | PE(dists6,5)], 142 k-steps (+2 zero) --------------------
         float x0[144];
-        {
-            const float e[16] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w,
-                                 e2.x, e2.y, e2.z, e2.w, e3.x, e3.y, e3.z, e3.w};
-#pragma unroll
-            for (int d = 0; d < 16; ++d) x0[d] = e[d];
-#pragma unroll
-            for (int d = 0; d < 16; ++d) {
-#pragma unroll
-                for (int f = 0; f < 3; ++f) {
-                    float sn, cs;
-                    sincosf(e[d] * (float)(1 << f), &sn, &cs);
-                    x0[16 + (d * 3 + f) * 2 + 0] = sn;
-                    x0[16 + (d * 3 + f) * 2 + 1] = cs;
-                }
-            }
-            const float dd[3] = {dd0, dd1, dd2};
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-#pragma unroll
-                for (int f = 0; f < 5; ++f) {
-                    float sn, cs;
-                    sincosf(dd[d] * (float)(1 << f), &sn, &cs);
-                    x0[112 + (d * 5 + f) * 2 + 0] = sn;
-                    x0[112 + (d * 5 + f) * 2 + 1] = cs;
-                }
-            }
-            x0[142] = 0.f;
-            x0[143] = 0.f;
-        }
+        RowCtx ctx;
+        load_rows<K8>(P, tile, lane, wave, S_valid, x0, ctx);
 
-        // ---- mlp_base (284 -> 256 -> 256), mlp_head (263 -> 256 -> 256) --------------------------------
         float hA[128];
         dense_layer<144, 8>(rsrc, w0, b0, lane, x0, hA);
 #pragma unroll
@@ -257,18 +354,8 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
 #pragma unroll
             for (int i = 0; i < 128; ++i) hB[i] = leaky(tmp[i]);
         }
-        {
-            // [color(3), dir @ Rw2c^T - view (3), <dir @ Rw2c^T, view> (1)]   (studio_model.py:322-335)
-            float sdx, sdy, sdz, vx, vy, vz;
-            rot_rows(P.Rw2c, c0.w, c1.x, c1.y, sdx, sdy, sdz);
-            rot_rows(P.Rw2c, dirx, diry, dirz, vx, vy, vz);
-            const float dv0 = sdx - vx, dv1 = sdy - vy, dv2 = sdz - vz;
-            const float dot = sdx * vx + sdy * vy + sdz * vz;
-            hB[128] = h ? c0.y : c0.x;
-            hB[129] = h ? dv0 : c0.z;
-            hB[130] = h ? dv2 : dv1;
-            hB[131] = h ? 0.f : dot;
-        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hB[128 + i] = ctx.ex[i];
         dense_layer<132, 8>(rsrc, w2, b2, lane, hB, hA);
 #pragma unroll
         for (int i = 0; i < 128; ++i) hA[i] = leaky(hA[i]);
@@ -276,38 +363,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
         dense_layer<128, 8>(rsrc, w3, b3, lane, hA, hC);
 #pragma unroll
         for (int i = 0; i < 128; ++i) hC[i] = leaky(hC[i]);
-
-        // ---- density head: alpha_k = relu(<w4, h> + b4) (studio_model.py:337) ---------------------------
-        float part = 0.f;
-#pragma unroll
-        for (int m = 0; m < 8; ++m)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 wv = *reinterpret_cast<const float4 *>(w4 + 32 * m + 8 * q + 4 * h);
-                part += hC[m * 16 + 4 * q + 0] * wv.x;
-                part += hC[m * 16 + 4 * q + 1] * wv.y;
-                part += hC[m * 16 + 4 * q + 2] * wv.z;
-                part += hC[m * 16 + 4 * q + 3] * wv.w;
-            }
-        part += __shfl_xor(part, 32, 64);
-        const float alpha = fmaxf(part + b4, 0.f);
-
-        // ---- weighted K-aggregation (studio_model.py:344,353) ------------------------------------------
-        const float sigma = seg_sum<K8>(alpha * wgt, K, lane);
-        const bool writer = row_ok && slot == 0;
-        if (writer && h == 0) P.smp_sigma[v_idx] = sigma;
-        float *dst = P.agg + (int64_t)v_idx * 256;
-#pragma unroll
-        for (int m = 0; m < 8; ++m)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float4 o;
-                o.x = seg_sum<K8>(hC[m * 16 + 4 * q + 0] * wgt, K, lane);
-                o.y = seg_sum<K8>(hC[m * 16 + 4 * q + 1] * wgt, K, lane);
-                o.z = seg_sum<K8>(hC[m * 16 + 4 * q + 2] * wgt, K, lane);
-                o.w = seg_sum<K8>(hC[m * 16 + 4 * q + 3] * wgt, K, lane);
-                if (writer) *reinterpret_cast<float4 *>(dst + 32 * m + 8 * q + 4 * h) = o;
-            }
+        finish_rows<K8>(P, lane, hC, ctx);
     }
 }
 
@@ -325,8 +381,6 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_color(ShadeParams P)
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wbuf), 0, (int)P.wbytes, 0x00020000);
     const int w5_ = (int)(P.w_off[5] * 4), w6_ = (int)(P.w_off[6] * 4), w7_ = (int)(P.w_off[7] * 4);
     const float *b5 = P.wbuf + P.b_off[5], *b6 = P.wbuf + P.b_off[6], *b7 = P.wbuf + P.b_off[7];
-    const float *w8 = P.wbuf + P.w_off[8];
-    const float *b8 = P.wbuf + P.b_off[8];
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int w5 = w5_, w6 = w6_, w7 = w7_;
@@ -368,30 +422,239 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_color(ShadeParams P)
 #pragma unroll
         for (int i = 0; i < 64; ++i) hA[i] = leaky(hA[i]);
         float rgb[3];
+        color_head(P, lane, hA, rgb);
+        if (ok && h == 0) P.smp_out[s] = make_float4(P.smp_sigma[v_idx], rgb[0], rgb[1], rgb[2]);
+    }
+}
+
+// ================================================================================================
+// bf16x3 mode
+// ================================================================================================
+constexpr int STAGE_U4 = 9 * 256;  // one LDS weight tile: up to 18 k-steps x {hi, lo} x 64 lanes x 16 B = 36 KiB
+constexpr int STAGE_ROUNDS_MAX = 9;
+
+__device__ __forceinline__ void split8(const float *v, bf16x8 &hi, bf16x8 &lo)
+{
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float part = 0.f;
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 hb = (__bf16)v[j];
+        hi[j] = hb;
+        lo[j] = (__bf16)(v[j] - (float)hb);
+    }
+}
+
+// global -> registers: ROUNDS 16-byte pieces per thread of the tile starting at byte offset `off`
+template <int ROUNDS>
+__device__ __forceinline__ void stage_load(__amdgpu_buffer_rsrc_t rsrc, int off, int tid, u32x4 (&r)[STAGE_ROUNDS_MAX])
+{
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+    for (int i = 0; i < ROUNDS; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tid * 16, off + i * 4096, 0);
+}
+
+template <int ROUNDS>
+__device__ __forceinline__ void stage_store(u32x4 *lds, int tid, const u32x4 (&r)[STAGE_ROUNDS_MAX])
+{
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 wv = *reinterpret_cast<const float4 *>(w8 + c * 128 + 32 * m + 8 * q + 4 * h);
-                    part += hA[m * 16 + 4 * q + 0] * wv.x;
-                    part += hA[m * 16 + 4 * q + 1] * wv.y;
-                    part += hA[m * 16 + 4 * q + 2] * wv.z;
-                    part += hA[m * 16 + 4 * q + 3] * wv.w;
-                }
-            part += __shfl_xor(part, 32, 64);
-            const float z = part + b8[c];
-            const float sg = 1.0f / (1.0f + expf(-z));
-            rgb[c] = sg * (1.0f + 2.0f * 0.001f) - 0.001f;  // studio_model.py:359
+    for (int i = 0; i < ROUNDS; ++i) lds[i * 256 + tid] = r[i];
+}
+
+// One dense layer on bf16 hi/lo splits.  MT output tiles of 32 features; tile m's weights
+// ([KS][{hi,lo}][64 lanes][8 bf16], KS * 2 KiB) must already sit in LDS buffer (m & 1) when the layer
+// starts (the previous layer staged it); while tile m is multiplied, tile m+1 (or the first tile of the NEXT
+// layer, KS_NEXT k-steps at byte offset wnext) is fetched into registers and written to the other buffer.
+template <int KS, int MT, int KS_NEXT>
+__device__ __forceinline__ void dense_layer_bf16(__amdgpu_buffer_rsrc_t rsrc, int wbase, int wnext,
+                                                 const float *__restrict__ bias, int lane, int tid, u32x4 *lds,
+                                                 const bf16x8 *xh, const bf16x8 *xl, float (&out)[MT * 16])
+{
+    static_assert(MT % 2 == 0, "buffer parity must be preserved across layers");
+    const int h = lane >> 5;
+    u32x4 stage[STAGE_ROUNDS_MAX];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        if (m + 1 < MT)
+            stage_load<(KS + 1) / 2>(rsrc, wbase + (m + 1) * KS * 2048, tid, stage);
+        else
+            stage_load<(KS_NEXT + 1) / 2>(rsrc, wnext, tid, stage);
+        const u32x4 *cur = lds + (m & 1) * STAGE_U4;
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 b = *reinterpret_cast<const float4 *>(bias + 32 * m + 8 * q + 4 * h);
+            acc[4 * q + 0] = b.x;
+            acc[4 * q + 1] = b.y;
+            acc[4 * q + 2] = b.z;
+            acc[4 * q + 3] = b.w;
         }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const bf16x8 wh = __builtin_bit_cast(bf16x8, cur[(2 * s) * 64 + lane]);
+            const bf16x8 wl = __builtin_bit_cast(bf16x8, cur[(2 * s + 1) * 64 + lane]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[s], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[m * 16 + r] = acc[r];
+        u32x4 *nxt = lds + ((m + 1) & 1) * STAGE_U4;
+        if (m + 1 < MT)
+            stage_store<(KS + 1) / 2>(nxt, tid, stage);
+        else
+            stage_store<(KS_NEXT + 1) / 2>(nxt, tid, stage);
+        __syncthreads();
+    }
+}
+
+// activation + hi/lo split of a layer's output into the next layer's operands
+template <int MT>
+__device__ __forceinline__ void act_split(const float (&o)[MT * 16], bf16x8 *xh, bf16x8 *xl)
+{
+#pragma unroll
+    for (int s = 0; s < 2 * MT; ++s) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = leaky(o[8 * s + j]);
+        split8(v, xh[s], xl[s]);
+    }
+}
+
+template <bool K8>
+__global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
+{
+    __shared__ u32x4 lds[2 * STAGE_U4];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int K = K8 ? 8 : P.K;
+    const int SPT = (32 / K) * WAVES;
+    const int S_valid = P.n_sel[1];
+    const int ntiles = (S_valid + SPT - 1) / SPT;
+    const int t_begin = (int)(((int64_t)ntiles * blockIdx.x) / gridDim.x);
+    const int t_end = (int)(((int64_t)ntiles * (blockIdx.x + 1)) / gridDim.x);
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wbuf), 0, (int)P.wbytes, 0x00020000);
+    const int w0_ = (int)(P.w16_off[0] * 4), w1_ = (int)(P.w16_off[1] * 4), w2_ = (int)(P.w16_off[2] * 4),
+              w3_ = (int)(P.w16_off[3] * 4);
+    const float *b0 = P.wbuf + P.b_off[0], *b1 = P.wbuf + P.b_off[1], *b2 = P.wbuf + P.b_off[2],
+                *b3 = P.wbuf + P.b_off[3];
+    if (t_begin >= t_end) return;  // uniform per workgroup
+    {
+        // first weight tile of the chain into LDS buffer 0
+        u32x4 st[STAGE_ROUNDS_MAX];
+        stage_load<9>(rsrc, w0_, tid, st);
+        stage_store<9>(lds, tid, st);
+        __syncthreads();
+    }
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        int w0 = w0_, w1 = w1_, w2 = w2_, w3 = w3_;
+        asm volatile("" : "+s"(w0), "+s"(w1), "+s"(w2), "+s"(w3));
+        RowCtx ctx;
+        bf16x8 xh[18], xl[18];
+        {
+            float x0[144];
+            load_rows<K8>(P, tile, lane, wave, S_valid, x0, ctx);
+#pragma unroll
+            for (int s = 0; s < 18; ++s) split8(&x0[8 * s], xh[s], xl[s]);
+        }
+        float o[128];
+        dense_layer_bf16<18, 8, 16>(rsrc, w0, w1, b0, lane, tid, lds, xh, xl, o);
+        bf16x8 yh[17], yl[17];
+        act_split<8>(o, yh, yl);
+        dense_layer_bf16<16, 8, 17>(rsrc, w1, w2, b1, lane, tid, lds, yh, yl, o);
+        act_split<8>(o, yh, yl);
+        {
+            float v[8] = {ctx.ex[0], ctx.ex[1], ctx.ex[2], ctx.ex[3], 0.f, 0.f, 0.f, 0.f};
+            split8(v, yh[16], yl[16]);
+        }
+        dense_layer_bf16<17, 8, 16>(rsrc, w2, w3, b2, lane, tid, lds, yh, yl, o);
+        act_split<8>(o, yh, yl);
+        // the chain wraps around: the next pair tile starts again with layer 0, tile 0
+        dense_layer_bf16<16, 8, 18>(rsrc, w3, w0, b3, lane, tid, lds, yh, yl, o);
+#pragma unroll
+        for (int i = 0; i < 128; ++i) o[i] = leaky(o[i]);
+        finish_rows<K8>(P, lane, o, ctx);
+    }
+}
+
+__global__ void __launch_bounds__(TPB, 1) k_shade_color_bf16(ShadeParams P)
+{
+    __shared__ u32x4 lds[2 * STAGE_U4];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int S_valid = P.n_sel[1];
+    constexpr int SPT = 32 * WAVES;
+    const int ntiles = (S_valid + SPT - 1) / SPT;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wbuf), 0, (int)P.wbytes, 0x00020000);
+    const int w5_ = (int)(P.w16_off[5] * 4), w6_ = (int)(P.w16_off[6] * 4), w7_ = (int)(P.w16_off[7] * 4);
+    const float *b5 = P.wbuf + P.b_off[5], *b6 = P.wbuf + P.b_off[6], *b7 = P.wbuf + P.b_off[7];
+    if ((int)blockIdx.x >= ntiles) return;
+    {
+        u32x4 st[STAGE_ROUNDS_MAX];
+        stage_load<9>(rsrc, w5_, tid, st);
+        stage_store<9>(lds, tid, st);
+        __syncthreads();
+    }
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int w5 = w5_, w6 = w6_, w7 = w7_;
+        asm volatile("" : "+s"(w5), "+s"(w6), "+s"(w7));
+        const int v_idx = tile * SPT + wave * 32 + j;
+        const bool ok = v_idx < S_valid;
+        const int s = ok ? P.vs_list[v_idx] : 0;
+        const int ray = P.smp_ray[s];
+        const float *src = P.agg + (int64_t)(ok ? v_idx : 0) * 256;
+        bf16x8 xh[18], xl[18];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            // k-step k: this lane half supplies features 16k + 8h .. 16k + 8h + 7
+            const float4 a = *reinterpret_cast<const float4 *>(src + 16 * k + 8 * h);
+            const float4 b = *reinterpret_cast<const float4 *>(src + 16 * k + 8 * h + 4);
+            const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            split8(v, xh[k], xl[k]);
+        }
+        {
+            float vx, vy, vz;
+            rot_rows(P.Rw2c, P.dirs[3 * (int64_t)ray], P.dirs[3 * (int64_t)ray + 1], P.dirs[3 * (int64_t)ray + 2], vx,
+                     vy, vz);
+            const float vv[3] = {vx, vy, vz};
+            float p[24];  // [sin(d*4+f) (12) | cos (12)]
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    float sn, cs;
+                    sincosf(vv[d] * (float)(1 << f), &sn, &cs);
+                    p[d * 4 + f] = sn;
+                    p[12 + d * 4 + f] = cs;
+                }
+            float v16[8], v17[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                v16[q] = h ? p[8 + q] : p[q];
+                v17[q] = h ? 0.f : p[16 + q];
+            }
+            split8(v16, xh[16], xl[16]);
+            split8(v17, xh[17], xl[17]);
+        }
+        float o[64];
+        dense_layer_bf16<18, 4, 8>(rsrc, w5, w6, b5, lane, tid, lds, xh, xl, o);
+        bf16x8 yh[8], yl[8];
+        act_split<4>(o, yh, yl);
+        dense_layer_bf16<8, 4, 8>(rsrc, w6, w7, b6, lane, tid, lds, yh, yl, o);
+        act_split<4>(o, yh, yl);
+        dense_layer_bf16<8, 4, 18>(rsrc, w7, w5, b7, lane, tid, lds, yh, yl, o);
+#pragma unroll
+        for (int i = 0; i < 64; ++i) o[i] = leaky(o[i]);
+        float rgb[3];
+        color_head(P, lane, o, rgb);
         if (ok && h == 0) P.smp_out[s] = make_float4(P.smp_sigma[v_idx], rgb[0], rgb[1], rgb[2]);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// weight packing: PyTorch [out,in] -> MFMA A-operand order (see header comment)
+// weight packing: PyTorch [out,in] -> MFMA A-operand order
 // ------------------------------------------------------------------------------------------------
 enum LayerKind { L_BASE0 = 0, L_HIDDEN = 1, L_HEAD0 = 2, L_COLOR0 = 3 };
 
@@ -401,7 +664,8 @@ __device__ __forceinline__ int hidden_feat(int t, int h)
     return 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
 }
 
-__device__ int feat_of(int kind, int t, int h, int n_in_hidden)
+// fp32 path: input feature of k-step t for lane half h
+__device__ int feat_of(int kind, int t, int h, int n_in)
 {
     switch (kind) {
     case L_BASE0:
@@ -416,7 +680,7 @@ __device__ int feat_of(int kind, int t, int h, int n_in_hidden)
         }
         return -1;
     case L_HIDDEN:
-        return t < n_in_hidden / 2 ? hidden_feat(t, h) : -1;
+        return t < n_in / 2 ? hidden_feat(t, h) : -1;
     case L_HEAD0:
         if (t < 128) return hidden_feat(t, h);
         if (t == 128) return h ? 257 : 256;
@@ -428,6 +692,32 @@ __device__ int feat_of(int kind, int t, int h, int n_in_hidden)
         if (t < 128) return 8 * (t >> 2) + 4 * h + (t & 3);
         if (t < 140) return (h ? 268 : 256) + (t - 128);
         return -1;
+    }
+    return -1;
+}
+
+// bf16 path: input feature of element j of k-step s (16 features) for lane half h.  Hidden layers: the
+// accumulator registers 8s'..8s'+7 of output tile m ARE k-step 2m+s' (row = 16s' + 8(j>>2) + 4h + (j&3)).
+__device__ int feat16_of(int kind, int s, int h, int j, int n_in)
+{
+    const int hid = 32 * (s >> 1) + 16 * (s & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
+    switch (kind) {
+    case L_BASE0:
+        return feat_of(L_BASE0, 8 * s + j, h, n_in);  // the lane's value i = 8s + j, same order as the fp32 path
+    case L_HIDDEN:
+        return s < n_in / 16 ? hid : -1;
+    case L_HEAD0:
+        if (s < 16) return hid;
+        if (s == 16 && j < 4) {
+            const int lo[4] = {256, 258, 260, 262}, hi[4] = {257, 259, 261, -1};
+            return h ? hi[j] : lo[j];
+        }
+        return -1;
+    case L_COLOR0: {
+        if (s < 16) return 16 * s + 8 * h + j;
+        const int f = 256 + (s - 16) * 16 + 8 * h + j;
+        return f < 280 ? f : -1;
+    }
     }
     return -1;
 }
@@ -447,6 +737,26 @@ __global__ void k_pack_layer(const float *__restrict__ W, int n_out, int n_in, i
     }
 }
 
+__global__ void k_pack_layer_bf16(const float *__restrict__ W, int n_out, int n_in, int kind, int ks,
+                                  unsigned short *__restrict__ dst)
+{
+    // dst[(((m*KS + s)*2 + plane)*64 + lane)*8 + j] = {hi, lo}(W[32m + (lane&31)][feat16(s, lane>>5, j)])
+    const int mt = n_out / 32;
+    const int64_t total = (int64_t)mt * ks * 64 * 8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        const int64_t ms = i >> 9;
+        const int s = (int)(ms % ks), m = (int)(ms / ks);
+        const int f = feat16_of(kind, s, lane >> 5, j, n_in);
+        const float w = (f >= 0 && f < n_in) ? W[(int64_t)(32 * m + (lane & 31)) * n_in + f] : 0.f;
+        const __bf16 hb = (__bf16)w;
+        const __bf16 lb = (__bf16)(w - (float)hb);
+        const int64_t base = ((ms * 2) * 64 + lane) * 8 + j;
+        dst[base] = __builtin_bit_cast(unsigned short, hb);
+        dst[base + 64 * 8] = __builtin_bit_cast(unsigned short, lb);
+    }
+}
+
 __global__ void k_copy(const float *__restrict__ src, int n, float *__restrict__ dst)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -454,7 +764,7 @@ __global__ void k_copy(const float *__restrict__ src, int n, float *__restrict__
 }
 
 int launch_shade(const pnr_scene *scene, const pnr_weights *w, const Camera &cam, const float *d_dirs, int K,
-                 RenderWs &ws, int64_t cap, hipStream_t stream, hipEvent_t ev_between)
+                 int precision, RenderWs &ws, int64_t cap, hipStream_t stream, hipEvent_t ev_between)
 {
     ShadeParams P{};
     P.point_rows = reinterpret_cast<const float4 *>(scene->point_rows);
@@ -462,6 +772,7 @@ int launch_shade(const pnr_scene *scene, const pnr_weights *w, const Camera &cam
     P.wbytes = w->bytes;
     for (int i = 0; i < 9; ++i) {
         P.w_off[i] = w->w_off[i];
+        P.w16_off[i] = w->w16_off[i];
         P.b_off[i] = w->b_off[i];
         P.Rw2c[i] = w->Rw2c[i];
     }
@@ -484,14 +795,25 @@ int launch_shade(const pnr_scene *scene, const pnr_weights *w, const Camera &cam
     const int spt = (32 / K) * WAVES;
     const int64_t max_tiles = (cap + spt - 1) / spt;
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cus, max_tiles));
-    if (K == 8)
-        hipLaunchKernelGGL(k_shade_pairs<true>, dim3(grid), dim3(TPB), 0, stream, P);
-    else
-        hipLaunchKernelGGL(k_shade_pairs<false>, dim3(grid), dim3(TPB), 0, stream, P);
+    const bool bf = precision == PNR_PRECISION_BF16X3;
+    if (K == 8) {
+        if (bf)
+            hipLaunchKernelGGL(k_shade_pairs_bf16<true>, dim3(grid), dim3(TPB), 0, stream, P);
+        else
+            hipLaunchKernelGGL(k_shade_pairs<true>, dim3(grid), dim3(TPB), 0, stream, P);
+    } else {
+        if (bf)
+            hipLaunchKernelGGL(k_shade_pairs_bf16<false>, dim3(grid), dim3(TPB), 0, stream, P);
+        else
+            hipLaunchKernelGGL(k_shade_pairs<false>, dim3(grid), dim3(TPB), 0, stream, P);
+    }
     if (ev_between) PNR_HIP_CHECK(hipEventRecord(ev_between, stream));
     const int64_t ctiles = (cap + 32 * WAVES - 1) / (32 * WAVES);
     const unsigned cgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cus, ctiles));
-    hipLaunchKernelGGL(k_shade_color, dim3(cgrid), dim3(TPB), 0, stream, P);
+    if (bf)
+        hipLaunchKernelGGL(k_shade_color_bf16, dim3(cgrid), dim3(TPB), 0, stream, P);
+    else
+        hipLaunchKernelGGL(k_shade_color, dim3(cgrid), dim3(TPB), 0, stream, P);
     PNR_HIP_CHECK(hipGetLastError());
     return PNR_OK;
 }
@@ -523,28 +845,38 @@ extern "C" int pnr_weights_pack(pnr_weights_t *w, const float *const d_w[9], con
     for (int i = 0; i < 9; ++i) PNR_REQUIRE(d_w[i] && d_b[i], "pnr_weights_pack: tensor %d is null", i);
     static const int n_out[9] = {256, 256, 256, 256, 1, 128, 128, 128, 3};
     static const int n_in[9] = {284, 256, 263, 256, 256, 280, 128, 128, 128};
-    static const int ksp[9] = {144, 128, 132, 128, 0, 140, 64, 64, 0};
+    static const int ksp[9] = {144, 128, 132, 128, 0, 140, 64, 64, 0};    // fp32 k-steps (2 features each)
+    static const int ks16[9] = {18, 16, 17, 16, 0, 18, 8, 8, 0};          // bf16 k-steps (16 features each)
     static const int kind[9] = {L_BASE0, L_HIDDEN, L_HEAD0, L_HIDDEN, -1, L_COLOR0, L_HIDDEN, L_HIDDEN, -1};
     size_t off = 0;
+    auto pad = [](size_t n) { return (n + 1023) / 1024 * 1024; };  // 4 KiB granules (LDS staging rounds)
     for (int i = 0; i < 9; ++i) {
         w->w_off[i] = off;
-        size_t n = ksp[i] ? (size_t)(n_out[i] / 32) * (ksp[i] / 4) * 256 : (size_t)n_out[i] * n_in[i];
-        off += (n + 63) / 64 * 64;
+        off += pad(ksp[i] ? (size_t)(n_out[i] / 32) * (ksp[i] / 4) * 256 : (size_t)n_out[i] * n_in[i]);
+    }
+    for (int i = 0; i < 9; ++i) {
+        w->w16_off[i] = off;
+        // [mt][ks][2 planes][64 lanes][8 bf16] = mt * ks * 2048 bytes = mt * ks * 512 floats
+        off += ks16[i] ? pad((size_t)(n_out[i] / 32) * ks16[i] * 512) : 0;
     }
     for (int i = 0; i < 9; ++i) {
         w->b_off[i] = off;
-        off += ((size_t)n_out[i] + 63) / 64 * 64;
+        off += pad((size_t)n_out[i]);
     }
+    off += 2 * 1024 * 9;  // tail pad: a staged tile may read up to 36 KiB from its start
     if (!w->buf || w->bytes != off * sizeof(float)) {
         if (w->buf) (void)hipFree(w->buf);
         w->buf = nullptr;
         PNR_HIP_CHECK(hipMalloc((void **)&w->buf, off * sizeof(float)));
         w->bytes = off * sizeof(float);
     }
+    PNR_HIP_CHECK(hipMemsetAsync(w->buf, 0, w->bytes, stream));
     for (int i = 0; i < 9; ++i) {
         if (ksp[i]) {
             hipLaunchKernelGGL(k_pack_layer, dim3(256), dim3(256), 0, stream, d_w[i], n_out[i], n_in[i], kind[i],
                                ksp[i], w->buf + w->w_off[i]);
+            hipLaunchKernelGGL(k_pack_layer_bf16, dim3(256), dim3(256), 0, stream, d_w[i], n_out[i], n_in[i], kind[i],
+                               ks16[i], reinterpret_cast<unsigned short *>(w->buf + w->w16_off[i]));
         } else {
             int n = n_out[i] * n_in[i];
             hipLaunchKernelGGL(k_copy, dim3((n + 255) / 256), dim3(256), 0, stream, d_w[i], n, w->buf + w->w_off[i]);

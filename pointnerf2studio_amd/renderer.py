@@ -213,7 +213,7 @@ class RendererHIP:
 
     def __init__(self, scene: SceneHIP, weights: WeightsHIP, SR: int = 80, K: int = 8, D: int = 400,
                  radius_limit: float = 0.016, vsize_z: float = 0.004, eval_clamp: bool = True,
-                 bg=(1.0, 1.0, 1.0)):
+                 bg=(1.0, 1.0, 1.0), precision: str = "fp32"):
         self.lib = _lib.load()
         self.scene, self.weights = scene, weights
         self.opts = _lib.RenderOpts()
@@ -222,6 +222,9 @@ class RendererHIP:
         self.opts.vsize_z = float(np.float32(vsize_z))
         self.opts.eval_clamp = int(bool(eval_clamp))
         self.opts.bg[:] = [float(b) for b in bg]
+        if precision not in _lib.PRECISION:
+            raise ValueError(f"precision must be one of {sorted(_lib.PRECISION)}, got {precision!r}")
+        self.opts.precision = _lib.PRECISION[precision]
         self._ws = None
         self._ws_key = None
         self._tmid = {}

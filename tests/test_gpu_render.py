@@ -15,7 +15,8 @@ RGB_TOL = 1e-4
 DEPTH_TOL = 1e-4
 
 
-def _render_both(oracle, device, N, SR, K, P, H, W, az, sigma_scale=300.0, shrink=1.0, window=None, Rw2c=None):
+def _render_both(oracle, device, N, SR, K, P, H, W, az, sigma_scale=300.0, shrink=1.0, window=None, Rw2c=None,
+                 precision="fp32"):
     pts = small_scene(N, shrink=shrink)
     if Rw2c is not None:
         pts["Rw2c"] = Rw2c
@@ -25,7 +26,7 @@ def _render_both(oracle, device, N, SR, K, P, H, W, az, sigma_scale=300.0, shrin
     ref = oracle.render(pts, w, cfg, campos[None].expand(dirs.shape[0], 3), dirs, 2.0, 6.0, camrot)
     scene, wh, hyp, info = build_hip(pts, cfg, device, weights=w)
     rnd = RendererHIP(scene, wh, SR=SR, K=K, D=cfg.z_depth_dim, radius_limit=float(oracle.radius_limit(cfg)),
-                      vsize_z=cfg.vsize[2])
+                      vsize_z=cfg.vsize[2], precision=precision)
     out = rnd.render(dirs.to(device), campos, camrot, 2.0, 6.0)
     return ref, out, rnd, dirs
 
@@ -58,6 +59,43 @@ def test_render_matches_oracle(oracle, gpu_device, N, SR, K, P, H, W, az):
     # the image must not be trivially white: some rays accumulate real opacity
     assert ref["acc"].max().item() > 0.5
     print(f"max|rgb err|={err:.2e} max|depth err|={derr:.2e} counters={out['counters']}")
+
+
+@pytest.mark.parametrize("N,SR,K,P,H,W,az", [
+    (60000, 80, 8, 12, 40, 40, 35.0),
+    (400000, 80, 8, 12, 32, 32, 120.0),
+    (50000, 32, 8, 12, 64, 64, 200.0),
+    (200000, 24, 12, 26, 32, 32, 300.0),
+])
+def test_render_bf16x3_matches_oracle(oracle, gpu_device, N, SR, K, P, H, W, az):
+    """The split-bf16 MFMA mode (3 bf16 products per fp32 product) against the SAME fp32 oracle and the SAME
+    1e-4 budget; neighbour lists / ray mask are untouched by the mode and stay exact."""
+    ref, out, rnd, dirs = _render_both(oracle, gpu_device, N, SR, K, P, H, W, az, precision="bf16x3")
+    err, derr = _check(ref, out)
+    assert ref["acc"].max().item() > 0.5
+    print(f"bf16x3: max|rgb err|={err:.2e} max|depth err|={derr:.2e}")
+
+
+def test_render_bf16x3_rotated_frame_and_sigma(oracle, gpu_device):
+    a, b = 0.7, -0.4
+    ca, sa, cb, sb = np.cos(a), np.sin(a), np.cos(b), np.sin(b)
+    Rw2c = torch.tensor([[ca, -sa, 0], [sa * cb, ca * cb, -sb], [sa * sb, ca * sb, cb]], dtype=torch.float32)
+    ref, out, rnd, dirs = _render_both(oracle, gpu_device, 120000, 80, 8, 12, 32, 32, 75.0, Rw2c=Rw2c,
+                                       precision="bf16x3")
+    _check(ref, out)
+    taps = rnd.taps(dirs.shape[0])
+    S = out["counters"]["samples_selected"]
+    cnt, off = taps["ray_cnt"].cpu().numpy(), taps["ray_off"].cpu().numpy()
+    dec = taps["smp_out"][:S].cpu().numpy()
+    keep = np.nonzero(ref["ray_mask"].numpy() > 0)[0]
+    ref_dec = ref["decoded"][0].numpy()
+    worst = 0.0
+    for row, r in enumerate(keep):
+        d, rd = dec[off[r]:off[r] + cnt[r]], ref_dec[row, :cnt[r]]
+        worst = max(worst, float(np.max(np.abs(d[:, 0] - rd[:, 0]))))
+    smax = float(ref_dec[..., 0].max())
+    # hi/lo-split products carry ~2^-16 relative error on |w||x| sums: sigma is good to ~1e-4 of its scale
+    assert worst <= 1e-4 * smax, f"sigma abs error {worst:.3e} vs scale {smax:.1f} in bf16x3 mode"
 
 
 def test_render_decoded_features_and_neighbours(oracle, gpu_device):
