@@ -9,7 +9,8 @@ import os
 from typing import Optional
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libpnr_hip.so")
+# PNR_LIB overrides the library path for diagnostic (ablation) builds; never set in normal use
+LIB_PATH = os.environ.get("PNR_LIB") or os.path.join(PKG_DIR, "libpnr_hip.so")
 
 NUM_COUNTERS = 8
 COUNTER_NAMES = ["rays_hit", "rays_kept", "samples_selected", "samples_valid", "pairs_valid", "candidates",

@@ -33,11 +33,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// diagnostic builds only (never shipped): bit0 cheap PE, bit1 no MFMA, bit2 no staging, bit3 no barrier, bit4 no split
+#ifndef PNR_ABLATE
+#define PNR_ABLATE 0
+#endif
+
 constexpr int WAVES = 4;
 constexpr int TPB = WAVES * 64;
 constexpr int PF = 6;  // fp32 path: weight loads (1 KiB each per wave) kept in flight
 
-__device__ __forceinline__ float leaky(float x) { return x > 0.f ? x : 0.1f * x; }
+// LeakyReLU(0.1): max(x, 0.1 x) (identical to the select form for finite x, one instruction shorter)
+__device__ __forceinline__ float leaky(float x) { return fmaxf(x, 0.1f * x); }
 
 struct ShadeParams {
     const float4 *point_rows;  // [N, 11] float4
@@ -89,9 +95,11 @@ template <bool POW2_8>
 __device__ __forceinline__ float seg_sum(float v, int K, int lane)
 {
     if (POW2_8) {
-        v += __shfl_xor(v, 1, 64);
-        v += __shfl_xor(v, 2, 64);
-        v += __shfl_xor(v, 4, 64);
+        // 8 consecutive lanes, all on the VALU (DPP): xor-1 and xor-2 inside each quad, then the mirrored quad
+        // of the 8-lane half row (lane i <- lane 7 - i) -- no LDS crossbar (ds_bpermute) involved
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
         return v;
     } else {
         const int j = lane & 31;
@@ -116,7 +124,7 @@ struct RowCtx {
 // x0: the lane's 144 layer-1 input values; value i = 8s + j is element j of k-step s in the bf16 path and
 // k-step t = i in the fp32 path.  Lane half h = 0 carries emb[0:16], their encodings and the rotated world
 // distances, h = 1 carries emb[16:32], their encodings and the camera-space distances.
-template <bool K8>
+template <bool K8, bool FAST_PE>
 __device__ __forceinline__ void load_rows(const ShadeParams &P, int tile, int lane, int wave, int S_valid,
                                           float (&x0)[144], RowCtx &ctx)
 {
@@ -166,20 +174,39 @@ __device__ __forceinline__ void load_rows(const ShadeParams &P, int tile, int la
     for (int d = 0; d < 16; ++d) x0[d] = e[d];
 #pragma unroll
     for (int d = 0; d < 16; ++d) {
+        float sn = 0.f, cs = 1.f;
 #pragma unroll
         for (int f = 0; f < 3; ++f) {
-            float sn, cs;
-            sincosf(e[d] * (float)(1 << f), &sn, &cs);
+            if (PNR_ABLATE & 1) {
+                sn = e[d] * (float)(1 << f);
+                cs = 1.0f - sn;
+            } else if (FAST_PE && f > 0) {
+                // double angle from the previous octave: sin 2a = 2 sin a cos a, cos 2a = (cos a - sin a)(cos a + sin a)
+                const float s2 = 2.0f * sn * cs, c2 = (cs - sn) * (cs + sn);
+                sn = s2;
+                cs = c2;
+            } else {
+                sincosf(e[d] * (float)(1 << f), &sn, &cs);
+            }
             x0[16 + (d * 3 + f) * 2 + 0] = sn;
             x0[16 + (d * 3 + f) * 2 + 1] = cs;
         }
     }
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
+        float sn = 0.f, cs = 1.f;
 #pragma unroll
         for (int f = 0; f < 5; ++f) {
-            float sn, cs;
-            sincosf(dd[d] * (float)(1 << f), &sn, &cs);
+            if (PNR_ABLATE & 1) {
+                sn = dd[d] * (float)(1 << f);
+                cs = 1.0f - sn;
+            } else if (FAST_PE && f > 0) {
+                const float s2 = 2.0f * sn * cs, c2 = (cs - sn) * (cs + sn);
+                sn = s2;
+                cs = c2;
+            } else {
+                sincosf(dd[d] * (float)(1 << f), &sn, &cs);
+            }
             x0[112 + (d * 5 + f) * 2 + 0] = sn;
             x0[112 + (d * 5 + f) * 2 + 1] = cs;
         }
@@ -341,7 +368,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
         asm volatile("" : "+s"(w0), "+s"(w1), "+s"(w2), "+s"(w3));
         float x0[144];
         RowCtx ctx;
-        load_rows<K8>(P, tile, lane, wave, S_valid, x0, ctx);
+        load_rows<K8, false>(P, tile, lane, wave, S_valid, x0, ctx);
 
         float hA[128];
         dense_layer<144, 8>(rsrc, w0, b0, lane, x0, hA);
@@ -430,8 +457,10 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_color(ShadeParams P)
 // ================================================================================================
 // bf16x3 mode
 // ================================================================================================
-constexpr int STAGE_U4 = 9 * 256;  // one LDS weight tile: up to 18 k-steps x {hi, lo} x 64 lanes x 16 B = 36 KiB
-constexpr int STAGE_ROUNDS_MAX = 9;
+constexpr int STAGE_U4 = 9 * 256;        // one LDS weight tile: up to 18 k-steps x {hi, lo} x 64 lanes x 16 B = 36 KiB
+constexpr int RING = 3;                  // weight tiles in LDS: one being multiplied, two in flight
+constexpr int BIAS_U4 = 256;             // 1024 floats of biases behind the ring
+constexpr int LDS_U4 = RING * STAGE_U4 + BIAS_U4;
 
 __device__ __forceinline__ void split8(const float *v, bf16x8 &hi, bf16x8 &lo)
 {
@@ -443,88 +472,169 @@ __device__ __forceinline__ void split8(const float *v, bf16x8 &hi, bf16x8 &lo)
     }
 }
 
-// global -> registers: ROUNDS 16-byte pieces per thread of the tile starting at byte offset `off`
+// LDS-DMA (buffer_load_dwordx4 ... lds): ROUNDS x 4 KiB of the weight tile at byte offset `off` go straight
+// from L2 into ring slot `slot`, no VGPRs; each wave moves 1 KiB per instruction (lane-linear image).
 template <int ROUNDS>
-__device__ __forceinline__ void stage_load(__amdgpu_buffer_rsrc_t rsrc, int off, int tid, u32x4 (&r)[STAGE_ROUNDS_MAX])
+__device__ __forceinline__ void stage_dma(__amdgpu_buffer_rsrc_t rsrc, int off, int tid, int wave_u, u32x4 *lds,
+                                          int slot)
 {
+    typedef __attribute__((address_space(3))) void *lds_ptr_t;
 #pragma unroll
-    for (int i = 0; i < ROUNDS; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, tid * 16, off + i * 4096, 0);
+    for (int i = 0; i < ROUNDS; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + slot * STAGE_U4 + i * 256 + wave_u * 64), 16,
+                                                 tid * 16, off + i * 4096, 0, 0);
 }
 
-template <int ROUNDS>
-__device__ __forceinline__ void stage_store(u32x4 *lds, int tid, const u32x4 (&r)[STAGE_ROUNDS_MAX])
-{
-#pragma unroll
-    for (int i = 0; i < ROUNDS; ++i) lds[i * 256 + tid] = r[i];
-}
+// per-wave state of the weight-tile ring
+struct Ring {
+    int cur;  // slot holding the tile about to be multiplied
+};
 
-// One dense layer on bf16 hi/lo splits.  MT output tiles of 32 features; tile m's weights
-// ([KS][{hi,lo}][64 lanes][8 bf16], KS * 2 KiB) must already sit in LDS buffer (m & 1) when the layer
-// starts (the previous layer staged it); while tile m is multiplied, tile m+1 (or the first tile of the NEXT
-// layer, KS_NEXT k-steps at byte offset wnext) is fetched into registers and written to the other buffer.
-template <int KS, int MT, int KS_NEXT>
-__device__ __forceinline__ void dense_layer_bf16(__amdgpu_buffer_rsrc_t rsrc, int wbase, int wnext,
-                                                 const float *__restrict__ bias, int lane, int tid, u32x4 *lds,
-                                                 const bf16x8 *xh, const bf16x8 *xl, float (&out)[MT * 16])
+// One dense layer on bf16 hi/lo splits.  MT output tiles of 32 features.  Weight tiles
+// ([KS][{hi,lo}][64 lanes][8 bf16], KS * 2 KiB) travel L2 -> LDS by LDS-DMA two tiles ahead of use in a 3-slot
+// ring: when tile T is multiplied, T+1 has landed or is landing and T+2 is issued.  KS_N1 / KS_N2 are the
+// k-step counts of the first / second tile of the following layers (wn1 / wn2 their byte offsets), used when
+// this layer's last tiles prefetch across the layer boundary.
+//
+// The instruction order is pinned by hand, because left alone hipcc serialises `ds_read -> lgkmcnt(0) -> mfma`
+// through one register quad and sinks loads down to their first use:
+//   * the DMA of tile T+2 issues first; biases come from LDS (a VMEM bias load issued behind the DMA would
+//     make the accumulator initialisation wait for the whole DMA: VMEM returns in order);
+//   * A-operand fragments are read from LDS two k-steps ahead into a three-deep register ring;
+//   * with SPLIT_OUT the activation + hi/lo split of the PREVIOUS output tile (16 values -> two k-steps of the
+//     next layer's operands) is cut in three and placed BETWEEN the three MFMAs of the first 8 k-steps
+//     (an in-order wave cannot issue VALU work placed behind an MFMA that waits for the matrix pipe);
+//   * one raw s_barrier per tile, preceded by a COUNTED vmcnt that retires tile T+1's DMA and leaves T+2's in
+//     flight (__syncthreads() would drain it with vmcnt(0)).
+template <int KS, int MT, int KS_N1, int KS_N2, bool SPLIT_OUT>
+__device__ __forceinline__ void dense_layer_bf16(__amdgpu_buffer_rsrc_t rsrc, int wbase, int wn1, int wn2,
+                                                 int bias_off, int lane, int tid, int wave_u, u32x4 *lds, Ring &ring,
+                                                 const bf16x8 *xh, const bf16x8 *xl, bf16x8 *yh, bf16x8 *yl,
+                                                 float *outf)
 {
-    static_assert(MT % 2 == 0, "buffer parity must be preserved across layers");
+    static_assert(KS >= 8, "the split of the previous tile is spread over 8 k-steps");
     const int h = lane >> 5;
-    u32x4 stage[STAGE_ROUNDS_MAX];
+    const float *bias_lds = reinterpret_cast<const float *>(lds + RING * STAGE_U4) + bias_off;
+    f32x16 prev;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        if (m + 1 < MT)
-            stage_load<(KS + 1) / 2>(rsrc, wbase + (m + 1) * KS * 2048, tid, stage);
+        // ---- tile T+2 on its way --------------------------------------------------------------------------
+        int slot2 = ring.cur + 2;
+        slot2 = slot2 >= RING ? slot2 - RING : slot2;
+        constexpr int R_SAME = (KS + 1) / 2, R_N1 = (KS_N1 + 1) / 2, R_N2 = (KS_N2 + 1) / 2;
+        if (m + 2 < MT)
+            stage_dma<R_SAME>(rsrc, wbase + (m + 2) * KS * 2048, tid, wave_u, lds, slot2);
+        else if (m + 2 == MT)
+            stage_dma<R_N1>(rsrc, wn1, tid, wave_u, lds, slot2);
         else
-            stage_load<(KS_NEXT + 1) / 2>(rsrc, wnext, tid, stage);
-        const u32x4 *cur = lds + (m & 1) * STAGE_U4;
+            stage_dma<R_N2>(rsrc, wn2, tid, wave_u, lds, slot2);
+        const int in_flight = (m + 2 < MT) ? R_SAME : (m + 2 == MT ? R_N1 : R_N2);
+        const u32x4 *cur = lds + ring.cur * STAGE_U4;
         f32x16 acc;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 b = *reinterpret_cast<const float4 *>(bias + 32 * m + 8 * q + 4 * h);
+            const float4 b = *reinterpret_cast<const float4 *>(bias_lds + 32 * m + 8 * q + 4 * h);
             acc[4 * q + 0] = b.x;
             acc[4 * q + 1] = b.y;
             acc[4 * q + 2] = b.z;
             acc[4 * q + 3] = b.w;
         }
+        u32x4 fh[3], fl[3];
+        fh[0] = cur[0 * 64 + lane];
+        fl[0] = cur[1 * 64 + lane];
+        fh[1] = cur[2 * 64 + lane];
+        fl[1] = cur[3 * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const bf16x8 wh = __builtin_bit_cast(bf16x8, cur[(2 * s) * 64 + lane]);
-            const bf16x8 wl = __builtin_bit_cast(bf16x8, cur[(2 * s + 1) * 64 + lane]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[s], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[s], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[s], acc, 0, 0, 0);
+            if (s + 2 < KS) {
+                fh[(s + 2) % 3] = cur[(2 * (s + 2)) * 64 + lane];
+                fl[(s + 2) % 3] = cur[(2 * (s + 2) + 1) * 64 + lane];
+            }
+            const bf16x8 wh = __builtin_bit_cast(bf16x8, fh[s % 3]);
+            const bf16x8 wl = __builtin_bit_cast(bf16x8, fl[s % 3]);
+            const bool do_split = SPLIT_OUT && m > 0 && s < 8 && !(PNR_ABLATE & 16);
+            float v0 = 0.f, v1 = 0.f, r0 = 0.f, r1 = 0.f;
+            __bf16 h0, h1;
+            if (PNR_ABLATE & 2)
+                asm volatile("" ::"v"(wh), "v"(wl), "v"(xh[s]), "v"(xl[s]));
+            else
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[s], acc, 0, 0, 0);
+            if (do_split) {
+                v0 = leaky(prev[2 * s]);
+                v1 = leaky(prev[2 * s + 1]);
+                h0 = (__bf16)v0;
+                h1 = (__bf16)v1;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(PNR_ABLATE & 2)) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[s], acc, 0, 0, 0);
+            if (do_split) {
+                r0 = v0 - (float)h0;
+                r1 = v1 - (float)h1;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(PNR_ABLATE & 2)) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[s], acc, 0, 0, 0);
+            if (do_split) {
+                const int kk = 2 * (m - 1) + s / 4, j0 = (2 * s) % 8;
+                yh[kk][j0] = h0;
+                yh[kk][j0 + 1] = h1;
+                yl[kk][j0] = (__bf16)r0;
+                yl[kk][j0 + 1] = (__bf16)r1;
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        if (SPLIT_OUT) {
+            prev = acc;
+        } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[m * 16 + r] = acc[r];
-        u32x4 *nxt = lds + ((m + 1) & 1) * STAGE_U4;
-        if (m + 1 < MT)
-            stage_store<(KS + 1) / 2>(nxt, tid, stage);
-        else
-            stage_store<(KS_NEXT + 1) / 2>(nxt, tid, stage);
-        __syncthreads();
+            for (int r = 0; r < 16; ++r) outf[m * 16 + r] = acc[r];
+        }
+        // ---- tile T+1 must have landed (this wave's share), T+2 stays in flight; then everybody's share ---------
+        if (!(PNR_ABLATE & 8)) {
+            if (in_flight == 9)
+                asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else if (in_flight == 8)
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        ring.cur = ring.cur + 1 >= RING ? 0 : ring.cur + 1;
+    }
+    if (SPLIT_OUT && !(PNR_ABLATE & 16)) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float v0 = leaky(prev[2 * s]), v1 = leaky(prev[2 * s + 1]);
+            const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
+            const int kk = 2 * (MT - 1) + s / 4, j0 = (2 * s) % 8;
+            yh[kk][j0] = h0;
+            yh[kk][j0 + 1] = h1;
+            yl[kk][j0] = (__bf16)(v0 - (float)h0);
+            yl[kk][j0 + 1] = (__bf16)(v1 - (float)h1);
+        }
     }
 }
 
-// activation + hi/lo split of a layer's output into the next layer's operands
-template <int MT>
-__device__ __forceinline__ void act_split(const float (&o)[MT * 16], bf16x8 *xh, bf16x8 *xl)
+// biases of layers [first, first+count) into the LDS table (float index = 256 * (layer - first))
+__device__ __forceinline__ void load_bias_table(const ShadeParams &P, int first, int count, int width, int tid,
+                                                u32x4 *lds)
 {
-#pragma unroll
-    for (int s = 0; s < 2 * MT; ++s) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = leaky(o[8 * s + j]);
-        split8(v, xh[s], xl[s]);
+    float *tab = reinterpret_cast<float *>(lds + RING * STAGE_U4);
+    for (int i = tid; i < count * 256; i += TPB) {
+        const int l = i >> 8, c = i & 255;
+        tab[i] = c < width ? P.wbuf[P.b_off[first + l] + c] : 0.f;
     }
 }
 
 template <bool K8>
 __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
 {
-    __shared__ u32x4 lds[2 * STAGE_U4];
+    __shared__ u32x4 lds[LDS_U4];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int K = K8 ? 8 : P.K;
     const int SPT = (32 / K) * WAVES;
     const int S_valid = P.n_sel[1];
@@ -535,16 +645,14 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wbuf), 0, (int)P.wbytes, 0x00020000);
     const int w0_ = (int)(P.w16_off[0] * 4), w1_ = (int)(P.w16_off[1] * 4), w2_ = (int)(P.w16_off[2] * 4),
               w3_ = (int)(P.w16_off[3] * 4);
-    const float *b0 = P.wbuf + P.b_off[0], *b1 = P.wbuf + P.b_off[1], *b2 = P.wbuf + P.b_off[2],
-                *b3 = P.wbuf + P.b_off[3];
     if (t_begin >= t_end) return;  // uniform per workgroup
-    {
-        // first weight tile of the chain into LDS buffer 0
-        u32x4 st[STAGE_ROUNDS_MAX];
-        stage_load<9>(rsrc, w0_, tid, st);
-        stage_store<9>(lds, tid, st);
-        __syncthreads();
-    }
+    Ring ring{0};
+    load_bias_table(P, 0, 4, 256, tid, lds);
+    // tiles 0 and 1 of the chain (layer 0, m = 0, 1) into ring slots 0 and 1
+    stage_dma<9>(rsrc, w0_, tid, wave_u, lds, 0);
+    stage_dma<9>(rsrc, w0_ + 18 * 2048, tid, wave_u, lds, 1);
+    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    __syncthreads();
     for (int tile = t_begin; tile < t_end; ++tile) {
         int w0 = w0_, w1 = w1_, w2 = w2_, w3 = w3_;
         asm volatile("" : "+s"(w0), "+s"(w1), "+s"(w2), "+s"(w3));
@@ -552,36 +660,41 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
         bf16x8 xh[18], xl[18];
         {
             float x0[144];
-            load_rows<K8>(P, tile, lane, wave, S_valid, x0, ctx);
+            load_rows<K8, true>(P, tile, lane, wave, S_valid, x0, ctx);
 #pragma unroll
             for (int s = 0; s < 18; ++s) split8(&x0[8 * s], xh[s], xl[s]);
         }
-        float o[128];
-        dense_layer_bf16<18, 8, 16>(rsrc, w0, w1, b0, lane, tid, lds, xh, xl, o);
         bf16x8 yh[17], yl[17];
-        act_split<8>(o, yh, yl);
-        dense_layer_bf16<16, 8, 17>(rsrc, w1, w2, b1, lane, tid, lds, yh, yl, o);
-        act_split<8>(o, yh, yl);
+        dense_layer_bf16<18, 8, 16, 16, true>(rsrc, w0, w1, w1 + 16 * 2048, 0, lane, tid, wave_u, lds, ring, xh, xl, yh,
+                                              yl, nullptr);
+        // xh/xl are free again: they receive layer 2's output (+ the 7 extra head inputs as k-step 16)
+        dense_layer_bf16<16, 8, 17, 17, true>(rsrc, w1, w2, w2 + 17 * 2048, 256, lane, tid, wave_u, lds, ring, yh, yl,
+                                              xh, xl, nullptr);
         {
             float v[8] = {ctx.ex[0], ctx.ex[1], ctx.ex[2], ctx.ex[3], 0.f, 0.f, 0.f, 0.f};
-            split8(v, yh[16], yl[16]);
+            split8(v, xh[16], xl[16]);
         }
-        dense_layer_bf16<17, 8, 16>(rsrc, w2, w3, b2, lane, tid, lds, yh, yl, o);
-        act_split<8>(o, yh, yl);
-        // the chain wraps around: the next pair tile starts again with layer 0, tile 0
-        dense_layer_bf16<16, 8, 18>(rsrc, w3, w0, b3, lane, tid, lds, yh, yl, o);
+        dense_layer_bf16<17, 8, 16, 16, true>(rsrc, w2, w3, w3 + 16 * 2048, 512, lane, tid, wave_u, lds, ring, xh, xl,
+                                              yh, yl, nullptr);
+        float o[128];
+        // the chain wraps around: the next pair tile starts again with layer 0, tiles 0 and 1
+        dense_layer_bf16<16, 8, 18, 18, false>(rsrc, w3, w0, w0 + 18 * 2048, 768, lane, tid, wave_u, lds, ring, yh, yl,
+                                               nullptr, nullptr, o);
 #pragma unroll
         for (int i = 0; i < 128; ++i) o[i] = leaky(o[i]);
         finish_rows<K8>(P, lane, o, ctx);
     }
+    // the two tiles prefetched for a pair tile that does not exist are simply dropped
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 __global__ void __launch_bounds__(TPB, 1) k_shade_color_bf16(ShadeParams P)
 {
-    __shared__ u32x4 lds[2 * STAGE_U4];
+    __shared__ u32x4 lds[LDS_U4];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int j = lane & 31, h = lane >> 5;
     const int S_valid = P.n_sel[1];
     constexpr int SPT = 32 * WAVES;
@@ -589,14 +702,13 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_color_bf16(ShadeParams P)
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wbuf), 0, (int)P.wbytes, 0x00020000);
     const int w5_ = (int)(P.w16_off[5] * 4), w6_ = (int)(P.w16_off[6] * 4), w7_ = (int)(P.w16_off[7] * 4);
-    const float *b5 = P.wbuf + P.b_off[5], *b6 = P.wbuf + P.b_off[6], *b7 = P.wbuf + P.b_off[7];
     if ((int)blockIdx.x >= ntiles) return;
-    {
-        u32x4 st[STAGE_ROUNDS_MAX];
-        stage_load<9>(rsrc, w5_, tid, st);
-        stage_store<9>(lds, tid, st);
-        __syncthreads();
-    }
+    Ring ring{0};
+    load_bias_table(P, 5, 3, 128, tid, lds);
+    stage_dma<9>(rsrc, w5_, tid, wave_u, lds, 0);
+    stage_dma<9>(rsrc, w5_ + 18 * 2048, tid, wave_u, lds, 1);
+    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    __syncthreads();
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int w5 = w5_, w6 = w6_, w7 = w7_;
         asm volatile("" : "+s"(w5), "+s"(w6), "+s"(w7));
@@ -638,19 +750,21 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_color_bf16(ShadeParams P)
             split8(v16, xh[16], xl[16]);
             split8(v17, xh[17], xl[17]);
         }
-        float o[64];
-        dense_layer_bf16<18, 4, 8>(rsrc, w5, w6, b5, lane, tid, lds, xh, xl, o);
         bf16x8 yh[8], yl[8];
-        act_split<4>(o, yh, yl);
-        dense_layer_bf16<8, 4, 8>(rsrc, w6, w7, b6, lane, tid, lds, yh, yl, o);
-        act_split<4>(o, yh, yl);
-        dense_layer_bf16<8, 4, 18>(rsrc, w7, w5, b7, lane, tid, lds, yh, yl, o);
+        dense_layer_bf16<18, 4, 8, 8, true>(rsrc, w5, w6, w6 + 8 * 2048, 0, lane, tid, wave_u, lds, ring, xh, xl, yh, yl,
+                                            nullptr);
+        dense_layer_bf16<8, 4, 8, 8, true>(rsrc, w6, w7, w7 + 8 * 2048, 256, lane, tid, wave_u, lds, ring, yh, yl, xh, xl,
+                                           nullptr);
+        float o[64];
+        dense_layer_bf16<8, 4, 18, 18, false>(rsrc, w7, w5, w5 + 18 * 2048, 512, lane, tid, wave_u, lds, ring, xh, xl,
+                                              nullptr, nullptr, o);
 #pragma unroll
         for (int i = 0; i < 64; ++i) o[i] = leaky(o[i]);
         float rgb[3];
         color_head(P, lane, o, rgb);
         if (ok && h == 0) P.smp_out[s] = make_float4(P.smp_sigma[v_idx], rgb[0], rgb[1], rgb[2]);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // ------------------------------------------------------------------------------------------------
