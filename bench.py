@@ -16,8 +16,10 @@ region; the timed region covers query + gather + MLPs + composite + all_gather f
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (k_shade_pairs, the fp32-MFMA MLP
-chain) against the 157.3 TFLOP/s dense fp32 matrix peak; `cpu_baseline` times the CPU oracle
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (the MLP chain k_shade_pairs*) against the
+dense MFMA peak of the mode that ran: bf16x3 (default: every fp32 product as 3 bf16 MFMA products on hi/lo
+splits, fp32 accumulate; RGB within 1e-5 of the exact mode) against 2.5 PFLOP/s, fp32 (exact fp32 MFMA) against
+157.3 TFLOP/s; `other_mode` holds the same workload in the other mode.  `cpu_baseline` times the CPU oracle
 (oracle/pnr_oracle.py, the PyTorch-CPU restatement of the reference path) on a bounded sample of the same
 workload on this box's host cores.
 """
@@ -43,6 +45,7 @@ from pointnerf2studio_amd.renderer import (RendererHIP, SceneHIP, WeightsHIP, gr
 FLOPS_PER_PAIR = 542_720       # 2 * (284*256 + 256*256 + 263*256 + 256*256 + 256)   SURVEY.md section 8d
 FLOPS_PER_SAMPLE = 137_984     # 2 * (280*128 + 2*128*128 + 128*3)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X dense bf16 matrix peak (no 2:1 sparsity)
 
 VSIZE = [0.004, 0.004, 0.004]
 VSCALE = [2, 2, 2]
@@ -75,13 +78,13 @@ def cpu_baseline(points, weights, cfgd, n_side, view):
                 seconds=dt), ref, dirs, campos, camrot
 
 
-def pmc_traffic_bytes():
-    """HBM bytes per k_shade_pairs launch from the committed PMC passes (bench.py cannot collect PMC counters
-    itself); None when the summary is absent."""
+def pmc_traffic_bytes(kernel):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (bench.py cannot collect PMC
+    counters itself); None when the summary is absent."""
     path = os.path.join(ROOT, "profiles", "r01", "pmc_hbm_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f)["kernels"]["pnr::k_shade_pairs<true>"]["hbm_bytes_per_launch_corrected"]
+            return json.load(f)["kernels"][f"pnr::{kernel}<true>"]["hbm_bytes_per_launch_corrected"]
     except (OSError, KeyError, ValueError):
         return None
 
@@ -95,7 +98,7 @@ def main():
     ap.add_argument("--points", type=int, default=None, help="override the number of points")
     ap.add_argument("--cpu-rays-side", type=int, default=64, help="side of the CPU-baseline window (0 = skip)")
     ap.add_argument("--sigma-scale", type=float, default=300.0)
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
+    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3"],
                     help="MLP arithmetic: exact fp32 MFMA, or 3 bf16 MFMAs per fp32 product (hi/lo split)")
     args = ap.parse_args()
 
@@ -164,84 +167,116 @@ def main():
     rnd.render(view_dirs[0], cams[0][0], cams[0][1], 2.0, 6.0, cap_samples=cap, out=outs)
 
     lib = _lib.load()
-    stage_ms = (C.c_float * _lib.NUM_STAGES)()
-    acc_ms = [0.0] * _lib.NUM_STAGES
-    acc_cnt = [0] * _lib.NUM_COUNTERS
-    n_launch = 0
+    n_calls_max = max(args.steps, 1) * world
+    counters_all = torch.zeros((n_calls_max, _lib.NUM_COUNTERS), dtype=torch.int64, device=dev)
 
-    def step(s, timed):
-        nonlocal n_launch
-        for i in range(world):
-            v = (s * world + i) % len(azimuths)
-            rnd.render(view_dirs[v], cams[v][0], cams[v][1], 2.0, 6.0, cap_samples=cap, sync_counters=False, out=outs)
-            local4[:, :3].copy_(outs["rgb"])
-            local4[:, 3].copy_(outs["depth"])
-            gather_image(local4, shard, out=image, gathered=gathered)
-            if timed:
-                # stage times come from HIP events recorded on the render stream (no extra kernels);
-                # reading them waits for this render only
-                _lib.check(lib.pnr_profile_last_ms(C.byref(stage_ms)), "pnr_profile_last_ms")
-                for k in range(_lib.NUM_STAGES):
-                    acc_ms[k] += stage_ms[k]
-                c = outs["counters_dev"].tolist()
-                for k in range(_lib.NUM_COUNTERS):
-                    acc_cnt[k] += c[k]
-                n_launch += 1
+    def run_steps(renderer, first, count, counters=None):
+        """`count` steps; NOTHING in here waits for the device (stage times and counters are read afterwards)."""
+        call = 0
+        for s in range(first, first + count):
+            for i in range(world):
+                v = (s * world + i) % len(azimuths)
+                if counters is not None:
+                    outs["counters_dev"] = counters[call]
+                renderer.render(view_dirs[v], cams[v][0], cams[v][1], 2.0, 6.0, cap_samples=cap, sync_counters=False,
+                                out=outs)
+                local4[:, :3].copy_(outs["rgb"])
+                local4[:, 3].copy_(outs["depth"])
+                gather_image(local4, shard, out=image, gathered=gathered)
+                call += 1
+        return call
 
-    for s in range(args.warmup):
-        step(s, False)
-    _lib.check(lib.pnr_profile_enable(1), "pnr_profile_enable")
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        step(args.warmup + s, True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    lib.pnr_profile_enable(0)
+    def timed(renderer, steps, first):
+        """barrier + synchronize, `steps` steps, barrier + synchronize; max over ranks; per-stage device times of
+        every launch of the region from the HIP events pnr_render recorded on its stream."""
+        _lib.check(lib.pnr_profile_enable(1), "pnr_profile_enable")
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = run_steps(renderer, first, steps, counters_all)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = (C.c_float * _lib.NUM_STAGES)()
+        acc = [0.0] * _lib.NUM_STAGES
+        recorded = int(lib.pnr_profile_calls())
+        lo = max(0, recorded - 256)
+        for c in range(lo, recorded):
+            _lib.check(lib.pnr_profile_read(c, C.byref(ms)), "pnr_profile_read")
+            for k in range(_lib.NUM_STAGES):
+                acc[k] += ms[k]
+        lib.pnr_profile_enable(0)
+        cnt = counters_all[lo:n].sum(0).tolist()
+        return float(t.item()), acc, cnt, max(recorded - lo, 1)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    def roofline(mode, acc_ms, cnt, n_launch):
+        pairs, samples = cnt[4], cnt[3]
+        t_pairs = acc_ms[2] / 1e3
+        achieved = pairs * FLOPS_PER_PAIR / t_pairs / 1e12 if t_pairs > 0 else 0.0
+        bf = mode == "bf16x3"
+        peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
+        kernel = "k_shade_pairs_bf16" if bf else "k_shade_pairs"
+        r = {
+            "bound": "mfma", "kernel": kernel, "mode": mode,
+            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            "peak_note": ("dense bf16 MFMA peak; the kernel executes 3 bf16 MFMA products per algorithmic fp32 product, "
+                          "so executed FLOP/s = 3 x achieved" if bf else "dense fp32 MFMA peak"),
+            "executed_mfma_frac": (3 * achieved / peak) if bf else achieved / peak,
+            "traffic": pmc_traffic_bytes(kernel),
+            "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                            "profiles/r01/pmc_hbm_traffic.json; algorithmic bytes = pairs*164 + samples*1028)",
+            "algorithmic_bytes_per_launch": (pairs * 164 + samples * 1028) / n_launch,
+            "avg_launch_ms": acc_ms[2] / n_launch,
+            "valid_pairs_per_launch": pairs / n_launch,
+            "flops_per_pair": FLOPS_PER_PAIR,
+        }
+        return r
+
+    run_steps(rnd, 0, args.warmup)
+    elapsed, acc_ms, acc_cnt, n_launch = timed(rnd, args.steps, args.warmup)
     rays_per_step = world * H * W
     value = rays_per_step * args.steps / elapsed
 
+    # the other arithmetic mode, for the record (same workload, 2 steps, not part of `value`)
+    alt = None
+    if world == 1:
+        alt_mode = "fp32" if args.precision == "bf16x3" else "bf16x3"
+        rnd_alt = RendererHIP(scene, wh, SR=SR, K=K, D=400, radius_limit=4 * max(VSIZE[0], VSIZE[1]),
+                              vsize_z=VSIZE[2], precision=alt_mode)
+        rnd_alt._ws, rnd_alt._ws_key, rnd_alt.cap_samples = rnd._ws, rnd._ws_key, rnd.cap_samples
+        run_steps(rnd_alt, 0, 1)
+        a_el, a_ms, a_cnt, a_n = timed(rnd_alt, 2, 1)
+        alt = {"mode": alt_mode, "value": rays_per_step * 2 / a_el, "unit": "rays/s", "ms_per_step": a_el / 2 * 1e3,
+               "roofline": roofline(alt_mode, a_ms, a_cnt, a_n)}
+
     if rank == 0:
-        pairs, samples = acc_cnt[4], acc_cnt[3]
-        t_pairs = acc_ms[2] / 1e3
-        achieved = pairs * FLOPS_PER_PAIR / t_pairs / 1e12 if t_pairs > 0 else 0.0
+        samples = acc_cnt[3]
         result = {
             "metric": "rays_per_sec", "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16x3 products, f32 accumulate" if args.precision == "bf16x3" else "f32",
+            "data": "synthetic",
             "config": {
                 "workload": f"{args.config}: chair-bbox synthetic cloud N={cfgd['N']}, {H}x{W} image, D=400, "
                             f"SR={SR}, K={K}, P={cfgd['P']}, jitter=0, {world} view(s)/step",
-                "rays_per_step": rays_per_step, "global_batch": rays_per_step,
+                "rays_per_step": rays_per_step, "global_batch": rays_per_step, "mlp_mode": args.precision,
                 "parallelism": f"ray-tile shard x{world} (16x16 tiles round-robin) + all_gather per view",
             },
-            "roofline": {
-                "bound": "mfma", "kernel": "k_shade_pairs",
-                "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                "traffic": pmc_traffic_bytes(),
-                "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
-                                "profiles/r01/pmc_hbm_traffic.json; algorithmic bytes = pairs*164 + samples*1028)",
-                "algorithmic_bytes_per_launch": (pairs * 164 + samples * 1028) / max(n_launch, 1),
-                "avg_launch_ms": acc_ms[2] / max(n_launch, 1),
-                "valid_pairs_per_launch": pairs / max(n_launch, 1),
-                "flops_per_pair": FLOPS_PER_PAIR,
-            },
-            "stages_ms_per_launch": {n: acc_ms[i] / max(n_launch, 1) for i, n in enumerate(_lib.STAGE_NAMES)},
-            "counters_per_launch": {n: acc_cnt[i] / max(n_launch, 1) for i, n in enumerate(_lib.COUNTER_NAMES)},
+            "roofline": roofline(args.precision, acc_ms, acc_cnt, n_launch),
+            "stages_ms_per_launch": {n: acc_ms[i] / n_launch for i, n in enumerate(_lib.STAGE_NAMES)},
+            "counters_per_launch": {n: acc_cnt[i] / n_launch for i, n in enumerate(_lib.COUNTER_NAMES)},
             "color_mlp_tflops": (samples * FLOPS_PER_SAMPLE / (acc_ms[3] / 1e3) / 1e12) if acc_ms[3] > 0 else None,
             "scene": {"occupied_voxels": info["occupied_voxels"], "points_in_voxel_lists": info["points_in_lists"],
                       "structure_bytes": info["device_bytes"], "build_s": build_s, "cap_samples": cap},
         }
+        if alt is not None:
+            result["other_mode"] = alt
         if world == 1 and args.cpu_rays_side > 0:
             cb, ref, dirs, campos, camrot = cpu_baseline(points, weights, cfgd, args.cpu_rays_side, azimuths[0])
             # parity on the very same rays: HIP render vs the oracle that was just timed

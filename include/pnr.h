@@ -172,9 +172,11 @@ int pnr_render_taps(void *d_workspace, size_t workspace_bytes, int64_t R, int64_
                     pnr_render_taps_t *taps);
 
 /* ---- per-stage device timing (bench / roofline) ------------------------------------------------- */
-/* When enabled, pnr_render records hipEvents on `stream` between its stages (no host sync is added);
- * pnr_profile_last_ms synchronises on the last event of the most recent pnr_render of this thread's
- * process and returns the elapsed device time of each stage in milliseconds. */
+/* When enabled, pnr_render records hipEvents on `stream` between its stages into a ring of
+ * PNR_PROFILE_SLOTS slots, one slot per call (no host sync is added to the render).  pnr_profile_calls() is
+ * the number of calls recorded since pnr_profile_enable(1); pnr_profile_read(call, ms) synchronises on that
+ * call's last event and returns the elapsed device time of each stage in milliseconds. */
+#define PNR_PROFILE_SLOTS 256
 enum {
     PNR_STAGE_SELECT = 0,      /* occupancy masking + sample selection + scan + expand     */
     PNR_STAGE_KNN = 1,         /* neighbour search + valid-sample compaction               */
@@ -184,7 +186,8 @@ enum {
     PNR_NUM_STAGES = 5
 };
 int pnr_profile_enable(int enable);
-int pnr_profile_last_ms(float ms[PNR_NUM_STAGES]);
+int64_t pnr_profile_calls(void);
+int pnr_profile_read(int64_t call, float ms[PNR_NUM_STAGES]);
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "pnr_weights_create", "pnr_weights_destroy", "pnr_weights_pack",
     "pnr_query_workspace_bytes", "pnr_query_raypos",
     "pnr_render_workspace_bytes", "pnr_render", "pnr_render_taps",
-    "pnr_profile_enable", "pnr_profile_last_ms",
+    "pnr_profile_enable", "pnr_profile_calls", "pnr_profile_read",
 ]
 NUM_STAGES = 5
 STAGE_NAMES = ["select", "knn", "shade_pairs", "shade_color", "composite"]
@@ -90,10 +90,13 @@ def load() -> C.CDLL:
                                vp, sz, i64, vp]
     lib.pnr_render_taps.argtypes = [vp, sz, i64, i64, i32, C.POINTER(RenderTaps)]
     lib.pnr_profile_enable.argtypes = [C.c_int]
-    lib.pnr_profile_last_ms.argtypes = [C.POINTER(C.c_float * 5)]
+    lib.pnr_profile_calls.restype = C.c_int64
+    lib.pnr_profile_calls.argtypes = []
+    lib.pnr_profile_read.argtypes = [C.c_int64, C.POINTER(C.c_float * 5)]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
-        if name not in ("pnr_last_error", "pnr_query_workspace_bytes", "pnr_render_workspace_bytes"):
+        if name not in ("pnr_last_error", "pnr_query_workspace_bytes", "pnr_render_workspace_bytes",
+                        "pnr_profile_calls"):
             fn.restype = C.c_int
     _lib = lib
     return lib

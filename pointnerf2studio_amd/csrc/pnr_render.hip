@@ -22,10 +22,11 @@ void set_error(const char *fmt, ...)
 
 constexpr int TPB = 256;
 
-// per-stage timing: events recorded on the caller's stream, read back on request
+// per-stage timing: events recorded on the caller's stream into a ring of slots (one slot per pnr_render
+// call), read back on request -- the timed loop itself never synchronises
 static bool g_prof = false;
-static hipEvent_t g_ev[PNR_NUM_STAGES + 1] = {nullptr};
-static bool g_prof_valid = false;
+static hipEvent_t g_evs[PNR_PROFILE_SLOTS][PNR_NUM_STAGES + 1] = {{nullptr}};
+static long long g_prof_calls = 0;
 
 // one thread per ray: its samples are contiguous in the compact list, at most SR of them.
 __global__ void __launch_bounds__(TPB) k_composite(Camera cam, pnr_render_opts_t opts, int64_t R,
@@ -176,7 +177,7 @@ extern "C" int pnr_render(const pnr_scene_t *scene, const pnr_weights_t *weights
     for (int i = 0; i < 3; ++i) cam.o[i] = cam_->campos[i];
     for (int i = 0; i < 9; ++i) cam.R[i] = cam_->camrotc2w[i];
     const bool prof = g_prof;
-    g_prof_valid = false;
+    hipEvent_t *g_ev = g_evs[g_prof_calls % PNR_PROFILE_SLOTS];
     if (prof) PNR_HIP_CHECK(hipEventRecord(g_ev[0], stream));
     int rc = launch_select_expand(scene->grid, cam, d_dirs, nullptr, R, opts->D, opts->SR, d_tmid, cap_samples, ws,
                                   d_counters, stream);
@@ -193,27 +194,32 @@ extern "C" int pnr_render(const pnr_scene_t *scene, const pnr_weights_t *weights
     if (rc != PNR_OK) return rc;
     if (prof) {
         PNR_HIP_CHECK(hipEventRecord(g_ev[5], stream));
-        g_prof_valid = true;
+        ++g_prof_calls;
     }
     return PNR_OK;
 }
 
 extern "C" int pnr_profile_enable(int enable)
 {
-    if (enable && !g_ev[0])
-        for (int i = 0; i <= PNR_NUM_STAGES; ++i) PNR_HIP_CHECK(hipEventCreate(&g_ev[i]));
+    if (enable && !g_evs[0][0])
+        for (int s = 0; s < PNR_PROFILE_SLOTS; ++s)
+            for (int i = 0; i <= PNR_NUM_STAGES; ++i) PNR_HIP_CHECK(hipEventCreate(&g_evs[s][i]));
     g_prof = enable != 0;
-    g_prof_valid = false;
+    g_prof_calls = 0;
     return PNR_OK;
 }
 
-extern "C" int pnr_profile_last_ms(float ms[PNR_NUM_STAGES])
+extern "C" int64_t pnr_profile_calls(void) { return g_prof_calls; }
+
+extern "C" int pnr_profile_read(int64_t call, float ms[PNR_NUM_STAGES])
 {
-    PNR_REQUIRE(ms != nullptr, "pnr_profile_last_ms: null argument");
-    if (!g_prof || !g_prof_valid) {
-        set_error("pnr_profile_last_ms: profiling not enabled or no pnr_render recorded");
+    PNR_REQUIRE(ms != nullptr, "pnr_profile_read: null argument");
+    if (call < 0 || call >= g_prof_calls || call < g_prof_calls - PNR_PROFILE_SLOTS) {
+        set_error("pnr_profile_read: call %lld not recorded (recorded %lld, ring of %d)", (long long)call,
+                  (long long)g_prof_calls, PNR_PROFILE_SLOTS);
         return PNR_ERR_STATE;
     }
+    hipEvent_t *g_ev = g_evs[call % PNR_PROFILE_SLOTS];
     PNR_HIP_CHECK(hipEventSynchronize(g_ev[PNR_NUM_STAGES]));
     for (int i = 0; i < PNR_NUM_STAGES; ++i) PNR_HIP_CHECK(hipEventElapsedTime(&ms[i], g_ev[i], g_ev[i + 1]));
     return PNR_OK;
