@@ -155,10 +155,28 @@ struct RenderWs {
     float *agg;        // [cap, 256] by valid index
     float4 *smp_out;   // [cap]
     int *n_sel;        // device ints: [0]=S_sel (clamped to cap), [1]=S_valid, [2]=R
+    unsigned long long *shards;  // statistics counters, SHARDS x 128-byte lines per counter (see shard_add)
     void *scan_temp;
     size_t total;
 };
 RenderWs carve_render_ws(void *base, int64_t R, int64_t cap, int K);
+
+// Statistics counters (rays hit, pairs, candidates, rays kept) are summed with atomics that nothing waits for.
+// One word saturates at ~88 atomics/us on MI355X: 128k waves adding to ONE counter cost 1.5 ms of a 20 ms frame.
+// Each counter is therefore spread over 64 cache lines indexed by workgroup; the lines are summed when published.
+constexpr int SHARDS = 64;
+constexpr int SHARD_STRIDE = 16;  // u64 per 128-byte line
+enum { SH_RAYS_HIT = 0, SH_PAIRS = 1, SH_CAND = 2, SH_KEPT = 3, SH_COUNT = 4 };
+__device__ __forceinline__ void shard_add(unsigned long long *shards, int counter, unsigned long long v)
+{
+    atomicAdd(&shards[((size_t)counter * SHARDS + (blockIdx.x & (SHARDS - 1))) * SHARD_STRIDE], v);
+}
+__device__ __forceinline__ unsigned long long shard_sum(const unsigned long long *shards, int counter)
+{
+    unsigned long long s = 0;
+    for (int i = 0; i < SHARDS; ++i) s += shards[((size_t)counter * SHARDS + i) * SHARD_STRIDE];
+    return s;
+}
 
 int launch_select_expand(const GridView &g, const Camera &cam, const float *d_dirs, const float *d_raypos,
                          int64_t R, int D, int SR, const float *d_tmid, int64_t cap, RenderWs &ws,

@@ -31,6 +31,7 @@ RenderWs carve_render_ws(void *base, int64_t R, int64_t cap, int K)
         return p;
     };
     ws.n_sel = (int *)take(64 * sizeof(int));
+    ws.shards = (unsigned long long *)take((size_t)SH_COUNT * SHARDS * SHARD_STRIDE * sizeof(unsigned long long));
     ws.ray_cnt = (int *)take((size_t)(R + 1) * sizeof(int));
     ws.ray_off = (int *)take((size_t)(R + 1) * sizeof(int));
     ws.ray_flag = (int *)take((size_t)(R + 1) * sizeof(int));
@@ -78,14 +79,51 @@ __global__ void __launch_bounds__(TPB) k_select(GridView g, Camera cam, const fl
                                                  const float *__restrict__ raypos, const float *__restrict__ tmid,
                                                  int64_t R, int D, int SR, int *__restrict__ ray_cnt,
                                                  unsigned long long *__restrict__ ray_bits,
-                                                 unsigned long long *__restrict__ n_hit_rays)
+                                                 unsigned long long *__restrict__ shards)
 {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
     if (r >= R) return;
     int total = 0;
     const int nwords = (D + 63) >> 6;
-    for (int w = 0; w < nwords; ++w) {
+    // Conservative ray / grid-box clip (generated positions only): a coarse sample outside the voxel grid can
+    // never be occupied (cu:182-187), so whole 64-sample words whose parameter range misses the box -- grown by
+    // two voxels against rounding -- are skipped without probing.  Every probed sample still takes the exact test.
+    float t_in = -3.0e38f, t_out = 3.0e38f;
+    if (!raypos) {
+        const float d[3] = {dirs[3 * r], dirs[3 * r + 1], dirs[3 * r + 2]};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float lo = g.shift[a] - 2.0f * g.vox[a], hi = g.shift[a] + (float)(g.dims[a] + 2) * g.vox[a];
+            if (fabsf(d[a]) > 1e-12f) {
+                const float ta = (lo - cam.o[a]) / d[a], tb = (hi - cam.o[a]) / d[a];
+                t_in = fmaxf(t_in, fminf(ta, tb));
+                t_out = fminf(t_out, fmaxf(ta, tb));
+            } else if (cam.o[a] < lo || cam.o[a] > hi) {
+                t_out = -3.0e38f;  // parallel to the slab and outside it
+            }
+        }
+    }
+    // word range that can intersect the box.  The table is monotonic and (at jitter 0) linear: the range comes
+    // from its end points with 3 samples of slack, then the first/last kept word is verified against the table.
+    int w_lo = 0, w_hi = nwords - 1;
+    if (!raypos && D > 1) {
+        const float t0 = tmid[0], t1 = tmid[D - 1];
+        const float inv_dt = (float)(D - 1) / (t1 - t0);
+        const float jl = (t_in - t0) * inv_dt - 3.0f, jh = (t_out - t0) * inv_dt + 3.0f;
+        if (!(jh >= 0.f) || !(jl <= (float)(D - 1))) {
+            w_lo = 1;
+            w_hi = 0;  // the ray misses the box: nothing to probe
+        } else {
+            w_lo = (int)fmaxf(jl, 0.f) >> 6;
+            w_hi = (int)fminf(jh, (float)(D - 1)) >> 6;
+            // guard against a non-linear (jittered) table: extend while the neighbouring word still overlaps
+            while (w_lo > 0 && tmid[w_lo * 64 - 1] >= t_in) --w_lo;
+            while (w_hi < nwords - 1 && tmid[(w_hi + 1) * 64] <= t_out) ++w_hi;
+        }
+    }
+    unsigned long long my_word = 0ull;  // lane w keeps word w
+    for (int w = w_lo; w <= w_hi; ++w) {
         int j = w * 64 + lane;
         bool hit = false;
         if (j < D) {
@@ -99,12 +137,13 @@ __global__ void __launch_bounds__(TPB) k_select(GridView g, Camera cam, const fl
             }
         }
         unsigned long long m = __ballot(hit);
-        if (lane == 0) ray_bits[r * 8 + w] = m;
+        if (lane == w) my_word = m;
         total += __popcll(m);
     }
+    if (lane < 8) ray_bits[r * 8 + lane] = my_word;  // one 64-byte store per ray
     if (lane == 0) {
         ray_cnt[r] = min(total, SR);
-        if (total > 0) atomicAdd(n_hit_rays, 1ull);
+        if (total > 0) shard_add(shards, SH_RAYS_HIT, 1ull);
     }
 }
 
@@ -155,8 +194,7 @@ __global__ void __launch_bounds__(TPB) k_knn(GridView g, int K, float radius_lim
                                               const float4 *__restrict__ smp_loc, const int *__restrict__ smp_ray,
                                               const int *__restrict__ n_sel, int *__restrict__ smp_pidx,
                                               int *__restrict__ smp_valid, int *__restrict__ ray_flag,
-                                              unsigned long long *__restrict__ n_pairs,
-                                              unsigned long long *__restrict__ n_cand)
+                                              unsigned long long *__restrict__ shards)
 {
     const int S = n_sel[0];
     for (int64_t s = (int64_t)blockIdx.x * TPB + threadIdx.x; s < S; s += (int64_t)gridDim.x * TPB) {
@@ -234,9 +272,9 @@ __global__ void __launch_bounds__(TPB) k_knn(GridView g, int K, float radius_lim
         smp_valid[s] = nn > 0;
         if (nn > 0) {
             ray_flag[smp_ray[s]] = 1;  // every writer stores the same value
-            atomicAdd(n_pairs, (unsigned long long)nn);
+            shard_add(shards, SH_PAIRS, (unsigned long long)nn);
         }
-        atomicAdd(n_cand, (unsigned long long)tested);
+        shard_add(shards, SH_CAND, (unsigned long long)tested);
     }
 }
 
@@ -251,9 +289,9 @@ __global__ void __launch_bounds__(TPB) k_compact_valid(const int *__restrict__ s
     if (s0 == 0) {
         n_sel[1] = smp_voff[S];
         counters[PNR_CNT_SAMPLES_VALID] = smp_voff[S];
-        counters[PNR_CNT_RAYS_HIT] = (int64_t)acc[0];
-        counters[PNR_CNT_PAIRS_VALID] = (int64_t)acc[1];
-        counters[PNR_CNT_CANDIDATES] = (int64_t)acc[2];
+        counters[PNR_CNT_RAYS_HIT] = (int64_t)shard_sum(acc, SH_RAYS_HIT);
+        counters[PNR_CNT_PAIRS_VALID] = (int64_t)shard_sum(acc, SH_PAIRS);
+        counters[PNR_CNT_CANDIDATES] = (int64_t)shard_sum(acc, SH_CAND);
     }
     for (int64_t s = s0; s < S; s += (int64_t)gridDim.x * TPB)
         if (smp_valid[s]) vs_list[smp_voff[s]] = (int)s;
@@ -299,18 +337,20 @@ __global__ void __launch_bounds__(TPB) k_scatter_compat(int64_t R, int SR, int K
 static inline unsigned nblk(int64_t n, int per = TPB) { return (unsigned)std::max<int64_t>(1, (n + per - 1) / per); }
 
 // accumulators (unsigned long long) live behind n_sel: [8..13] as 64-bit words
-static inline unsigned long long *acc_ptr(RenderWs &ws) { return (unsigned long long *)(ws.n_sel + 16); }
+static inline unsigned long long *acc_ptr(RenderWs &ws) { return ws.shards; }
 
 int launch_select_expand(const GridView &g, const Camera &cam, const float *d_dirs, const float *d_raypos,
                          int64_t R, int D, int SR, const float *d_tmid, int64_t cap, RenderWs &ws,
                          int64_t *d_counters, hipStream_t stream)
 {
     PNR_HIP_CHECK(hipMemsetAsync(ws.n_sel, 0, 64 * sizeof(int), stream));
+    PNR_HIP_CHECK(hipMemsetAsync(ws.shards, 0, (size_t)SH_COUNT * SHARDS * SHARD_STRIDE * sizeof(unsigned long long),
+                                 stream));
     PNR_HIP_CHECK(hipMemsetAsync(d_counters, 0, PNR_NUM_COUNTERS * sizeof(int64_t), stream));
     PNR_HIP_CHECK(hipMemsetAsync(ws.ray_flag, 0, (size_t)(R + 1) * sizeof(int), stream));
     unsigned long long *acc = acc_ptr(ws);
     hipLaunchKernelGGL(k_select, dim3(nblk(R, TPB / 64)), dim3(TPB), 0, stream, g, cam, d_dirs, d_raypos, d_tmid, R,
-                       D, SR, ws.ray_cnt, ws.ray_bits, acc + 0);
+                       D, SR, ws.ray_cnt, ws.ray_bits, acc);
     int rc = scan_exclusive_i32(ws.ray_cnt, ws.ray_off, R, nullptr, nullptr, ws.scan_temp, stream);
     if (rc != PNR_OK) return rc;
     hipLaunchKernelGGL(k_expand, dim3(nblk(R, TPB / 64)), dim3(TPB), 0, stream, cam, d_dirs, d_raypos, d_tmid, R, D,
@@ -328,13 +368,13 @@ int launch_knn(const GridView &g, int K, float radius_limit, RenderWs &ws, int64
     const unsigned grid = (unsigned)std::min<int64_t>(nblk(cap), 256 * 32);
     if (K <= 8)
         hipLaunchKernelGGL(k_knn<8>, dim3(grid), dim3(TPB), 0, stream, g, K, r2, ws.smp_loc, ws.smp_ray, ws.n_sel,
-                           ws.smp_pidx, ws.smp_valid, ws.ray_flag, acc + 1, acc + 2);
+                           ws.smp_pidx, ws.smp_valid, ws.ray_flag, acc);
     else if (K <= 16)
         hipLaunchKernelGGL(k_knn<16>, dim3(grid), dim3(TPB), 0, stream, g, K, r2, ws.smp_loc, ws.smp_ray, ws.n_sel,
-                           ws.smp_pidx, ws.smp_valid, ws.ray_flag, acc + 1, acc + 2);
+                           ws.smp_pidx, ws.smp_valid, ws.ray_flag, acc);
     else
         hipLaunchKernelGGL(k_knn<32>, dim3(grid), dim3(TPB), 0, stream, g, K, r2, ws.smp_loc, ws.smp_ray, ws.n_sel,
-                           ws.smp_pidx, ws.smp_valid, ws.ray_flag, acc + 1, acc + 2);
+                           ws.smp_pidx, ws.smp_valid, ws.ray_flag, acc);
     int rc = scan_exclusive_i32(ws.smp_valid, ws.smp_voff, cap, ws.n_sel, nullptr, ws.scan_temp, stream);
     if (rc != PNR_OK) return rc;
     hipLaunchKernelGGL(k_compact_valid, dim3(grid), dim3(TPB), 0, stream, ws.smp_valid, ws.smp_voff, ws.n_sel,

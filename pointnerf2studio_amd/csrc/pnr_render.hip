@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(TPB) k_composite(Camera cam, pnr_render_opts_t
                                                     const float4 *__restrict__ smp_out, const int *__restrict__ n_sel,
                                                     float *__restrict__ rgb, float *__restrict__ depth,
                                                     float *__restrict__ acc_out, int8_t *__restrict__ ray_mask,
-                                                    unsigned long long *__restrict__ n_kept)
+                                                    unsigned long long *__restrict__ shards)
 {
     const int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x;
     if (r >= R) return;
@@ -108,18 +108,18 @@ __global__ void __launch_bounds__(TPB) k_composite(Camera cam, pnr_render_opts_t
     if (depth) depth[r] = keep ? dsum / (acc + 1e-6f) : 0.f;
     if (acc_out) acc_out[r] = keep ? acc : 0.f;
     ray_mask[r] = (int8_t)(keep ? 1 : 0);
-    if (keep) atomicAdd(n_kept, 1ull);
+    if (keep) shard_add(shards, SH_KEPT, 1ull);
 }
 
-__global__ void k_publish_kept(const unsigned long long *__restrict__ n_kept, int64_t *__restrict__ counters)
+__global__ void k_publish_kept(const unsigned long long *__restrict__ shards, int64_t *__restrict__ counters)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) counters[PNR_CNT_RAYS_KEPT] = (int64_t)*n_kept;
+    if (threadIdx.x == 0 && blockIdx.x == 0) counters[PNR_CNT_RAYS_KEPT] = (int64_t)shard_sum(shards, SH_KEPT);
 }
 
 int launch_composite(const Camera &cam, const pnr_render_opts_t &opts, int64_t R, RenderWs &ws, float *d_rgb,
                      float *d_depth, float *d_acc, int8_t *d_ray_mask, int64_t *d_counters, hipStream_t stream)
 {
-    unsigned long long *n_kept = (unsigned long long *)(ws.n_sel + 16) + 3;
+    unsigned long long *n_kept = ws.shards;
     hipLaunchKernelGGL(k_composite, dim3((unsigned)((R + TPB - 1) / TPB)), dim3(TPB), 0, stream, cam, opts, R,
                        ws.ray_cnt, ws.ray_off, ws.ray_flag, ws.smp_loc, ws.smp_out, ws.n_sel, d_rgb, d_depth, d_acc,
                        d_ray_mask, n_kept);

@@ -38,6 +38,24 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define PNR_ABLATE 0
 #endif
 
+// diagnostic builds only: -DPNR_STAMPS=1 accumulates s_memtime deltas of the phases of k_shade_pairs_bf16 per wave
+// and writes them (never into an output) to the tail of the smp_sigma buffer
+#ifndef PNR_STAMPS
+#define PNR_STAMPS 0
+#endif
+__device__ __forceinline__ unsigned long long stamp()
+{
+#if PNR_STAMPS
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+#else
+    return 0;
+#endif
+}
+
 constexpr int WAVES = 4;
 constexpr int TPB = WAVES * 64;
 constexpr int PF = 6;  // fp32 path: weight loads (1 KiB each per wave) kept in flight
@@ -64,6 +82,7 @@ struct ShadeParams {
     float *agg;        // [S_valid, 256]
     float4 *smp_out;   // [S_sel]
     int K;
+    long long dbg_off;  // PNR_STAMPS builds: float offset into smp_sigma of the stamp area
 };
 
 __device__ __forceinline__ float4 load_w(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff)
@@ -88,6 +107,32 @@ __device__ __forceinline__ void to_cam(const Camera &cam, float x, float y, floa
     cx = sx * cam.R[0] + sy * cam.R[3] + sz * cam.R[6];
     cy = sx * cam.R[1] + sy * cam.R[4] + sz * cam.R[7];
     cz = sx * cam.R[2] + sy * cam.R[5] + sz * cam.R[8];
+}
+
+// sin and cos for the bf16x3 mode: Cody-Waite reduction by pi/2 (two constants, exact for |x| < ~800) + the
+// single-precision minimax polynomials on [-pi/4, pi/4] (max error ~1e-7, below the mode's 2^-16 products).
+// Branch-free and ~25 instructions against ~60 for sincosf with its large-argument path; arguments beyond the
+// reduction's range (never produced by trained embeddings or voxel-sized distances) fall back to sincosf.
+__device__ __forceinline__ void fast_sincos(float x, float &sn, float &cs)
+{
+    if (__builtin_expect(fabsf(x) > 512.0f, 0)) {
+        sincosf(x, &sn, &cs);
+        return;
+    }
+    const float k = rintf(x * 0.636619772367581343f);           // x * 2/pi
+    float r = fmaf(-k, 1.5707962512969970703125f, x);           // pi/2 high part
+    r = fmaf(-k, 7.54978995489188216e-8f, r);                   // pi/2 low part
+    const float z = r * r;
+    float ps = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = fmaf(z, ps, -1.6666654611e-1f);
+    const float s0 = fmaf(r * z, ps, r);
+    float pc = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = fmaf(z, pc, 4.166664568298827e-2f);
+    const float c0 = fmaf(z * z, pc, fmaf(z, -0.5f, 1.0f));
+    const int q = (int)k;
+    const float ss = (q & 1) ? c0 : s0, cc = (q & 1) ? s0 : c0;
+    sn = (q & 2) ? -ss : ss;
+    cs = ((q + 1) & 2) ? -cc : cc;
 }
 
 // sum over the K lanes of one sample (lanes [g*K, g*K+K) inside each 32-lane half)
@@ -185,6 +230,8 @@ __device__ __forceinline__ void load_rows(const ShadeParams &P, int tile, int la
                 const float s2 = 2.0f * sn * cs, c2 = (cs - sn) * (cs + sn);
                 sn = s2;
                 cs = c2;
+            } else if (FAST_PE) {
+                fast_sincos(e[d], sn, cs);
             } else {
                 sincosf(e[d] * (float)(1 << f), &sn, &cs);
             }
@@ -204,6 +251,8 @@ __device__ __forceinline__ void load_rows(const ShadeParams &P, int tile, int la
                 const float s2 = 2.0f * sn * cs, c2 = (cs - sn) * (cs + sn);
                 sn = s2;
                 cs = c2;
+            } else if (FAST_PE) {
+                fast_sincos(dd[d], sn, cs);
             } else {
                 sincosf(dd[d] * (float)(1 << f), &sn, &cs);
             }
@@ -226,6 +275,38 @@ __device__ __forceinline__ void load_rows(const ShadeParams &P, int tile, int la
     ctx.ex[3] = h ? 0.f : dot;
 }
 
+// Bias-initialised accumulator of an output tile.  The tile's 32 biases are wave-uniform: they are fetched through
+// the SCALAR cache (s_load_dwordx16 x2, counted on lgkmcnt, issued a few k-steps ahead) and selected per lane
+// half.  Not from LDS: hipcc cannot tell an LDS read from the LDS-DMA destinations in flight and guards it with
+// s_waitcnt vmcnt(0), draining the DMA once per tile; not by VMEM either: vector memory returns in order, behind
+// the DMA.  (hipcc emits vector loads for a plain `bias[i]`, hence the inline asm.)
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+struct BiasRegs {
+    i32x16 a, b;
+};
+
+__device__ __forceinline__ void bias_issue(const float *bias32, BiasRegs &r)
+{
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=s"(r.a), "=s"(r.b) : "s"(bias32) : "memory");
+}
+
+__device__ __forceinline__ f32x16 bias_finish(BiasRegs &r, int h)
+{
+    // also retires the (at most four) fragment reads in flight: one LDS latency per tile
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r.a), "+s"(r.b)::"memory");
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int lo = 8 * q + i, hi = 8 * q + 4 + i;
+            const float flo = __int_as_float(lo < 16 ? r.a[lo] : r.b[lo - 16]);
+            const float fhi = __int_as_float(hi < 16 ? r.a[hi] : r.b[hi - 16]);
+            acc[4 * q + i] = h ? fhi : flo;
+        }
+    return acc;
+}
+
 // density head + weighted K-aggregation + stores (studio_model.py:337-353)
 template <bool K8>
 __device__ __forceinline__ void finish_rows(const ShadeParams &P, int lane, const float (&hC)[128],
@@ -235,17 +316,27 @@ __device__ __forceinline__ void finish_rows(const ShadeParams &P, int lane, cons
     const int K = K8 ? 8 : P.K;
     const float *w4 = P.wbuf + P.w_off[4];
     const float b4 = P.wbuf[P.b_off[4]];
-    float part = 0.f;
+    // The 256 head weights are wave-uniform: 32 at a time through the scalar cache (hipcc turned the per-lane
+    // float4 loads of an earlier version into 32 load -> vmcnt(0) -> use round trips, 12k cycles per tile).
+    // Both lane halves multiply with uniform weights (SGPR operand) and pick their own sum at the end.
+    float part_lo = 0.f, part_hi = 0.f;
 #pragma unroll
-    for (int m = 0; m < 8; ++m)
+    for (int m = 0; m < 8; ++m) {
+        BiasRegs wr;
+        bias_issue(w4 + 32 * m, wr);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(wr.a), "+s"(wr.b)::"memory");
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 wv = *reinterpret_cast<const float4 *>(w4 + 32 * m + 8 * q + 4 * h);
-            part += hC[m * 16 + 4 * q + 0] * wv.x;
-            part += hC[m * 16 + 4 * q + 1] * wv.y;
-            part += hC[m * 16 + 4 * q + 2] * wv.z;
-            part += hC[m * 16 + 4 * q + 3] * wv.w;
-        }
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int lo = 8 * q + i, hi = 8 * q + 4 + i;
+                const float wlo = __int_as_float(lo < 16 ? wr.a[lo] : wr.b[lo - 16]);
+                const float whi = __int_as_float(hi < 16 ? wr.a[hi] : wr.b[hi - 16]);
+                part_lo += hC[m * 16 + 4 * q + i] * wlo;
+                part_hi += hC[m * 16 + 4 * q + i] * whi;
+            }
+    }
+    float part = h ? part_hi : part_lo;
     part += __shfl_xor(part, 32, 64);
     const float alpha = fmaxf(part + b4, 0.f);
     const float sigma = seg_sum<K8>(alpha * ctx.wgt, K, lane);
@@ -458,9 +549,8 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_color(ShadeParams P)
 // bf16x3 mode
 // ================================================================================================
 constexpr int STAGE_U4 = 9 * 256;        // one LDS weight tile: up to 18 k-steps x {hi, lo} x 64 lanes x 16 B = 36 KiB
-constexpr int RING = 3;                  // weight tiles in LDS: one being multiplied, two in flight
-constexpr int BIAS_U4 = 256;             // 1024 floats of biases behind the ring
-constexpr int LDS_U4 = RING * STAGE_U4 + BIAS_U4;
+constexpr int RING = 4;                  // weight tiles in LDS: one being multiplied, up to three landed / in flight
+constexpr int LDS_U4 = RING * STAGE_U4;
 
 __device__ __forceinline__ void split8(const float *v, bf16x8 &hi, bf16x8 &lo)
 {
@@ -485,75 +575,79 @@ __device__ __forceinline__ void stage_dma(__amdgpu_buffer_rsrc_t rsrc, int off, 
                                                  tid * 16, off + i * 4096, 0, 0);
 }
 
-// per-wave state of the weight-tile ring
+__device__ __forceinline__ void stage_dma_one(__amdgpu_buffer_rsrc_t rsrc, int off, int tid, int wave_u, u32x4 *lds,
+                                              int slot, int i)
+{
+    typedef __attribute__((address_space(3))) void *lds_ptr_t;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + slot * STAGE_U4 + i * 256 + wave_u * 64), 16, tid * 16,
+                                             off + i * 4096, 0, 0);
+}
+
+// per-wave state of the weight-tile ring: slot of the tile being multiplied, the A fragments of the next two
+// k-steps (already read from LDS) and the bias-initialised accumulator of the next tile
 struct Ring {
-    int cur;  // slot holding the tile about to be multiplied
+    int cur;
+    u32x4 ah, al, bh, bl;
+    f32x16 acc0;
 };
 
 // One dense layer on bf16 hi/lo splits.  MT output tiles of 32 features.  Weight tiles
-// ([KS][{hi,lo}][64 lanes][8 bf16], KS * 2 KiB) travel L2 -> LDS by LDS-DMA two tiles ahead of use in a 3-slot
-// ring: when tile T is multiplied, T+1 has landed or is landing and T+2 is issued.  KS_N1 / KS_N2 are the
-// k-step counts of the first / second tile of the following layers (wn1 / wn2 their byte offsets), used when
-// this layer's last tiles prefetch across the layer boundary.
+// ([KS][{hi,lo}][64 lanes][8 bf16], KS * 2 KiB) travel L2 -> LDS by LDS-DMA into a 4-slot ring, issued three
+// tiles ahead of use.  KS_NX is the k-step count of the NEXT layer's tiles (byte offset wnx, biases at
+// bias_nx_off): this layer's last tiles prefetch across the layer boundary, so the k-loop of the whole MLP chain
+// is one continuous stream of MFMAs.
 //
-// The instruction order is pinned by hand, because left alone hipcc serialises `ds_read -> lgkmcnt(0) -> mfma`
-// through one register quad and sinks loads down to their first use:
-//   * the DMA of tile T+2 issues first; biases come from LDS (a VMEM bias load issued behind the DMA would
-//     make the accumulator initialisation wait for the whole DMA: VMEM returns in order);
-//   * A-operand fragments are read from LDS two k-steps ahead into a three-deep register ring;
+// The instruction order is pinned by hand (left alone hipcc serialises `ds_read -> lgkmcnt(0) -> mfma` through
+// one register quad and sinks loads down to their first use):
+//   * A-operand fragments are read from LDS two k-steps ahead, ACROSS tile and layer boundaries, and the next
+//     tile's accumulator is initialised from the LDS bias table during the last k-step (a VMEM bias load
+//     issued behind the DMA would wait for the whole DMA: VMEM returns in order);
+//   * ONE raw s_barrier per tile, in the MIDDLE of the tile: it publishes tile T+1 (whose DMA was issued two
+//     tiles earlier; a COUNTED vmcnt keeps tile T+2's DMA in flight -- __syncthreads() would drain it) and
+//     frees the slot of tile T-1 for the DMA of tile T+3, issued right behind it.  The fragment stream never
+//     stops at a barrier;
 //   * with SPLIT_OUT the activation + hi/lo split of the PREVIOUS output tile (16 values -> two k-steps of the
-//     next layer's operands) is cut in three and placed BETWEEN the three MFMAs of the first 8 k-steps
-//     (an in-order wave cannot issue VALU work placed behind an MFMA that waits for the matrix pipe);
-//   * one raw s_barrier per tile, preceded by a COUNTED vmcnt that retires tile T+1's DMA and leaves T+2's in
-//     flight (__syncthreads() would drain it with vmcnt(0)).
-template <int KS, int MT, int KS_N1, int KS_N2, bool SPLIT_OUT>
-__device__ __forceinline__ void dense_layer_bf16(__amdgpu_buffer_rsrc_t rsrc, int wbase, int wn1, int wn2,
-                                                 int bias_off, int lane, int tid, int wave_u, u32x4 *lds, Ring &ring,
-                                                 const bf16x8 *xh, const bf16x8 *xl, bf16x8 *yh, bf16x8 *yl,
-                                                 float *outf)
+//     next layer's operands) is cut in three and placed BETWEEN the three MFMAs of the first 8 k-steps (an
+//     in-order wave cannot issue VALU work placed behind an MFMA that waits for the matrix pipe).
+template <int KS, int MT, int KS_NX, bool SPLIT_OUT>
+__device__ __forceinline__ void dense_layer_bf16(__amdgpu_buffer_rsrc_t rsrc, int wbase, int wnx,
+                                                 const float *__restrict__ bias, const float *__restrict__ bias_nx,
+                                                 int lane, int tid, int wave_u, u32x4 *lds,
+                                                 Ring &ring, const bf16x8 *xh, const bf16x8 *xl, bf16x8 *yh,
+                                                 bf16x8 *yl, float *outf)
 {
     static_assert(KS >= 8, "the split of the previous tile is spread over 8 k-steps");
+    static_assert(MT >= 3, "the DMA runs three tiles ahead");
     const int h = lane >> 5;
-    const float *bias_lds = reinterpret_cast<const float *>(lds + RING * STAGE_U4) + bias_off;
+    constexpr int R_SAME = (KS + 1) / 2, R_NX = (KS_NX + 1) / 2;
     f32x16 prev;
+    BiasRegs breg;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        // ---- tile T+2 on its way --------------------------------------------------------------------------
-        int slot2 = ring.cur + 2;
-        slot2 = slot2 >= RING ? slot2 - RING : slot2;
-        constexpr int R_SAME = (KS + 1) / 2, R_N1 = (KS_N1 + 1) / 2, R_N2 = (KS_N2 + 1) / 2;
-        if (m + 2 < MT)
-            stage_dma<R_SAME>(rsrc, wbase + (m + 2) * KS * 2048, tid, wave_u, lds, slot2);
-        else if (m + 2 == MT)
-            stage_dma<R_N1>(rsrc, wn1, tid, wave_u, lds, slot2);
-        else
-            stage_dma<R_N2>(rsrc, wn2, tid, wave_u, lds, slot2);
-        const int in_flight = (m + 2 < MT) ? R_SAME : (m + 2 == MT ? R_N1 : R_N2);
         const u32x4 *cur = lds + ring.cur * STAGE_U4;
-        f32x16 acc;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 b = *reinterpret_cast<const float4 *>(bias_lds + 32 * m + 8 * q + 4 * h);
-            acc[4 * q + 0] = b.x;
-            acc[4 * q + 1] = b.y;
-            acc[4 * q + 2] = b.z;
-            acc[4 * q + 3] = b.w;
-        }
-        u32x4 fh[3], fl[3];
-        fh[0] = cur[0 * 64 + lane];
-        fl[0] = cur[1 * 64 + lane];
-        fh[1] = cur[2 * 64 + lane];
-        fl[1] = cur[3 * 64 + lane];
-        __builtin_amdgcn_sched_barrier(0);
+        const int nxs = ring.cur + 1 >= RING ? ring.cur + 1 - RING : ring.cur + 1;
+        const u32x4 *nxt = lds + nxs * STAGE_U4;
+        f32x16 acc = ring.acc0;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
+            // fragments of k-step s+2: of this tile, or of the next tile (published by the mid-tile barrier)
+            u32x4 ch, cl;
             if (s + 2 < KS) {
-                fh[(s + 2) % 3] = cur[(2 * (s + 2)) * 64 + lane];
-                fl[(s + 2) % 3] = cur[(2 * (s + 2) + 1) * 64 + lane];
+                ch = cur[(2 * (s + 2)) * 64 + lane];
+                cl = cur[(2 * (s + 2) + 1) * 64 + lane];
+            } else {
+                ch = nxt[(2 * (s + 2 - KS)) * 64 + lane];
+                cl = nxt[(2 * (s + 2 - KS) + 1) * 64 + lane];
             }
-            const bf16x8 wh = __builtin_bit_cast(bf16x8, fh[s % 3]);
-            const bf16x8 wl = __builtin_bit_cast(bf16x8, fl[s % 3]);
-            const bool do_split = SPLIT_OUT && m > 0 && s < 8 && !(PNR_ABLATE & 16);
+            if (s == KS - 6) bias_issue((m + 1 < MT) ? bias + 32 * (m + 1) : bias_nx, breg);
+            if (s == KS - 1) ring.acc0 = bias_finish(breg, h);
+            const bf16x8 wh = __builtin_bit_cast(bf16x8, ring.ah);
+            const bf16x8 wl = __builtin_bit_cast(bf16x8, ring.al);
+            // the previous tile's accumulators are read two k-steps into this tile at the earliest: its last MFMA
+            // needs ~64 cycles to retire
+            constexpr int S0 = KS >= 10 ? 2 : 0;
+            const bool do_split = SPLIT_OUT && m > 0 && s >= S0 && s < S0 + 8 && !(PNR_ABLATE & 16);
+            const int sp = s - S0;
             float v0 = 0.f, v1 = 0.f, r0 = 0.f, r1 = 0.f;
             __bf16 h0, h1;
             if (PNR_ABLATE & 2)
@@ -561,8 +655,8 @@ __device__ __forceinline__ void dense_layer_bf16(__amdgpu_buffer_rsrc_t rsrc, in
             else
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[s], acc, 0, 0, 0);
             if (do_split) {
-                v0 = leaky(prev[2 * s]);
-                v1 = leaky(prev[2 * s + 1]);
+                v0 = leaky(prev[2 * sp]);
+                v1 = leaky(prev[2 * sp + 1]);
                 h0 = (__bf16)v0;
                 h1 = (__bf16)v1;
             }
@@ -575,11 +669,42 @@ __device__ __forceinline__ void dense_layer_bf16(__amdgpu_buffer_rsrc_t rsrc, in
             __builtin_amdgcn_sched_barrier(0);
             if (!(PNR_ABLATE & 2)) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[s], acc, 0, 0, 0);
             if (do_split) {
-                const int kk = 2 * (m - 1) + s / 4, j0 = (2 * s) % 8;
+                const int kk = 2 * (m - 1) + sp / 4, j0 = (2 * sp) % 8;
                 yh[kk][j0] = h0;
                 yh[kk][j0 + 1] = h1;
                 yl[kk][j0] = (__bf16)r0;
                 yl[kk][j0 + 1] = (__bf16)r1;
+            }
+            ring.ah = ring.bh;
+            ring.al = ring.bl;
+            ring.bh = ch;
+            ring.bl = cl;
+            constexpr int S_MID = KS / 2 - 1;
+            if (s == S_MID && !(PNR_ABLATE & 8)) {
+                // ---- mid-tile: tile T+1 has landed everywhere, slot of tile T-1 is free ---------------------------
+                if ((m + 2 < MT ? R_SAME : R_NX) == 9)
+                    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                else if ((m + 2 < MT ? R_SAME : R_NX) == 8)
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            // ---- DMA of tile T+3 into the freed slot: two 1-KiB pieces per k-step behind the barrier, so the
+            //      scalar address arithmetic hides between MFMAs instead of stalling the matrix pipe in one burst
+            if (s > S_MID && !(PNR_ABLATE & 8)) {
+                constexpr int R3 = 0;
+                (void)R3;
+                const int rounds = (m + 3 < MT) ? R_SAME : R_NX;
+                constexpr int STEPS = KS - 1 - S_MID;               // k-steps left behind the barrier
+                const int per = (rounds + STEPS - 1) / STEPS;       // pieces per k-step (1..3)
+                const int first = per * (s - S_MID - 1);
+                int slot3 = ring.cur + 3;
+                slot3 = slot3 >= RING ? slot3 - RING : slot3;
+                const int off3 = (m + 3 < MT) ? wbase + (m + 3) * KS * 2048 : wnx + (m + 3 - MT) * KS_NX * 2048;
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (q < per && first + q < rounds) stage_dma_one(rsrc, off3, tid, wave_u, lds, slot3, first + q);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -589,18 +714,7 @@ __device__ __forceinline__ void dense_layer_bf16(__amdgpu_buffer_rsrc_t rsrc, in
 #pragma unroll
             for (int r = 0; r < 16; ++r) outf[m * 16 + r] = acc[r];
         }
-        // ---- tile T+1 must have landed (this wave's share), T+2 stays in flight; then everybody's share ---------
-        if (!(PNR_ABLATE & 8)) {
-            if (in_flight == 9)
-                asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-            else if (in_flight == 8)
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-        ring.cur = ring.cur + 1 >= RING ? 0 : ring.cur + 1;
+        ring.cur = nxs;
     }
     if (SPLIT_OUT && !(PNR_ABLATE & 16)) {
 #pragma unroll
@@ -616,15 +730,25 @@ __device__ __forceinline__ void dense_layer_bf16(__amdgpu_buffer_rsrc_t rsrc, in
     }
 }
 
-// biases of layers [first, first+count) into the LDS table (float index = 256 * (layer - first))
-__device__ __forceinline__ void load_bias_table(const ShadeParams &P, int first, int count, int width, int tid,
-                                                u32x4 *lds)
+// first three tiles of a chain into slots 0..2, fragments of k-steps 0 and 1 and the first accumulator
+template <int KS0>
+__device__ __forceinline__ void ring_start(__amdgpu_buffer_rsrc_t rsrc, int w_first, const float *__restrict__ bias0,
+                                           int lane, int tid, int wave_u, u32x4 *lds, Ring &ring)
 {
-    float *tab = reinterpret_cast<float *>(lds + RING * STAGE_U4);
-    for (int i = tid; i < count * 256; i += TPB) {
-        const int l = i >> 8, c = i & 255;
-        tab[i] = c < width ? P.wbuf[P.b_off[first + l] + c] : 0.f;
-    }
+    constexpr int R0 = (KS0 + 1) / 2;
+    stage_dma<R0>(rsrc, w_first, tid, wave_u, lds, 0);
+    stage_dma<R0>(rsrc, w_first + KS0 * 2048, tid, wave_u, lds, 1);
+    stage_dma<R0>(rsrc, w_first + 2 * KS0 * 2048, tid, wave_u, lds, 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    ring.cur = 0;
+    ring.ah = lds[0 * 64 + lane];
+    ring.al = lds[1 * 64 + lane];
+    ring.bh = lds[2 * 64 + lane];
+    ring.bl = lds[3 * 64 + lane];
+    BiasRegs breg;
+    bias_issue(bias0, breg);
+    ring.acc0 = bias_finish(breg, lane >> 5);
 }
 
 template <bool K8>
@@ -646,44 +770,66 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
     const int w0_ = (int)(P.w16_off[0] * 4), w1_ = (int)(P.w16_off[1] * 4), w2_ = (int)(P.w16_off[2] * 4),
               w3_ = (int)(P.w16_off[3] * 4);
     if (t_begin >= t_end) return;  // uniform per workgroup
-    Ring ring{0};
-    load_bias_table(P, 0, 4, 256, tid, lds);
-    // tiles 0 and 1 of the chain (layer 0, m = 0, 1) into ring slots 0 and 1
-    stage_dma<9>(rsrc, w0_, tid, wave_u, lds, 0);
-    stage_dma<9>(rsrc, w0_ + 18 * 2048, tid, wave_u, lds, 1);
-    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-    __syncthreads();
+    const float *__restrict__ b0 = P.wbuf + P.b_off[0];
+    const float *__restrict__ b1 = P.wbuf + P.b_off[1];
+    const float *__restrict__ b2 = P.wbuf + P.b_off[2];
+    const float *__restrict__ b3 = P.wbuf + P.b_off[3];
+    Ring ring;
+    ring_start<18>(rsrc, w0_, b0, lane, tid, wave_u, lds, ring);
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int tile = t_begin; tile < t_end; ++tile) {
         int w0 = w0_, w1 = w1_, w2 = w2_, w3 = w3_;
         asm volatile("" : "+s"(w0), "+s"(w1), "+s"(w2), "+s"(w3));
+        const unsigned long long ts0 = stamp();
         RowCtx ctx;
         bf16x8 xh[18], xl[18];
         {
             float x0[144];
             load_rows<K8, true>(P, tile, lane, wave, S_valid, x0, ctx);
+            const unsigned long long ts0b = stamp();
+            ph[6] += ts0b - ts0;
 #pragma unroll
             for (int s = 0; s < 18; ++s) split8(&x0[8 * s], xh[s], xl[s]);
         }
+        const unsigned long long ts1 = stamp();
         bf16x8 yh[17], yl[17];
-        dense_layer_bf16<18, 8, 16, 16, true>(rsrc, w0, w1, w1 + 16 * 2048, 0, lane, tid, wave_u, lds, ring, xh, xl, yh,
-                                              yl, nullptr);
+        dense_layer_bf16<18, 8, 16, true>(rsrc, w0, w1, b0, b1, lane, tid, wave_u, lds, ring, xh, xl, yh, yl, nullptr);
+        const unsigned long long ts2 = stamp();
         // xh/xl are free again: they receive layer 2's output (+ the 7 extra head inputs as k-step 16)
-        dense_layer_bf16<16, 8, 17, 17, true>(rsrc, w1, w2, w2 + 17 * 2048, 256, lane, tid, wave_u, lds, ring, yh, yl,
-                                              xh, xl, nullptr);
+        dense_layer_bf16<16, 8, 17, true>(rsrc, w1, w2, b1, b2, lane, tid, wave_u, lds, ring, yh, yl, xh, xl, nullptr);
+        const unsigned long long ts3 = stamp();
         {
             float v[8] = {ctx.ex[0], ctx.ex[1], ctx.ex[2], ctx.ex[3], 0.f, 0.f, 0.f, 0.f};
             split8(v, xh[16], xl[16]);
         }
-        dense_layer_bf16<17, 8, 16, 16, true>(rsrc, w2, w3, w3 + 16 * 2048, 512, lane, tid, wave_u, lds, ring, xh, xl,
-                                              yh, yl, nullptr);
+        dense_layer_bf16<17, 8, 16, true>(rsrc, w2, w3, b2, b3, lane, tid, wave_u, lds, ring, xh, xl, yh, yl, nullptr);
+        const unsigned long long ts4 = stamp();
         float o[128];
-        // the chain wraps around: the next pair tile starts again with layer 0, tiles 0 and 1
-        dense_layer_bf16<16, 8, 18, 18, false>(rsrc, w3, w0, w0 + 18 * 2048, 768, lane, tid, wave_u, lds, ring, yh, yl,
-                                               nullptr, nullptr, o);
+        // the chain wraps around: the next pair tile starts again with layer 0
+        dense_layer_bf16<16, 8, 18, false>(rsrc, w3, w0, b3, b0, lane, tid, wave_u, lds, ring, yh, yl, nullptr, nullptr,
+                                           o);
+        const unsigned long long ts5 = stamp();
 #pragma unroll
         for (int i = 0; i < 128; ++i) o[i] = leaky(o[i]);
         finish_rows<K8>(P, lane, o, ctx);
+        const unsigned long long ts6 = stamp();
+        ph[0] += ts1 - ts0;
+        ph[1] += ts2 - ts1;
+        ph[2] += ts3 - ts2;
+        ph[3] += ts4 - ts3;
+        ph[4] += ts5 - ts4;
+        ph[5] += ts6 - ts5;
+        ph[7] += 1;
     }
+#if PNR_STAMPS
+    if (lane == 0) {
+        // debug tail of the sigma buffer: [cap - 8192 .. cap) floats hold 8 x u64 per wave for the first 512 waves
+        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(P.smp_sigma + P.dbg_off);
+        const int wid = blockIdx.x * WAVES + wave;
+        if (wid < 256)
+            for (int i = 0; i < 8; ++i) dbg[wid * 8 + i] = ph[i];
+    }
+#endif
     // the two tiles prefetched for a pair tile that does not exist are simply dropped
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -703,12 +849,11 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_color_bf16(ShadeParams P)
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wbuf), 0, (int)P.wbytes, 0x00020000);
     const int w5_ = (int)(P.w16_off[5] * 4), w6_ = (int)(P.w16_off[6] * 4), w7_ = (int)(P.w16_off[7] * 4);
     if ((int)blockIdx.x >= ntiles) return;
-    Ring ring{0};
-    load_bias_table(P, 5, 3, 128, tid, lds);
-    stage_dma<9>(rsrc, w5_, tid, wave_u, lds, 0);
-    stage_dma<9>(rsrc, w5_ + 18 * 2048, tid, wave_u, lds, 1);
-    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-    __syncthreads();
+    const float *__restrict__ b5 = P.wbuf + P.b_off[5];
+    const float *__restrict__ b6 = P.wbuf + P.b_off[6];
+    const float *__restrict__ b7 = P.wbuf + P.b_off[7];
+    Ring ring;
+    ring_start<18>(rsrc, w5_, b5, lane, tid, wave_u, lds, ring);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int w5 = w5_, w6 = w6_, w7 = w7_;
         asm volatile("" : "+s"(w5), "+s"(w6), "+s"(w7));
@@ -751,13 +896,10 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_color_bf16(ShadeParams P)
             split8(v17, xh[17], xl[17]);
         }
         bf16x8 yh[8], yl[8];
-        dense_layer_bf16<18, 4, 8, 8, true>(rsrc, w5, w6, w6 + 8 * 2048, 0, lane, tid, wave_u, lds, ring, xh, xl, yh, yl,
-                                            nullptr);
-        dense_layer_bf16<8, 4, 8, 8, true>(rsrc, w6, w7, w7 + 8 * 2048, 256, lane, tid, wave_u, lds, ring, yh, yl, xh, xl,
-                                           nullptr);
+        dense_layer_bf16<18, 4, 8, true>(rsrc, w5, w6, b5, b6, lane, tid, wave_u, lds, ring, xh, xl, yh, yl, nullptr);
+        dense_layer_bf16<8, 4, 8, true>(rsrc, w6, w7, b6, b7, lane, tid, wave_u, lds, ring, yh, yl, xh, xl, nullptr);
         float o[64];
-        dense_layer_bf16<8, 4, 18, 18, false>(rsrc, w7, w5, w5 + 18 * 2048, 512, lane, tid, wave_u, lds, ring, xh, xl,
-                                              nullptr, nullptr, o);
+        dense_layer_bf16<8, 4, 18, false>(rsrc, w7, w5, b7, b5, lane, tid, wave_u, lds, ring, xh, xl, nullptr, nullptr, o);
 #pragma unroll
         for (int i = 0; i < 64; ++i) o[i] = leaky(o[i]);
         float rgb[3];
@@ -901,6 +1043,7 @@ int launch_shade(const pnr_scene *scene, const pnr_weights *w, const Camera &cam
     P.agg = ws.agg;
     P.smp_out = ws.smp_out;
     P.K = K;
+    P.dbg_off = cap - 8192;
     int dev = 0, cus = 256;
     PNR_HIP_CHECK(hipGetDevice(&dev));
     PNR_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
