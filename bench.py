@@ -7,8 +7,9 @@ K = 8 neighbours, fp32, jitter 0; MLP weights Xavier-initialised (seed 0), densi
 opacities are non-trivial.  Datasets / checkpoints are not reachable: data is synthetic, seeded.
 
 One step = N views (N = number of GPUs).  Every view is cut into 16x16-pixel tiles dealt round-robin to the
-N ranks; each rank renders its tiles of every view (N * 640000 / N = 640000 rays per rank per step: weak
-scaling) and ONE all_gather per view (RCCL over xGMI) puts the full RGB+depth image on every rank.
+N ranks; each rank renders its tiles of all N views in ONE multi-camera call (N * 640000 / N = 640000 rays per
+rank per step: weak scaling) and ONE all_gather per step (RCCL over xGMI) puts the N full RGB+depth images on
+every rank.
 Inputs (ray directions, point tensors, weights, voxel structure) are resident in HBM before the timed
 region; the timed region covers query + gather + MLPs + composite + all_gather for K steps.
 
@@ -39,7 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from pointnerf2studio_amd import _lib, synthetic  # noqa: E402
-from pointnerf2studio_amd.distributed import gather_image, make_shard  # noqa: E402
+from pointnerf2studio_amd.distributed import gather_views, make_shard  # noqa: E402
 from pointnerf2studio_amd.renderer import (RendererHIP, SceneHIP, WeightsHIP, grid_hyperparameters)  # noqa: E402
 
 FLOPS_PER_PAIR = 542_720       # 2 * (284*256 + 256*256 + 263*256 + 256*256 + 256)   SURVEY.md section 8d
@@ -146,7 +147,14 @@ def main():
         d = synthetic.make_rays(H, W, campos, camrot).to(dev)
         view_dirs.append(d.index_select(0, shard.pixels).contiguous())
         cams.append((campos, camrot))
-    n_local = shard.n_pad
+    n_local = shard.n_pad * world          # this rank's rays of one step: its tiles of `world` views
+    # the view sets a step can consist of: views (s*world + i) % 8, i < world -- concatenated once, resident in HBM
+    step_sets = {}
+    for s0 in range(len(azimuths)):
+        vs = tuple((s0 * world + i) % len(azimuths) for i in range(world))
+        if vs not in step_sets:
+            step_sets[vs] = (torch.cat([view_dirs[v] for v in vs]).contiguous(),
+                             [(cams[v][0], cams[v][1], 2.0, 6.0) for v in vs])
     outs = {
         "rgb": torch.empty((n_local, 3), dtype=torch.float32, device=dev),
         "depth": torch.empty((n_local,), dtype=torch.float32, device=dev),
@@ -155,35 +163,36 @@ def main():
         "counters_dev": torch.zeros(_lib.NUM_COUNTERS, dtype=torch.int64, device=dev),
     }
     local4 = torch.empty((n_local, 4), dtype=torch.float32, device=dev)
-    gathered = torch.empty((world * n_local, 4), dtype=torch.float32, device=dev)
-    image = torch.empty((H * W, 4), dtype=torch.float32, device=dev)
+    gathered = torch.empty((world, world, shard.n_pad, 4), dtype=torch.float32, device=dev)
+    images = torch.empty((world, H * W, 4), dtype=torch.float32, device=dev)
 
-    # capacity: size the workspace once from the heaviest view (untimed)
+    # capacity: size the workspace once from the heaviest step (untimed)
     cap = 0
-    for v in range(len(azimuths)):
-        o = rnd.render(view_dirs[v], cams[v][0], cams[v][1], 2.0, 6.0, out=outs)
+    for dirs_s, cams_s in step_sets.values():
+        o = rnd.render_views(dirs_s, cams_s, shard.n_pad, out=outs)
         cap = max(cap, o["counters"]["samples_selected"])
     cap = int(cap * 1.05) + 4096
-    rnd.render(view_dirs[0], cams[0][0], cams[0][1], 2.0, 6.0, cap_samples=cap, out=outs)
+    d0, c0 = next(iter(step_sets.values()))
+    rnd.render_views(d0, c0, shard.n_pad, cap_samples=cap, out=outs)
 
     lib = _lib.load()
-    n_calls_max = max(args.steps, 1) * world
+    n_calls_max = max(args.steps, 1)
     counters_all = torch.zeros((n_calls_max, _lib.NUM_COUNTERS), dtype=torch.int64, device=dev)
 
     def run_steps(renderer, first, count, counters=None):
-        """`count` steps; NOTHING in here waits for the device (stage times and counters are read afterwards)."""
+        """`count` steps; NOTHING in here waits for the device (stage times and counters are read afterwards).
+        One step = ONE render call over this rank's tiles of all `world` views + ONE all_gather."""
         call = 0
         for s in range(first, first + count):
-            for i in range(world):
-                v = (s * world + i) % len(azimuths)
-                if counters is not None:
-                    outs["counters_dev"] = counters[call]
-                renderer.render(view_dirs[v], cams[v][0], cams[v][1], 2.0, 6.0, cap_samples=cap, sync_counters=False,
-                                out=outs)
-                local4[:, :3].copy_(outs["rgb"])
-                local4[:, 3].copy_(outs["depth"])
-                gather_image(local4, shard, out=image, gathered=gathered)
-                call += 1
+            vs = tuple((s * world + i) % len(azimuths) for i in range(world))
+            dirs_s, cams_s = step_sets[vs]
+            if counters is not None:
+                outs["counters_dev"] = counters[call]
+            renderer.render_views(dirs_s, cams_s, shard.n_pad, cap_samples=cap, sync_counters=False, out=outs)
+            local4[:, :3].copy_(outs["rgb"])
+            local4[:, 3].copy_(outs["depth"])
+            gather_views(local4, shard, world, out=images, gathered=gathered)
+            call += 1
         return call
 
     def timed(renderer, steps, first):
@@ -266,7 +275,9 @@ def main():
                 "workload": f"{args.config}: chair-bbox synthetic cloud N={cfgd['N']}, {H}x{W} image, D=400, "
                             f"SR={SR}, K={K}, P={cfgd['P']}, jitter=0, {world} view(s)/step",
                 "rays_per_step": rays_per_step, "global_batch": rays_per_step, "mlp_mode": args.precision,
-                "parallelism": f"ray-tile shard x{world} (16x16 tiles round-robin) + all_gather per view",
+                "rays_per_rank_per_step": n_local,
+                "parallelism": f"ray-tile shard x{world} (16x16 tiles round-robin), one multi-camera render + one "
+                               f"all_gather per step",
             },
             "roofline": roofline(args.precision, acc_ms, acc_cnt, n_launch),
             "stages_ms_per_launch": {n: acc_ms[i] / n_launch for i, n in enumerate(_lib.STAGE_NAMES)},

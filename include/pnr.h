@@ -40,6 +40,7 @@ extern "C" {
 #define PNR_MAX_K 32             /* neighbours per sample; the reference breaks at K>8 (cu:14) */
 #define PNR_MAX_D 512            /* coarse samples per ray (z_depth_dim, default 400)   */
 #define PNR_POINT_ROW_FLOATS 44  /* packed point row: xyz conf | emb[32] | color dir pad */
+#define PNR_MAX_CAMS 16          /* cameras per pnr_render_views call                    */
 
 typedef enum {
     PNR_OK = 0,
@@ -157,6 +158,17 @@ int pnr_render(const pnr_scene_t *scene, const pnr_weights_t *weights, const flo
                const pnr_camera_t *cam, const float *d_tmid, const pnr_render_opts_t *opts,
                float *d_rgb, float *d_depth, float *d_acc, int8_t *d_ray_mask, int64_t *d_counters,
                void *d_workspace, size_t workspace_bytes, int64_t cap_samples, void *stream);
+
+/* Several ray bundles (cameras) in ONE call: ray r belongs to camera d_ray_cam[r] or, when d_ray_cam is NULL,
+ * to camera r / rays_per_cam (bundles concatenated back to back).  `cams` is a HOST array of n_cams cameras
+ * (<= PNR_MAX_CAMS), d_tmid holds n_cams tables of D coarse-sample parameters.  Lifts the reference's
+ * one-camera-per-bundle assumption (studio_utils.py:152) and lets a multi-view step pay the per-call overheads
+ * once.  Same outputs as pnr_render, in ray order. */
+int pnr_render_views(const pnr_scene_t *scene, const pnr_weights_t *weights, const float *d_dirs, int64_t R,
+                     const pnr_camera_t *cams, int32_t n_cams, const int32_t *d_ray_cam, int64_t rays_per_cam,
+                     const float *d_tmid, const pnr_render_opts_t *opts, float *d_rgb, float *d_depth, float *d_acc,
+                     int8_t *d_ray_mask, int64_t *d_counters, void *d_workspace, size_t workspace_bytes,
+                     int64_t cap_samples, void *stream);
 
 /* Debug/test taps into the last pnr_render workspace (device pointers, valid until the workspace is
  * reused): per selected sample s: loc+t float4, ray id, neighbour list [K], decoded (sigma,r,g,b). */

@@ -18,6 +18,7 @@ COUNTER_NAMES = ["rays_hit", "rays_kept", "samples_selected", "samples_valid", "
 POINT_ROW_FLOATS = 44
 MAX_K = 32
 MAX_D = 512
+MAX_CAMS = 16
 
 # every symbol include/pnr.h declares (tests check that the library exports all of them)
 EXPORTED_SYMBOLS = [
@@ -25,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "pnr_scene_create", "pnr_scene_destroy", "pnr_scene_build", "pnr_scene_info", "pnr_points_pack",
     "pnr_weights_create", "pnr_weights_destroy", "pnr_weights_pack",
     "pnr_query_workspace_bytes", "pnr_query_raypos",
-    "pnr_render_workspace_bytes", "pnr_render", "pnr_render_taps",
+    "pnr_render_workspace_bytes", "pnr_render", "pnr_render_views", "pnr_render_taps",
     "pnr_profile_enable", "pnr_profile_calls", "pnr_profile_read",
 ]
 NUM_STAGES = 5
@@ -88,6 +89,8 @@ def load() -> C.CDLL:
     lib.pnr_render_workspace_bytes.argtypes = [i64, i64, i32]
     lib.pnr_render.argtypes = [vp, vp, vp, i64, C.POINTER(CameraC), vp, C.POINTER(RenderOpts), vp, vp, vp, vp, vp,
                                vp, sz, i64, vp]
+    lib.pnr_render_views.argtypes = [vp, vp, vp, i64, C.POINTER(CameraC), i32, vp, i64, vp, C.POINTER(RenderOpts), vp, vp,
+                                     vp, vp, vp, vp, sz, i64, vp]
     lib.pnr_render_taps.argtypes = [vp, sz, i64, i64, i32, C.POINTER(RenderTaps)]
     lib.pnr_profile_enable.argtypes = [C.c_int]
     lib.pnr_profile_calls.restype = C.c_int64

@@ -84,6 +84,45 @@ struct Camera {
     float R[9];  // camrotc2w row-major
 };
 
+// The cameras of one render call live in a small device array; ray r belongs to camera ray_cam[r] or, when
+// ray_cam is null, to camera r / rays_per_cam (views concatenated back to back).  tmid holds one table of D
+// coarse-sample parameters per camera.
+struct CamRef {
+    const Camera *cams;
+    const int *ray_cam;
+    long long rays_per_cam;
+    const float *tmid;
+    int D;
+    int n_cams;
+};
+struct CamSet {
+    Camera c[PNR_MAX_CAMS];
+};
+__device__ __forceinline__ int cam_id(const CamRef &cr, long long r)
+{
+    if (cr.n_cams <= 1) return 0;
+    return cr.ray_cam ? cr.ray_cam[r] : (int)((unsigned)r / (unsigned)cr.rays_per_cam);  // R < 2^31
+}
+__device__ __forceinline__ Camera load_cam(const CamRef &cr, int cid)
+{
+    Camera c;
+    const float *p = reinterpret_cast<const float *>(cr.cams + cid);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) c.o[i] = p[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c.R[i] = p[3 + i];
+    return c;
+}
+// camera of a per-lane ray: rays are ordered by camera, so a wavefront almost always sees ONE camera and can
+// fetch it with wave-uniform (scalar) loads; only a wavefront straddling two bundles loads per lane
+__device__ __forceinline__ Camera load_cam_lanes(const CamRef &cr, int cid)
+{
+    const int cid0 = __builtin_amdgcn_readfirstlane(cid);
+    if (__all(cid == cid0)) return load_cam(cr, cid0);
+    return load_cam(cr, cid);
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // device-wide exclusive scan of int32 (n read from device memory when n_dev != nullptr)
 // ------------------------------------------------------------------------------------------------
@@ -156,6 +195,7 @@ struct RenderWs {
     float4 *smp_out;   // [cap]
     int *n_sel;        // device ints: [0]=S_sel (clamped to cap), [1]=S_valid, [2]=R
     unsigned long long *shards;  // statistics counters, SHARDS x 128-byte lines per counter (see shard_add)
+    Camera *cams;                // [PNR_MAX_CAMS] cameras of the call
     void *scan_temp;
     size_t total;
 };
@@ -178,14 +218,14 @@ __device__ __forceinline__ unsigned long long shard_sum(const unsigned long long
     return s;
 }
 
-int launch_select_expand(const GridView &g, const Camera &cam, const float *d_dirs, const float *d_raypos,
-                         int64_t R, int D, int SR, const float *d_tmid, int64_t cap, RenderWs &ws,
-                         int64_t *d_counters, hipStream_t stream);
+int launch_select_expand(const GridView &g, const CamRef &cr, const float *d_dirs, const float *d_raypos,
+                         int64_t R, int D, int SR, int64_t cap, RenderWs &ws, int64_t *d_counters,
+                         hipStream_t stream);
 int launch_knn(const GridView &g, int K, float radius_limit, RenderWs &ws, int64_t cap, int64_t *d_counters,
                hipStream_t stream);
-int launch_shade(const pnr_scene *scene, const pnr_weights *w, const Camera &cam, const float *d_dirs, int K,
+int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr, const float *d_dirs, int K,
                  int precision, RenderWs &ws, int64_t cap, hipStream_t stream, hipEvent_t ev_between);
-int launch_composite(const Camera &cam, const pnr_render_opts_t &opts, int64_t R, RenderWs &ws, float *d_rgb,
+int launch_composite(const CamRef &cr, const pnr_render_opts_t &opts, int64_t R, RenderWs &ws, float *d_rgb,
                      float *d_depth, float *d_acc, int8_t *d_ray_mask, int64_t *d_counters,
                      hipStream_t stream);
 

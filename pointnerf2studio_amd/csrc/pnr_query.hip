@@ -32,6 +32,7 @@ RenderWs carve_render_ws(void *base, int64_t R, int64_t cap, int K)
     };
     ws.n_sel = (int *)take(64 * sizeof(int));
     ws.shards = (unsigned long long *)take((size_t)SH_COUNT * SHARDS * SHARD_STRIDE * sizeof(unsigned long long));
+    ws.cams = (Camera *)take(sizeof(Camera) * PNR_MAX_CAMS);
     ws.ray_cnt = (int *)take((size_t)(R + 1) * sizeof(int));
     ws.ray_off = (int *)take((size_t)(R + 1) * sizeof(int));
     ws.ray_flag = (int *)take((size_t)(R + 1) * sizeof(int));
@@ -57,7 +58,7 @@ RenderWs carve_render_ws(void *base, int64_t R, int64_t cap, int K)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void sample_pos(const float *__restrict__ raypos, const float *__restrict__ dirs,
                                            const float *__restrict__ tmid, const Camera &cam, int64_t r, int D,
-                                           int j, float &px, float &py, float &pz, float &t)
+                                           int j, float &px, float &py, float &pz, float &t)  // tmid: this camera's table
 {
     if (raypos) {
         const float *p = raypos + ((int64_t)r * D + j) * 3;
@@ -75,8 +76,8 @@ __device__ __forceinline__ void sample_pos(const float *__restrict__ raypos, con
     }
 }
 
-__global__ void __launch_bounds__(TPB) k_select(GridView g, Camera cam, const float *__restrict__ dirs,
-                                                 const float *__restrict__ raypos, const float *__restrict__ tmid,
+__global__ void __launch_bounds__(TPB) k_select(GridView g, CamRef cr, const float *__restrict__ dirs,
+                                                 const float *__restrict__ raypos,
                                                  int64_t R, int D, int SR, int *__restrict__ ray_cnt,
                                                  unsigned long long *__restrict__ ray_bits,
                                                  unsigned long long *__restrict__ shards)
@@ -86,6 +87,13 @@ __global__ void __launch_bounds__(TPB) k_select(GridView g, Camera cam, const fl
     if (r >= R) return;
     int total = 0;
     const int nwords = (D + 63) >> 6;
+    Camera cam{};
+    const float *tmid = nullptr;
+    if (!raypos) {  // the ray's camera: wave-uniform
+        const int cid = cam_id(cr, r);
+        cam = load_cam(cr, cid);
+        tmid = cr.tmid + (size_t)cid * D;
+    }
     // Conservative ray / grid-box clip (generated positions only): a coarse sample outside the voxel grid can
     // never be occupied (cu:182-187), so whole 64-sample words whose parameter range misses the box -- grown by
     // two voxels against rounding -- are skipped without probing.  Every probed sample still takes the exact test.
@@ -150,8 +158,8 @@ __global__ void __launch_bounds__(TPB) k_select(GridView g, Camera cam, const fl
 // ------------------------------------------------------------------------------------------------
 // k_expand: one wavefront per ray; hit j with rank < SR becomes sample off[r] + rank.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(TPB) k_expand(Camera cam, const float *__restrict__ dirs,
-                                                 const float *__restrict__ raypos, const float *__restrict__ tmid,
+__global__ void __launch_bounds__(TPB) k_expand(CamRef cr, const float *__restrict__ dirs,
+                                                 const float *__restrict__ raypos,
                                                  int64_t R, int D, int SR, const int *__restrict__ ray_off,
                                                  const unsigned long long *__restrict__ ray_bits, int64_t cap,
                                                  float4 *__restrict__ smp_loc, int *__restrict__ smp_ray,
@@ -167,6 +175,13 @@ __global__ void __launch_bounds__(TPB) k_expand(Camera cam, const float *__restr
         if (total > cap) counters[PNR_CNT_OVERFLOW] = 1;
     }
     if (r >= R) return;
+    Camera cam{};
+    const float *tmid = nullptr;
+    if (!raypos) {
+        const int cid = cam_id(cr, r);
+        cam = load_cam(cr, cid);
+        tmid = cr.tmid + (size_t)cid * D;
+    }
     const int off = ray_off[r];
     int base = 0;
     const int nwords = (D + 63) >> 6;
@@ -339,9 +354,9 @@ static inline unsigned nblk(int64_t n, int per = TPB) { return (unsigned)std::ma
 // accumulators (unsigned long long) live behind n_sel: [8..13] as 64-bit words
 static inline unsigned long long *acc_ptr(RenderWs &ws) { return ws.shards; }
 
-int launch_select_expand(const GridView &g, const Camera &cam, const float *d_dirs, const float *d_raypos,
-                         int64_t R, int D, int SR, const float *d_tmid, int64_t cap, RenderWs &ws,
-                         int64_t *d_counters, hipStream_t stream)
+int launch_select_expand(const GridView &g, const CamRef &cr, const float *d_dirs, const float *d_raypos,
+                         int64_t R, int D, int SR, int64_t cap, RenderWs &ws, int64_t *d_counters,
+                         hipStream_t stream)
 {
     PNR_HIP_CHECK(hipMemsetAsync(ws.n_sel, 0, 64 * sizeof(int), stream));
     PNR_HIP_CHECK(hipMemsetAsync(ws.shards, 0, (size_t)SH_COUNT * SHARDS * SHARD_STRIDE * sizeof(unsigned long long),
@@ -349,12 +364,12 @@ int launch_select_expand(const GridView &g, const Camera &cam, const float *d_di
     PNR_HIP_CHECK(hipMemsetAsync(d_counters, 0, PNR_NUM_COUNTERS * sizeof(int64_t), stream));
     PNR_HIP_CHECK(hipMemsetAsync(ws.ray_flag, 0, (size_t)(R + 1) * sizeof(int), stream));
     unsigned long long *acc = acc_ptr(ws);
-    hipLaunchKernelGGL(k_select, dim3(nblk(R, TPB / 64)), dim3(TPB), 0, stream, g, cam, d_dirs, d_raypos, d_tmid, R,
-                       D, SR, ws.ray_cnt, ws.ray_bits, acc);
+    hipLaunchKernelGGL(k_select, dim3(nblk(R, TPB / 64)), dim3(TPB), 0, stream, g, cr, d_dirs, d_raypos, R, D, SR,
+                       ws.ray_cnt, ws.ray_bits, acc);
     int rc = scan_exclusive_i32(ws.ray_cnt, ws.ray_off, R, nullptr, nullptr, ws.scan_temp, stream);
     if (rc != PNR_OK) return rc;
-    hipLaunchKernelGGL(k_expand, dim3(nblk(R, TPB / 64)), dim3(TPB), 0, stream, cam, d_dirs, d_raypos, d_tmid, R, D,
-                       SR, ws.ray_off, ws.ray_bits, cap, ws.smp_loc, ws.smp_ray, ws.n_sel, d_counters);
+    hipLaunchKernelGGL(k_expand, dim3(nblk(R, TPB / 64)), dim3(TPB), 0, stream, cr, d_dirs, d_raypos, R, D, SR,
+                       ws.ray_off, ws.ray_bits, cap, ws.smp_loc, ws.smp_ray, ws.n_sel, d_counters);
     PNR_HIP_CHECK(hipGetLastError());
     return PNR_OK;
 }
@@ -419,8 +434,9 @@ extern "C" int pnr_query_raypos(const pnr_scene_t *scene, const float *d_raypos,
     }
     const int64_t cap = R * (int64_t)SR;
     RenderWs ws = carve_render_ws(d_workspace, R, cap, K);
-    Camera cam{};
-    int rc = launch_select_expand(scene->grid, cam, nullptr, d_raypos, R, D, SR, nullptr, cap, ws, d_counters, stream);
+    CamRef cr{};  // explicit positions: no camera involved
+    cr.D = D;
+    int rc = launch_select_expand(scene->grid, cr, nullptr, d_raypos, R, D, SR, cap, ws, d_counters, stream);
     if (rc != PNR_OK) return rc;
     rc = launch_knn(scene->grid, K, radius_limit, ws, cap, d_counters, stream);
     if (rc != PNR_OK) return rc;

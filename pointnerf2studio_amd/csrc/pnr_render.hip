@@ -29,7 +29,13 @@ static hipEvent_t g_evs[PNR_PROFILE_SLOTS][PNR_NUM_STAGES + 1] = {{nullptr}};
 static long long g_prof_calls = 0;
 
 // one thread per ray: its samples are contiguous in the compact list, at most SR of them.
-__global__ void __launch_bounds__(TPB) k_composite(Camera cam, pnr_render_opts_t opts, int64_t R,
+__global__ void k_set_cams(CamSet set, int n, Camera *__restrict__ dst)
+{
+    const int i = threadIdx.x;
+    if (i < n) dst[i] = set.c[i];
+}
+
+__global__ void __launch_bounds__(TPB) k_composite(CamRef cr, pnr_render_opts_t opts, int64_t R,
                                                     const int *__restrict__ ray_cnt, const int *__restrict__ ray_off,
                                                     const int *__restrict__ ray_flag,
                                                     const float4 *__restrict__ smp_loc,
@@ -45,8 +51,9 @@ __global__ void __launch_bounds__(TPB) k_composite(Camera cam, pnr_render_opts_t
     int cnt = ray_cnt[r];
     if ((int64_t)off + cnt > S) cnt = max(0, S - off);  // capacity overflow: drop what did not fit
     const bool keep = ray_flag[r] != 0 && cnt > 0;
-    float cr = 0.f, cg = 0.f, cb = 0.f, acc = 0.f, dsum = 0.f;
+    float cr_ = 0.f, cg = 0.f, cb = 0.f, acc = 0.f, dsum = 0.f;
     if (keep) {
+        const Camera cam = load_cam_lanes(cr, cam_id(cr, r));
         const float vs = opts.vsize_z;
         const float two_vs = 2.0f * vs;
         // camera-space z of a world point: sum_j (p - o)[j] * R[j][2]   (studio_utils.py:137-144)
@@ -83,14 +90,14 @@ __global__ void __launch_bounds__(TPB) k_composite(Camera cam, pnr_render_opts_t
             const float opacity = 1.0f - expf(-sigma * delta);
             const float w = opacity * T;
             T = T * (1.0f - opacity + 1e-10f);
-            cr += w * o.y;
+            cr_ += w * o.y;
             cg += w * o.z;
             cb += w * o.w;
             acc += w;
             dsum += w * t_i;
         }
     }
-    float o0 = cr + opts.bg[0] * (1.0f - acc);
+    float o0 = cr_ + opts.bg[0] * (1.0f - acc);
     float o1 = cg + opts.bg[1] * (1.0f - acc);
     float o2 = cb + opts.bg[2] * (1.0f - acc);
     if (!keep) {
@@ -116,11 +123,11 @@ __global__ void k_publish_kept(const unsigned long long *__restrict__ shards, in
     if (threadIdx.x == 0 && blockIdx.x == 0) counters[PNR_CNT_RAYS_KEPT] = (int64_t)shard_sum(shards, SH_KEPT);
 }
 
-int launch_composite(const Camera &cam, const pnr_render_opts_t &opts, int64_t R, RenderWs &ws, float *d_rgb,
+int launch_composite(const CamRef &cr, const pnr_render_opts_t &opts, int64_t R, RenderWs &ws, float *d_rgb,
                      float *d_depth, float *d_acc, int8_t *d_ray_mask, int64_t *d_counters, hipStream_t stream)
 {
     unsigned long long *n_kept = ws.shards;
-    hipLaunchKernelGGL(k_composite, dim3((unsigned)((R + TPB - 1) / TPB)), dim3(TPB), 0, stream, cam, opts, R,
+    hipLaunchKernelGGL(k_composite, dim3((unsigned)((R + TPB - 1) / TPB)), dim3(TPB), 0, stream, cr, opts, R,
                        ws.ray_cnt, ws.ray_off, ws.ray_flag, ws.smp_loc, ws.smp_out, ws.n_sel, d_rgb, d_depth, d_acc,
                        d_ray_mask, n_kept);
     hipLaunchKernelGGL(k_publish_kept, dim3(1), dim3(64), 0, stream, n_kept, d_counters);
@@ -142,61 +149,95 @@ extern "C" size_t pnr_render_workspace_bytes(int64_t R, int64_t cap_samples, int
     return carve_render_ws(nullptr, R, cap_samples, K).total;
 }
 
-extern "C" int pnr_render(const pnr_scene_t *scene, const pnr_weights_t *weights, const float *d_dirs, int64_t R,
-                          const pnr_camera_t *cam_, const float *d_tmid, const pnr_render_opts_t *opts,
-                          float *d_rgb, float *d_depth, float *d_acc, int8_t *d_ray_mask, int64_t *d_counters,
-                          void *d_workspace, size_t workspace_bytes, int64_t cap_samples, void *stream_)
+static int render_views(const pnr_scene_t *scene, const pnr_weights_t *weights, const float *d_dirs, int64_t R,
+                        const pnr_camera_t *cams, int32_t n_cams, const int32_t *d_ray_cam, int64_t rays_per_cam,
+                        const float *d_tmid, const pnr_render_opts_t *opts, float *d_rgb, float *d_depth, float *d_acc,
+                        int8_t *d_ray_mask, int64_t *d_counters, void *d_workspace, size_t workspace_bytes,
+                        int64_t cap_samples, hipStream_t stream, const char *who)
 {
-    hipStream_t stream = (hipStream_t)stream_;
-    PNR_REQUIRE(scene && weights && d_dirs && cam_ && d_tmid && opts && d_rgb && d_ray_mask && d_counters &&
+    PNR_REQUIRE(scene && weights && d_dirs && cams && d_tmid && opts && d_rgb && d_ray_mask && d_counters &&
                     d_workspace,
-                "pnr_render: null argument");
+                "%s: null argument", who);
     if (!scene->built || !scene->packed) {
-        set_error("pnr_render: scene not built / points not packed");
+        set_error("%s: scene not built / points not packed", who);
         return PNR_ERR_STATE;
     }
     if (!weights->packed) {
-        set_error("pnr_render: weights not packed");
+        set_error("%s: weights not packed", who);
         return PNR_ERR_STATE;
     }
-    PNR_REQUIRE(R >= 1 && R < (int64_t)0x7FFFFFF0, "pnr_render: R=%lld out of range", (long long)R);
-    PNR_REQUIRE(opts->D >= 1 && opts->D <= PNR_MAX_D, "pnr_render: D=%d not in [1,%d]", opts->D, PNR_MAX_D);
-    PNR_REQUIRE(opts->K >= 1 && opts->K <= PNR_MAX_K, "pnr_render: K=%d not in [1,%d]", opts->K, PNR_MAX_K);
-    PNR_REQUIRE(opts->SR >= 1, "pnr_render: SR=%d", opts->SR);
+    PNR_REQUIRE(R >= 1 && R < (int64_t)0x7FFFFFF0, "%s: R=%lld out of range", who, (long long)R);
+    PNR_REQUIRE(n_cams >= 1 && n_cams <= PNR_MAX_CAMS, "%s: n_cams=%d not in [1,%d]", who, n_cams, PNR_MAX_CAMS);
+    PNR_REQUIRE(d_ray_cam != nullptr || (rays_per_cam >= 1 && rays_per_cam * n_cams >= R),
+                "%s: rays_per_cam=%lld does not cover R=%lld rays with %d cameras", who, (long long)rays_per_cam,
+                (long long)R, n_cams);
+    PNR_REQUIRE(opts->D >= 1 && opts->D <= PNR_MAX_D, "%s: D=%d not in [1,%d]", who, opts->D, PNR_MAX_D);
+    PNR_REQUIRE(opts->K >= 1 && opts->K <= PNR_MAX_K, "%s: K=%d not in [1,%d]", who, opts->K, PNR_MAX_K);
+    PNR_REQUIRE(opts->SR >= 1, "%s: SR=%d", who, opts->SR);
     PNR_REQUIRE(opts->precision == PNR_PRECISION_FP32 || opts->precision == PNR_PRECISION_BF16X3,
-                "pnr_render: unknown precision %d", opts->precision);
+                "%s: unknown precision %d", who, opts->precision);
     PNR_REQUIRE(cap_samples >= 1 && cap_samples < (int64_t)0x7FFFFFF0 / std::max(opts->K, 1),
-                "pnr_render: cap_samples=%lld out of range", (long long)cap_samples);
+                "%s: cap_samples=%lld out of range", who, (long long)cap_samples);
     const size_t need = pnr_render_workspace_bytes(R, cap_samples, opts->K);
     if (workspace_bytes < need) {
-        set_error("pnr_render: workspace of %zu bytes < %zu required", workspace_bytes, need);
+        set_error("%s: workspace of %zu bytes < %zu required", who, workspace_bytes, need);
         return PNR_ERR_WORKSPACE;
     }
     RenderWs ws = carve_render_ws(d_workspace, R, cap_samples, opts->K);
-    Camera cam{};
-    for (int i = 0; i < 3; ++i) cam.o[i] = cam_->campos[i];
-    for (int i = 0; i < 9; ++i) cam.R[i] = cam_->camrotc2w[i];
+    CamSet set{};
+    for (int c = 0; c < n_cams; ++c) {
+        for (int i = 0; i < 3; ++i) set.c[c].o[i] = cams[c].campos[i];
+        for (int i = 0; i < 9; ++i) set.c[c].R[i] = cams[c].camrotc2w[i];
+    }
+    hipLaunchKernelGGL(k_set_cams, dim3(1), dim3(64), 0, stream, set, n_cams, ws.cams);
+    CamRef cr{};
+    cr.cams = ws.cams;
+    cr.ray_cam = d_ray_cam;
+    cr.rays_per_cam = d_ray_cam ? 1 : rays_per_cam;
+    cr.tmid = d_tmid;
+    cr.D = opts->D;
+    cr.n_cams = n_cams;
     const bool prof = g_prof;
     hipEvent_t *g_ev = g_evs[g_prof_calls % PNR_PROFILE_SLOTS];
     if (prof) PNR_HIP_CHECK(hipEventRecord(g_ev[0], stream));
-    int rc = launch_select_expand(scene->grid, cam, d_dirs, nullptr, R, opts->D, opts->SR, d_tmid, cap_samples, ws,
-                                  d_counters, stream);
+    int rc = launch_select_expand(scene->grid, cr, d_dirs, nullptr, R, opts->D, opts->SR, cap_samples, ws, d_counters,
+                                  stream);
     if (rc != PNR_OK) return rc;
     if (prof) PNR_HIP_CHECK(hipEventRecord(g_ev[1], stream));
     rc = launch_knn(scene->grid, opts->K, opts->radius_limit, ws, cap_samples, d_counters, stream);
     if (rc != PNR_OK) return rc;
     if (prof) PNR_HIP_CHECK(hipEventRecord(g_ev[2], stream));
-    rc = launch_shade(scene, weights, cam, d_dirs, opts->K, opts->precision, ws, cap_samples, stream,
+    rc = launch_shade(scene, weights, cr, d_dirs, opts->K, opts->precision, ws, cap_samples, stream,
                       prof ? g_ev[3] : nullptr);
     if (rc != PNR_OK) return rc;
     if (prof) PNR_HIP_CHECK(hipEventRecord(g_ev[4], stream));
-    rc = launch_composite(cam, *opts, R, ws, d_rgb, d_depth, d_acc, d_ray_mask, d_counters, stream);
+    rc = launch_composite(cr, *opts, R, ws, d_rgb, d_depth, d_acc, d_ray_mask, d_counters, stream);
     if (rc != PNR_OK) return rc;
     if (prof) {
         PNR_HIP_CHECK(hipEventRecord(g_ev[5], stream));
         ++g_prof_calls;
     }
     return PNR_OK;
+}
+
+extern "C" int pnr_render(const pnr_scene_t *scene, const pnr_weights_t *weights, const float *d_dirs, int64_t R,
+                          const pnr_camera_t *cam, const float *d_tmid, const pnr_render_opts_t *opts, float *d_rgb,
+                          float *d_depth, float *d_acc, int8_t *d_ray_mask, int64_t *d_counters, void *d_workspace,
+                          size_t workspace_bytes, int64_t cap_samples, void *stream)
+{
+    return render_views(scene, weights, d_dirs, R, cam, 1, nullptr, R, d_tmid, opts, d_rgb, d_depth, d_acc, d_ray_mask,
+                        d_counters, d_workspace, workspace_bytes, cap_samples, (hipStream_t)stream, "pnr_render");
+}
+
+extern "C" int pnr_render_views(const pnr_scene_t *scene, const pnr_weights_t *weights, const float *d_dirs, int64_t R,
+                                const pnr_camera_t *cams, int32_t n_cams, const int32_t *d_ray_cam,
+                                int64_t rays_per_cam, const float *d_tmid, const pnr_render_opts_t *opts, float *d_rgb,
+                                float *d_depth, float *d_acc, int8_t *d_ray_mask, int64_t *d_counters,
+                                void *d_workspace, size_t workspace_bytes, int64_t cap_samples, void *stream)
+{
+    return render_views(scene, weights, d_dirs, R, cams, n_cams, d_ray_cam, rays_per_cam, d_tmid, opts, d_rgb, d_depth,
+                        d_acc, d_ray_mask, d_counters, d_workspace, workspace_bytes, cap_samples, (hipStream_t)stream,
+                        "pnr_render_views");
 }
 
 extern "C" int pnr_profile_enable(int enable)

@@ -71,7 +71,7 @@ struct ShadeParams {
     size_t w16_off[9];  // float offsets: bf16x3-packed layers (0 for the heads)
     size_t b_off[9];
     float Rw2c[9];
-    Camera cam;
+    CamRef cr;
     const float *dirs;
     const float4 *smp_loc;
     const int *smp_ray;
@@ -193,6 +193,7 @@ __device__ __forceinline__ void load_rows(const ShadeParams &P, int tile, int la
     const int ray = P.smp_ray[s];
     const float dirx = P.dirs[3 * (int64_t)ray], diry = P.dirs[3 * (int64_t)ray + 1],
                 dirz = P.dirs[3 * (int64_t)ray + 2];
+    const Camera cam = load_cam_lanes(P.cr, cam_id(P.cr, ray));
 
     // dists + inverse-distance weight (studio_model.py:270-286,467-475)
     const float dwx = a0.x - loc.x, dwy = a0.y - loc.y, dwz = a0.z - loc.z;
@@ -206,8 +207,8 @@ __device__ __forceinline__ void load_rows(const ShadeParams &P, int tile, int la
         rot_rows(P.Rw2c, dwx, dwy, dwz, dd[0], dd[1], dd[2]);  // dists[:3] @ Rw2c^T   (studio_model.py:313)
     } else {
         float pcx, pcy, pcz, scx, scy, scz;
-        to_cam(P.cam, a0.x, a0.y, a0.z, pcx, pcy, pcz);
-        to_cam(P.cam, loc.x, loc.y, loc.z, scx, scy, scz);
+        to_cam(cam, a0.x, a0.y, a0.z, pcx, pcy, pcz);
+        to_cam(cam, loc.x, loc.y, loc.z, scx, scy, scz);
         const float ppx = pcx / pcz, ppy = pcy / pcz, spx = scx / scz, spy = scy / scz;
         dd[0] = ppx * pcz - spx * scz;
         dd[1] = ppy * pcz - spy * scz;
@@ -1019,7 +1020,7 @@ __global__ void k_copy(const float *__restrict__ src, int n, float *__restrict__
     if (i < n) dst[i] = src[i];
 }
 
-int launch_shade(const pnr_scene *scene, const pnr_weights *w, const Camera &cam, const float *d_dirs, int K,
+int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr, const float *d_dirs, int K,
                  int precision, RenderWs &ws, int64_t cap, hipStream_t stream, hipEvent_t ev_between)
 {
     ShadeParams P{};
@@ -1032,7 +1033,7 @@ int launch_shade(const pnr_scene *scene, const pnr_weights *w, const Camera &cam
         P.b_off[i] = w->b_off[i];
         P.Rw2c[i] = w->Rw2c[i];
     }
-    P.cam = cam;
+    P.cr = cr;
     P.dirs = d_dirs;
     P.smp_loc = ws.smp_loc;
     P.smp_ray = ws.smp_ray;

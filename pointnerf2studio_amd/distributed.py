@@ -63,6 +63,27 @@ def make_shard(H: int, W: int, world: int, rank: int, tile: int = 16) -> TileSha
                      scatter[slot_index].contiguous())
 
 
+def gather_views(local: torch.Tensor, shard: TileShard, n_views: int, out: Optional[torch.Tensor] = None,
+                 gathered: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Several views rendered in one call: local [n_views * n_pad, C] (view-major, each view in shard.pixels order)
+    -> images [n_views, H*W, C] on every rank with ONE all_gather_into_tensor + one index_copy."""
+    C = local.shape[1]
+    w, n = shard.world, shard.n_pad
+    if gathered is None:
+        gathered = torch.empty((w, n_views, n, C), dtype=local.dtype, device=local.device)
+    if w > 1:
+        dist.all_gather_into_tensor(gathered.view(-1, C), local.contiguous())
+    else:
+        gathered.view(-1, C).copy_(local)
+    if out is None:
+        out = torch.empty((n_views, shard.H * shard.W, C), dtype=local.dtype, device=local.device)
+    # [world, V, n_pad, C] -> [V, world * n_pad, C]: the per-view layout gather_image produces
+    per_view = gathered.permute(1, 0, 2, 3).reshape(n_views, w * n, C)
+    src = per_view if shard.slot_index.numel() == w * n else per_view.index_select(1, shard.slot_index)
+    out.index_copy_(1, shard.pixel_index, src)
+    return out
+
+
 def gather_image(local: torch.Tensor, shard: TileShard, out: Optional[torch.Tensor] = None,
                  gathered: Optional[torch.Tensor] = None) -> torch.Tensor:
     """local [n_pad, C] (this rank's rendered pixels in shard.pixels order) -> full image [H*W, C] on EVERY

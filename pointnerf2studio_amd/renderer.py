@@ -228,6 +228,7 @@ class RendererHIP:
         self._ws = None
         self._ws_key = None
         self._tmid = {}
+        self._cam_cache = {}
         self.cap_samples = 0
 
     def _workspace(self, R: int, cap: int, dev):
@@ -248,18 +249,39 @@ class RendererHIP:
 
     def render(self, directions: torch.Tensor, campos, camrotc2w, near: float, far: float,
                cap_samples: Optional[int] = None, sync_counters: bool = True, out: Optional[dict] = None):
-        """directions [R,3] (GPU), campos [3], camrotc2w [3,3] (host or device).  Returns dict with
-        rgb [R,3], depth [R], acc [R], ray_mask [R] int8, counters (dict if sync_counters else tensor)."""
+        """One ray bundle of ONE camera (the reference's contract).  directions [R,3] (GPU), campos [3],
+        camrotc2w [3,3] (host or device).  Returns dict with rgb [R,3], depth [R], acc [R], ray_mask [R] int8,
+        counters (dict if sync_counters else only `counters_dev`)."""
+        return self.render_views(directions, [(campos, camrotc2w, near, far)], directions.reshape(-1, 3).shape[0],
+                                 cap_samples=cap_samples, sync_counters=sync_counters, out=out)
+
+    def render_views(self, directions: torch.Tensor, cams, rays_per_cam: int, ray_cam: Optional[torch.Tensor] = None,
+                     cap_samples: Optional[int] = None, sync_counters: bool = True, out: Optional[dict] = None):
+        """Several cameras in one call (pnr_render_views).  `cams` = [(campos, camrotc2w, near, far), ...]; ray r
+        belongs to camera ray_cam[r] (int32 GPU tensor) or, without it, to camera r // rays_per_cam."""
         dev = directions.device
         if not directions.is_cuda:
             raise RuntimeError("RendererHIP.render: directions must be a GPU tensor (no CPU fallback)")
         d = _f32c(directions.reshape(-1, 3), dev)
         R = d.shape[0]
-        cam = _lib.CameraC()
-        cam.campos[:] = [float(v) for v in torch.as_tensor(campos).reshape(3).tolist()]
-        cam.camrotc2w[:] = [float(v) for v in torch.as_tensor(camrotc2w).reshape(9).tolist()]
-        cam.near_plane, cam.far_plane = float(near), float(far)
-        tm = self.tmid(near, far, dev)
+        n = len(cams)
+        if not 1 <= n <= _lib.MAX_CAMS:
+            raise ValueError(f"1..{_lib.MAX_CAMS} cameras per call, got {n}")
+        key = tuple((tuple(torch.as_tensor(c[0]).reshape(3).tolist()), tuple(torch.as_tensor(c[1]).reshape(9).tolist()),
+                     float(c[2]), float(c[3])) for c in cams)
+        cached = self._cam_cache.get(key)
+        if cached is None:
+            arr = (_lib.CameraC * n)()
+            for i, (pos, rot, near, far) in enumerate(key):
+                arr[i].campos[:] = pos
+                arr[i].camrotc2w[:] = rot
+                arr[i].near_plane, arr[i].far_plane = near, far
+            tm = torch.stack([self.tmid(c[2], c[3], dev) for c in key]).contiguous()
+            if len(self._cam_cache) > 64:
+                self._cam_cache.clear()
+            cached = self._cam_cache[key] = (arr, tm)
+        arr, tm = cached
+        rc = None if ray_cam is None else ray_cam.to(device=dev, dtype=torch.int32).contiguous()
         cap = int(cap_samples or self.cap_samples or max(4096, min(R * self.opts.SR, R * 16)))
         if out is None:
             out = {
@@ -272,10 +294,10 @@ class RendererHIP:
         while True:
             ws = self._workspace(R, cap, dev)
             with torch.cuda.device(dev):
-                _lib.check(self.lib.pnr_render(
-                    self.scene.handle, self.weights.handle, _ptr(d), R, C.byref(cam), _ptr(tm), C.byref(self.opts),
-                    _ptr(out["rgb"]), _ptr(out["depth"]), _ptr(out["acc"]), _ptr(out["ray_mask"]),
-                    _ptr(out["counters_dev"]), _ptr(ws), ws.numel(), cap, _stream_ptr(dev)), "pnr_render")
+                _lib.check(self.lib.pnr_render_views(
+                    self.scene.handle, self.weights.handle, _ptr(d), R, arr, n, _ptr(rc), int(rays_per_cam), _ptr(tm),
+                    C.byref(self.opts), _ptr(out["rgb"]), _ptr(out["depth"]), _ptr(out["acc"]), _ptr(out["ray_mask"]),
+                    _ptr(out["counters_dev"]), _ptr(ws), ws.numel(), cap, _stream_ptr(dev)), "pnr_render_views")
             if not sync_counters:
                 return out
             cnt = out["counters_dev"].cpu().tolist()

@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from pointnerf2studio_amd.distributed import gather_image, make_shard
+from pointnerf2studio_amd.distributed import gather_image, gather_views, make_shard
 
 
 def _free_port():
@@ -33,6 +33,11 @@ def _worker(rank, world, port, H, W, q):
         img = gather_image(local, shard)
         expect = _fake_render(torch.arange(H * W))
         ok = torch.equal(img, expect)
+        # bench.py's step: `world` views rendered in one call, one all_gather for all of them
+        V = world
+        local_v = torch.cat([_fake_render(shard.pixels) + 1000.0 * v for v in range(V)])
+        imgs = gather_views(local_v, shard, V)
+        ok = ok and all(torch.equal(imgs[v], expect + 1000.0 * v) for v in range(V))
         # bench.py's timing reduction: max over ranks
         t = torch.tensor([1.0 + rank], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -174,3 +174,37 @@ def test_render_full_size_properties(gpu_device):
     acc = a["acc"] if "acc" in a else None
     assert a["counters"]["rays_kept"] > 10000
     assert float(b["acc"].min()) >= 0.0 and float(b["acc"].max()) <= 1.0 + 1e-5
+
+
+def test_render_views_equals_per_camera_renders(oracle, gpu_device):
+    """pnr_render_views (several cameras in one call; the reference allows one per bundle, studio_utils.py:152):
+    pixels are bitwise identical to per-camera pnr_render calls, with contiguous bundles and with an explicit
+    per-ray camera index in shuffled order."""
+    pts = small_scene(80000)
+    cfg = oracle_cfg(oracle)
+    w = synthetic.make_weights(0, sigma_scale=300.0, bias_scale=0.1)
+    scene, wh, hyp, info = build_hip(pts, cfg, gpu_device, weights=w)
+    for precision in ("fp32", "bf16x3"):
+        rnd = RendererHIP(scene, wh, precision=precision)
+        cams, dirs, singles = [], [], []
+        for az in (15.0, 140.0, 260.0):
+            campos, camrot, d = camera_rays(24, 24, az=az)
+            cams.append((campos, camrot, 2.0, 6.0))
+            dirs.append(d.to(gpu_device))
+            o = rnd.render(dirs[-1], campos, camrot, 2.0, 6.0)
+            singles.append((o["rgb"].clone(), o["depth"].clone(), o["ray_mask"].clone()))
+        n = dirs[0].shape[0]
+        out = rnd.render_views(torch.cat(dirs), cams, n)
+        for v in range(3):
+            assert torch.equal(out["rgb"][v * n:(v + 1) * n], singles[v][0])
+            assert torch.equal(out["depth"][v * n:(v + 1) * n], singles[v][1])
+            assert torch.equal(out["ray_mask"][v * n:(v + 1) * n], singles[v][2])
+        # shuffled rays with an explicit camera index
+        g = torch.Generator().manual_seed(0)
+        perm = torch.randperm(3 * n, generator=g).to(gpu_device)
+        ray_cam = (perm // n).to(torch.int32)
+        out2 = rnd.render_views(torch.cat(dirs)[perm], cams, n, ray_cam=ray_cam)
+        assert torch.equal(out2["rgb"], out["rgb"][perm]) and torch.equal(out2["ray_mask"], out["ray_mask"][perm])
+    # and one of the views against the oracle
+    ref = oracle.render(pts, w, cfg, cams[1][0][None].expand(n, 3), dirs[1].cpu(), 2.0, 6.0, cams[1][1])
+    assert (out["rgb"][n:2 * n].cpu() - ref["coarse_raycolor"]).abs().max().item() <= RGB_TOL
