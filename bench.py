@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--points", type=int, default=None, help="override the number of points")
     ap.add_argument("--cpu-rays-side", type=int, default=64, help="side of the CPU-baseline window (0 = skip)")
     ap.add_argument("--sigma-scale", type=float, default=300.0)
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="diagnostic, single process: shard as rank --emulate-rank of this many ranks, no collectives")
+    ap.add_argument("--emulate-rank", type=int, default=0)
     ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3"],
                     help="MLP arithmetic: exact fp32 MFMA, or 3 bf16 MFMAs per fp32 product (hi/lo split)")
     args = ap.parse_args()
@@ -115,6 +118,9 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
+    emulate = args.emulate_world > 1 and world == 1
+    if emulate:   # per-rank work of an N-rank run, without the collectives (local copy instead of all_gather)
+        world, rank = args.emulate_world, args.emulate_rank
 
     cfgd = dict(synthetic.SCENE_CONFIGS[args.config])
     if args.points:
@@ -191,7 +197,10 @@ def main():
             renderer.render_views(dirs_s, cams_s, shard.n_pad, cap_samples=cap, sync_counters=False, out=outs)
             local4[:, :3].copy_(outs["rgb"])
             local4[:, 3].copy_(outs["depth"])
-            gather_views(local4, shard, world, out=images, gathered=gathered)
+            if emulate:
+                gathered[0].view(-1, 4).copy_(local4)
+            else:
+                gather_views(local4, shard, world, out=images, gathered=gathered)
             call += 1
         return call
 
@@ -199,17 +208,17 @@ def main():
         """barrier + synchronize, `steps` steps, barrier + synchronize; max over ranks; per-stage device times of
         every launch of the region from the HIP events pnr_render recorded on its stream."""
         _lib.check(lib.pnr_profile_enable(1), "pnr_profile_enable")
-        if world > 1:
+        if world > 1 and not emulate:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         n = run_steps(renderer, first, steps, counters_all)
-        if world > 1:
+        if world > 1 and not emulate:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        if world > 1:
+        if world > 1 and not emulate:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ms = (C.c_float * _lib.NUM_STAGES)()
         acc = [0.0] * _lib.NUM_STAGES
@@ -253,7 +262,7 @@ def main():
 
     # the other arithmetic mode, for the record (same workload, 2 steps, not part of `value`)
     alt = None
-    if world == 1:
+    if world == 1 and not emulate:
         alt_mode = "fp32" if args.precision == "bf16x3" else "bf16x3"
         rnd_alt = RendererHIP(scene, wh, SR=SR, K=K, D=400, radius_limit=4 * max(VSIZE[0], VSIZE[1]),
                               vsize_z=VSIZE[2], precision=alt_mode)
@@ -263,7 +272,7 @@ def main():
         alt = {"mode": alt_mode, "value": rays_per_step * 2 / a_el, "unit": "rays/s", "ms_per_step": a_el / 2 * 1e3,
                "roofline": roofline(alt_mode, a_ms, a_cnt, a_n)}
 
-    if rank == 0:
+    if rank == 0 or emulate:
         samples = acc_cnt[3]
         result = {
             "metric": "rays_per_sec", "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
@@ -288,7 +297,7 @@ def main():
         }
         if alt is not None:
             result["other_mode"] = alt
-        if world == 1 and args.cpu_rays_side > 0:
+        if world == 1 and not emulate and args.cpu_rays_side > 0:
             cb, ref, dirs, campos, camrot = cpu_baseline(points, weights, cfgd, args.cpu_rays_side, azimuths[0])
             # parity on the very same rays: HIP render vs the oracle that was just timed
             out = RendererHIP(scene, wh, SR=SR, K=K, D=400, radius_limit=4 * max(VSIZE[0], VSIZE[1]),
@@ -301,7 +310,7 @@ def main():
                                                              + 1e-20))}
             result["speedup_vs_cpu_baseline"] = value / cb["value"]
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if world > 1 and not emulate:
         dist.destroy_process_group()
 
 
