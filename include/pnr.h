@@ -85,6 +85,9 @@ typedef struct {
     int32_t eval_clamp;    /* 1: clamp rgb to [0,1] (nerfstudio RGBRenderer outside training) */
     float bg[3];           /* background colour (white in the reference)                   */
     int32_t precision;     /* PNR_PRECISION_FP32 (exact fp32 MFMA) or PNR_PRECISION_BF16X3 */
+    float jitter;          /* coarse-sample jitter as a fraction of the step (the reference hard-codes 0.3,
+                              studio_utils.py:166); 0 = the mid-points of the table                      */
+    uint32_t seed;         /* seed of the counter-based uniforms u(seed, ray, sample) used when jitter > 0 */
 } pnr_render_opts_t;
 
 /* MLP arithmetic.  FP32: v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fma chain.  BF16X3: every fp32 product is
@@ -150,14 +153,20 @@ int pnr_query_raypos(const pnr_scene_t *scene, const float *d_raypos, int64_t R,
 
 /* ---- fused render: NeuralPoints.forward + PointNerf.get_outputs for one ray bundle -------------- */
 size_t pnr_render_workspace_bytes(int64_t R, int64_t cap_samples, int32_t K);
-/* d_dirs [R,3] ray directions, d_tmid [D] coarse-sample ray parameters (diff_ray_marching.py:307-323
- * evaluated on the host).  Outputs: d_rgb [R,3] (coarse_raycolor, background-filled), d_depth [R],
+/* d_dirs [R,3] ray directions, d_tmid [2,D]: row 0 = coarse-sample mid-point ray parameters at jitter 0, row 1 =
+ * segment lengths tvals[j+1] - tvals[j] (diff_ray_marching.py:307-323 evaluated on the host).  With
+ * opts->jitter > 0 every ray draws u_j = pnr_jitter_uniform(seed, ray, j) and follows the reference's arithmetic:
+ * seg_j * (1 + jitter * (u_j - 0.5)), running sum, + near, mid-points (diff_ray_marching.py:312-323).  Outputs: d_rgb [R,3] (coarse_raycolor, background-filled), d_depth [R],
  * d_acc [R], d_ray_mask [R] int8, d_counters [PNR_NUM_COUNTERS] int64.  cap_samples bounds the number
  * of selected shading samples held in the workspace; if exceeded PNR_CNT_OVERFLOW is set. */
 int pnr_render(const pnr_scene_t *scene, const pnr_weights_t *weights, const float *d_dirs, int64_t R,
                const pnr_camera_t *cam, const float *d_tmid, const pnr_render_opts_t *opts,
                float *d_rgb, float *d_depth, float *d_acc, int8_t *d_ray_mask, int64_t *d_counters,
                void *d_workspace, size_t workspace_bytes, int64_t cap_samples, void *stream);
+
+/* The counter-based uniform in [0,1) (24 random bits) the kernels draw for coarse sample `sample` of ray `ray`
+ * (ray = index of the ray inside the call) when jitter > 0; host-callable so a caller can reproduce a frame. */
+float pnr_jitter_uniform(uint32_t seed, uint32_t ray, uint32_t sample);
 
 /* Several ray bundles (cameras) in ONE call: ray r belongs to camera d_ray_cam[r] or, when d_ray_cam is NULL,
  * to camera r / rays_per_cam (bundles concatenated back to back).  `cams` is a HOST array of n_cams cameras

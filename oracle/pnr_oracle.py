@@ -118,6 +118,24 @@ def ray_generation(campos: torch.Tensor, raydir: torch.Tensor, point_count: int,
     return raypos, mid
 
 
+def jitter_uniforms(R: int, D: int, seed: int) -> torch.Tensor:
+    """The counter-based uniforms the HIP path draws when jitter > 0 (pnr_uniform in
+    pointnerf2studio_amd/csrc/pnr_internal.h, restated bit for bit): u[0, r, j] in [0, 1) with 24 random bits.
+    They stand where the reference calls torch.rand((N, R, D)) (diff_ray_marching.py:316-319)."""
+    m32 = np.uint64(0xFFFFFFFF)
+    r = np.arange(R, dtype=np.uint64)[:, None]
+    j = np.arange(D, dtype=np.uint64)[None, :]
+    h = (np.uint64(seed & 0xFFFFFFFF) * np.uint64(0x9E3779B1) + r * np.uint64(0x85EBCA77) + j * np.uint64(0xC2B2AE3D)
+         + np.uint64(0x27D4EB2F)) & m32
+    h ^= h >> np.uint64(15)
+    h = (h * np.uint64(0x2C1B3C6D)) & m32
+    h ^= h >> np.uint64(12)
+    h = (h * np.uint64(0x297A2D39)) & m32
+    h ^= h >> np.uint64(15)
+    u = (h >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return torch.from_numpy(u)[None]
+
+
 def get_hyperparameters(cfg: OracleConfig, xyz: torch.Tensor):
     """studio_utils.py:104-127: voxel size, clipped + padded bbox, scaled grid dims.
 

@@ -22,7 +22,7 @@ MAX_CAMS = 16
 
 # every symbol include/pnr.h declares (tests check that the library exports all of them)
 EXPORTED_SYMBOLS = [
-    "pnr_last_error", "pnr_version",
+    "pnr_last_error", "pnr_version", "pnr_jitter_uniform",
     "pnr_scene_create", "pnr_scene_destroy", "pnr_scene_build", "pnr_scene_info", "pnr_points_pack",
     "pnr_weights_create", "pnr_weights_destroy", "pnr_weights_pack",
     "pnr_query_workspace_bytes", "pnr_query_raypos",
@@ -46,7 +46,7 @@ class CameraC(C.Structure):
 
 class RenderOpts(C.Structure):
     _fields_ = [("SR", C.c_int32), ("K", C.c_int32), ("D", C.c_int32), ("radius_limit", C.c_float),
-                ("vsize_z", C.c_float), ("eval_clamp", C.c_int32), ("bg", C.c_float * 3), ("precision", C.c_int32)]
+                ("vsize_z", C.c_float), ("eval_clamp", C.c_int32), ("bg", C.c_float * 3), ("precision", C.c_int32), ("jitter", C.c_float), ("seed", C.c_uint32)]
 
 
 PRECISION = {"fp32": 0, "bf16x3": 1}
@@ -74,6 +74,8 @@ def load() -> C.CDLL:
     lib.pnr_last_error.restype = C.c_char_p
     lib.pnr_last_error.argtypes = []
     lib.pnr_version.restype = C.c_int
+    lib.pnr_jitter_uniform.restype = C.c_float
+    lib.pnr_jitter_uniform.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
     lib.pnr_scene_create.argtypes = [C.POINTER(vp)]
     lib.pnr_scene_destroy.argtypes = [vp]
     lib.pnr_scene_build.argtypes = [vp, vp, i64, C.POINTER(GridParams), vp]
@@ -99,7 +101,7 @@ def load() -> C.CDLL:
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("pnr_last_error", "pnr_query_workspace_bytes", "pnr_render_workspace_bytes",
-                        "pnr_profile_calls"):
+                        "pnr_profile_calls", "pnr_jitter_uniform"):
             fn.restype = C.c_int
     _lib = lib
     return lib

@@ -91,10 +91,26 @@ struct CamRef {
     const Camera *cams;
     const int *ray_cam;
     long long rays_per_cam;
-    const float *tmid;
+    const float *tmid;  // per camera [2, D]: mid-points at jitter 0, segment lengths
     int D;
     int n_cams;
+    float jitter;
+    unsigned seed;
+    float nears[PNR_MAX_CAMS];
 };
+
+// counter-based uniform in [0, 1) with 24 random bits: two rounds of a 32-bit mix over (seed, ray, sample);
+// restated bit for bit in oracle/pnr_oracle.py::jitter_uniforms
+__host__ __device__ __forceinline__ float pnr_uniform(unsigned seed, unsigned ray, unsigned j)
+{
+    unsigned h = seed * 0x9E3779B1u + ray * 0x85EBCA77u + j * 0xC2B2AE3Du + 0x27D4EB2Fu;
+    h ^= h >> 15;
+    h *= 0x2C1B3C6Du;
+    h ^= h >> 12;
+    h *= 0x297A2D39u;
+    h ^= h >> 15;
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
 struct CamSet {
     Camera c[PNR_MAX_CAMS];
 };

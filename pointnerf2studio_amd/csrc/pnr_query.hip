@@ -56,18 +56,45 @@ RenderWs carve_render_ws(void *base, int64_t R, int64_t cap, int K)
 // k_select: one wavefront per ray.  bits[r][w] = occupancy of coarse samples 64w..64w+63,
 // cnt[r] = min(SR, hits).  Either explicit positions (d_raypos, the drop-in op) or o + d * t.
 // ------------------------------------------------------------------------------------------------
+// Ray parameter of coarse sample j = 64w + lane.  jitter == 0: the host table.  jitter > 0: the reference's
+// arithmetic per ray (diff_ray_marching.py:312-323): seg_j * (1 + jitter * (u_j - 0.5)); running sum (torch's CPU
+// cumsum accumulates float32 in double and rounds every prefix); + near; mid-points of consecutive end points.
+// `carry` (running double sum) and `e_prev` (end point of sample 64w - 1) flow from word to word.
+__device__ __forceinline__ float sample_t(const CamRef &cr, const float *__restrict__ tab, float near_plane,
+                                          int64_t r, int D, int w, int lane, double &carry, float &e_prev)
+{
+    const int j = w * 64 + lane;
+    if (cr.jitter == 0.0f) return j < D ? tab[j] : 0.f;
+    float seg = 0.f;
+    if (j < D) {
+        const float u = pnr_uniform(cr.seed, (unsigned)r, (unsigned)j);
+        seg = tab[D + j] * (1.0f + cr.jitter * (u - 0.5f));
+    }
+    double s = (double)seg;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double o = __shfl_up(s, d, 64);
+        if (lane >= d) s += o;
+    }
+    s += carry;
+    carry = __shfl(s, 63, 64);
+    const float e = near_plane + (float)s;          // end point of sample j
+    float e_left = __shfl_up(e, 1, 64);
+    if (lane == 0) e_left = e_prev;
+    e_prev = __shfl(e, 63, 64);
+    return (e_left + e) / 2.0f;
+}
+
 __device__ __forceinline__ void sample_pos(const float *__restrict__ raypos, const float *__restrict__ dirs,
-                                           const float *__restrict__ tmid, const Camera &cam, int64_t r, int D,
-                                           int j, float &px, float &py, float &pz, float &t)  // tmid: this camera's table
+                                           const Camera &cam, int64_t r, int D, int j, float t, float &px, float &py,
+                                           float &pz)
 {
     if (raypos) {
         const float *p = raypos + ((int64_t)r * D + j) * 3;
         px = p[0];
         py = p[1];
         pz = p[2];
-        t = 0.f;
     } else {
-        t = tmid[j];
         float dx = dirs[3 * r], dy = dirs[3 * r + 1], dz = dirs[3 * r + 2];
         float mx = dx * t, my = dy * t, mz = dz * t;  // unfused: raydir * t, then campos + (.)
         px = cam.o[0] + mx;
@@ -89,11 +116,14 @@ __global__ void __launch_bounds__(TPB) k_select(GridView g, CamRef cr, const flo
     const int nwords = (D + 63) >> 6;
     Camera cam{};
     const float *tmid = nullptr;
+    float near_plane = 0.f;
     if (!raypos) {  // the ray's camera: wave-uniform
         const int cid = cam_id(cr, r);
         cam = load_cam(cr, cid);
-        tmid = cr.tmid + (size_t)cid * D;
+        tmid = cr.tmid + (size_t)cid * 2 * D;
+        near_plane = cr.nears[cid];
     }
+    const bool jittered = !raypos && cr.jitter != 0.0f;
     // Conservative ray / grid-box clip (generated positions only): a coarse sample outside the voxel grid can
     // never be occupied (cu:182-187), so whole 64-sample words whose parameter range misses the box -- grown by
     // two voxels against rounding -- are skipped without probing.  Every probed sample still takes the exact test.
@@ -115,7 +145,7 @@ __global__ void __launch_bounds__(TPB) k_select(GridView g, CamRef cr, const flo
     // word range that can intersect the box.  The table is monotonic and (at jitter 0) linear: the range comes
     // from its end points with 3 samples of slack, then the first/last kept word is verified against the table.
     int w_lo = 0, w_hi = nwords - 1;
-    if (!raypos && D > 1) {
+    if (!raypos && !jittered && D > 1) {  // jittered parameters drift from the table: probe every word
         const float t0 = tmid[0], t1 = tmid[D - 1];
         const float inv_dt = (float)(D - 1) / (t1 - t0);
         const float jl = (t_in - t0) * inv_dt - 3.0f, jh = (t_out - t0) * inv_dt + 3.0f;
@@ -131,12 +161,15 @@ __global__ void __launch_bounds__(TPB) k_select(GridView g, CamRef cr, const flo
         }
     }
     unsigned long long my_word = 0ull;  // lane w keeps word w
+    double carry = 0.0;
+    float e_prev = near_plane;
     for (int w = w_lo; w <= w_hi; ++w) {
         int j = w * 64 + lane;
         bool hit = false;
+        const float t = raypos ? 0.f : sample_t(cr, tmid, near_plane, r, D, w, lane, carry, e_prev);
         if (j < D) {
-            float px, py, pz, t;
-            sample_pos(raypos, dirs, tmid, cam, r, D, j, px, py, pz, t);
+            float px, py, pz;
+            sample_pos(raypos, dirs, cam, r, D, j, t, px, py, pz);
             int cx, cy, cz;
             if (cell_of(g, px, py, pz, cx, cy, cz)) {
                 int brick, bit;
@@ -177,22 +210,28 @@ __global__ void __launch_bounds__(TPB) k_expand(CamRef cr, const float *__restri
     if (r >= R) return;
     Camera cam{};
     const float *tmid = nullptr;
+    float near_plane = 0.f;
     if (!raypos) {
         const int cid = cam_id(cr, r);
         cam = load_cam(cr, cid);
-        tmid = cr.tmid + (size_t)cid * D;
+        tmid = cr.tmid + (size_t)cid * 2 * D;
+        near_plane = cr.nears[cid];
     }
     const int off = ray_off[r];
+    if (ray_off[r + 1] == off) return;  // no selected sample on this ray
     int base = 0;
     const int nwords = (D + 63) >> 6;
+    double carry = 0.0;
+    float e_prev = near_plane;
     for (int w = 0; w < nwords && base < SR; ++w) {
         unsigned long long m = ray_bits[r * 8 + w];
+        const float t = raypos ? 0.f : sample_t(cr, tmid, near_plane, r, D, w, lane, carry, e_prev);
         if ((m >> lane) & 1ull) {
             int rank = base + __popcll(m & ((1ull << lane) - 1ull));
             int64_t s = (int64_t)off + rank;
             if (rank < SR && s < cap) {
-                float px, py, pz, t;
-                sample_pos(raypos, dirs, tmid, cam, r, D, w * 64 + lane, px, py, pz, t);
+                float px, py, pz;
+                sample_pos(raypos, dirs, cam, r, D, w * 64 + lane, t, px, py, pz);
                 smp_loc[s] = make_float4(px, py, pz, t);
                 smp_ray[s] = (int)r;
             }

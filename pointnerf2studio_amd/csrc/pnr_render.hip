@@ -141,6 +141,7 @@ using namespace pnr;
 
 extern "C" const char *pnr_last_error(void) { return g_err; }
 extern "C" int pnr_version(void) { return PNR_VERSION; }
+extern "C" float pnr_jitter_uniform(uint32_t seed, uint32_t ray, uint32_t sample) { return pnr_uniform(seed, ray, sample); }
 
 extern "C" size_t pnr_render_workspace_bytes(int64_t R, int64_t cap_samples, int32_t K)
 {
@@ -174,6 +175,7 @@ static int render_views(const pnr_scene_t *scene, const pnr_weights_t *weights, 
     PNR_REQUIRE(opts->D >= 1 && opts->D <= PNR_MAX_D, "%s: D=%d not in [1,%d]", who, opts->D, PNR_MAX_D);
     PNR_REQUIRE(opts->K >= 1 && opts->K <= PNR_MAX_K, "%s: K=%d not in [1,%d]", who, opts->K, PNR_MAX_K);
     PNR_REQUIRE(opts->SR >= 1, "%s: SR=%d", who, opts->SR);
+    PNR_REQUIRE(opts->jitter >= 0.f && opts->jitter < 1.f, "%s: jitter=%g not in [0,1)", who, opts->jitter);
     PNR_REQUIRE(opts->precision == PNR_PRECISION_FP32 || opts->precision == PNR_PRECISION_BF16X3,
                 "%s: unknown precision %d", who, opts->precision);
     PNR_REQUIRE(cap_samples >= 1 && cap_samples < (int64_t)0x7FFFFFF0 / std::max(opts->K, 1),
@@ -197,6 +199,9 @@ static int render_views(const pnr_scene_t *scene, const pnr_weights_t *weights, 
     cr.tmid = d_tmid;
     cr.D = opts->D;
     cr.n_cams = n_cams;
+    cr.jitter = opts->jitter;
+    cr.seed = opts->seed;
+    for (int c = 0; c < n_cams; ++c) cr.nears[c] = cams[c].near_plane;
     const bool prof = g_prof;
     hipEvent_t *g_ev = g_evs[g_prof_calls % PNR_PROFILE_SLOTS];
     if (prof) PNR_HIP_CHECK(hipEventRecord(g_ev[0], stream));

@@ -38,6 +38,13 @@ def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
     return C.c_void_p(0 if t is None else t.data_ptr())
 
 
+def coarse_segments(D: int, near: float, far: float) -> torch.Tensor:
+    """tvals[j+1] - tvals[j] of near_far_linear_ray_generation (diff_ray_marching.py:307-311), float32 [D]."""
+    tvals = torch.linspace(0, 1, D + 1).view(1, -1)
+    tvals = near * (1 - tvals) + far * tvals
+    return (tvals[..., 1:] - tvals[..., :-1]).reshape(D).contiguous()
+
+
 def coarse_t_table(D: int, near: float, far: float) -> torch.Tensor:
     """Ray parameters of the D coarse mid-points at jitter 0, evaluated with the very torch ops of
     near_far_linear_ray_generation (reference models/rendering/diff_ray_marching.py:307-323) on the host."""
@@ -213,7 +220,7 @@ class RendererHIP:
 
     def __init__(self, scene: SceneHIP, weights: WeightsHIP, SR: int = 80, K: int = 8, D: int = 400,
                  radius_limit: float = 0.016, vsize_z: float = 0.004, eval_clamp: bool = True,
-                 bg=(1.0, 1.0, 1.0), precision: str = "fp32"):
+                 bg=(1.0, 1.0, 1.0), precision: str = "fp32", jitter: float = 0.0, seed: int = 0):
         self.lib = _lib.load()
         self.scene, self.weights = scene, weights
         self.opts = _lib.RenderOpts()
@@ -225,6 +232,8 @@ class RendererHIP:
         if precision not in _lib.PRECISION:
             raise ValueError(f"precision must be one of {sorted(_lib.PRECISION)}, got {precision!r}")
         self.opts.precision = _lib.PRECISION[precision]
+        self.opts.jitter = float(jitter)
+        self.opts.seed = int(seed) & 0xFFFFFFFF
         self._ws = None
         self._ws_key = None
         self._tmid = {}
@@ -244,7 +253,8 @@ class RendererHIP:
     def tmid(self, near: float, far: float, dev) -> torch.Tensor:
         key = (self.opts.D, float(near), float(far), str(dev))
         if key not in self._tmid:
-            self._tmid[key] = coarse_t_table(self.opts.D, float(near), float(far)).to(dev)
+            self._tmid[key] = torch.stack([coarse_t_table(self.opts.D, float(near), float(far)),
+                                           coarse_segments(self.opts.D, float(near), float(far))]).to(dev)
         return self._tmid[key]
 
     def render(self, directions: torch.Tensor, campos, camrotc2w, near: float, far: float,

@@ -34,7 +34,7 @@ def test_struct_layouts_match_header(lib):
     from pointnerf2studio_amd import _lib
     assert C.sizeof(_lib.GridParams) == 6 * 4 + 3 * 4 + 3 * 4 + 3 * 4 + 3 * 4 + 3 * 4
     assert C.sizeof(_lib.CameraC) == (3 + 9 + 2) * 4
-    assert C.sizeof(_lib.RenderOpts) == 10 * 4
+    assert C.sizeof(_lib.RenderOpts) == 12 * 4
 
 
 def test_argument_validation_fails_loudly(lib):
@@ -123,3 +123,15 @@ def test_product_package_never_touches_the_oracle():
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "pnr_oracle" not in src and "oracle/" not in src and "import oracle" not in src, f
                 assert "/root/reference" not in src, f
+
+
+def test_jitter_uniform_matches_oracle_generator(lib, oracle):
+    """The host-callable copy of the kernels' counter-based uniform against the oracle's numpy restatement."""
+    u = oracle.jitter_uniforms(37, 400, seed=7)[0].numpy()
+    for r, j in [(0, 0), (0, 399), (5, 17), (36, 1), (36, 399), (12, 200)]:
+        assert lib.pnr_jitter_uniform(7, r, j) == float(u[r, j])
+    u2 = oracle.jitter_uniforms(4, 16, seed=0xFFFFFFFF)[0].numpy()
+    assert lib.pnr_jitter_uniform(0xFFFFFFFF, 3, 15) == float(u2[3, 15])
+    big = oracle.jitter_uniforms(2000, 400, seed=3)[0].numpy()
+    assert 0.0 <= big.min() and big.max() < 1.0 and abs(big.mean() - 0.5) < 2e-3
+    assert abs(np.corrcoef(big[:, :-1].ravel(), big[:, 1:].ravel())[0, 1]) < 5e-3

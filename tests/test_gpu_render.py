@@ -208,3 +208,38 @@ def test_render_views_equals_per_camera_renders(oracle, gpu_device):
     # and one of the views against the oracle
     ref = oracle.render(pts, w, cfg, cams[1][0][None].expand(n, 3), dirs[1].cpu(), 2.0, 6.0, cams[1][1])
     assert (out["rgb"][n:2 * n].cpu() - ref["coarse_raycolor"]).abs().max().item() <= RGB_TOL
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_render_with_jitter_matches_oracle(oracle, gpu_device, precision):
+    """jitter 0.3 (what the plugin uses, studio_utils.py:166) with the counter-based uniforms shared by kernel and
+    oracle: the oracle feeds the same u to the reference's ray-generation arithmetic (pinned by the golden
+    ref_raygen jit_* vectors); sample positions, neighbour lists and the image must agree as at jitter 0."""
+    pts = small_scene(80000)
+    cfg = oracle_cfg(oracle)
+    w = synthetic.make_weights(0, sigma_scale=300.0, bias_scale=0.1)
+    campos, camrot, dirs = camera_rays(32, 32, az=50.0)
+    R = dirs.shape[0]
+    u = oracle.jitter_uniforms(R, cfg.z_depth_dim, seed=7)
+    assert 0.0 <= float(u.min()) and float(u.max()) < 1.0 and abs(float(u.mean()) - 0.5) < 0.01
+    ref = oracle.render(pts, w, cfg, campos[None].expand(R, 3), dirs, 2.0, 6.0, camrot, jitter=0.3, u=u)
+    ref0 = oracle.render(pts, w, cfg, campos[None].expand(R, 3), dirs, 2.0, 6.0, camrot)
+    assert (ref["coarse_raycolor"] - ref0["coarse_raycolor"]).abs().max() > 1e-3     # the jitter does something
+    scene, wh, hyp, info = build_hip(pts, cfg, gpu_device, weights=w)
+    rnd = RendererHIP(scene, wh, precision=precision, jitter=0.3, seed=7)
+    out = rnd.render(dirs.to(gpu_device), campos, camrot, 2.0, 6.0)
+    _check(ref, out)
+    taps = rnd.taps(R)
+    S = out["counters"]["samples_selected"]
+    cnt, off = taps["ray_cnt"].cpu().numpy(), taps["ray_off"].cpu().numpy()
+    loc = taps["smp_loc"][:S].cpu().numpy()
+    pidx = taps["smp_pidx"][:S].cpu().numpy()
+    keep = np.nonzero(ref["ray_mask"].numpy() > 0)[0]
+    ref_loc, ref_mask = ref["sample_loc_w"][0].numpy(), ref["pnt_mask"][0].numpy()
+    for row, r in enumerate(keep):
+        assert np.array_equal(loc[off[r]:off[r] + cnt[r], :3], ref_loc[row, :cnt[r]]), "jittered sample positions differ"
+        assert np.array_equal(pidx[off[r]:off[r] + cnt[r]] >= 0, ref_mask[row, :cnt[r]])
+    # a different seed gives a different image, the same seed the same image
+    out_b = RendererHIP(scene, wh, precision=precision, jitter=0.3, seed=8).render(dirs.to(gpu_device), campos, camrot, 2.0, 6.0)
+    out_c = RendererHIP(scene, wh, precision=precision, jitter=0.3, seed=7).render(dirs.to(gpu_device), campos, camrot, 2.0, 6.0)
+    assert not torch.equal(out_b["rgb"], out["rgb"]) and torch.equal(out_c["rgb"], out["rgb"])

@@ -125,3 +125,26 @@ def test_method_registration_constants():
     assert studio_config.EVAL_NUM_RAYS_PER_CHUNK == 2304
     f = studio_config.pointnerf_lr_lambda()
     assert f(0) == 1.0 and abs(f(1000000) - 0.1) < 1e-12
+
+
+def test_loads_reference_checkpoint_layout(tmp_path, monkeypatch):
+    """studio_model.py:147-166 / base_model.py:85-102: `{iter}_net_ray_marching.pth` + `{iter}_states.pth`; the
+    newest iteration wins, only the neural_points.* keys are consumed, aggregator.* weights are ignored."""
+    sd_old, sd_new = _state_dict(300), _state_dict(500)
+    sd_new["aggregator.block1.0.weight"] = torch.zeros(256, 284)      # present in real checkpoints, unused
+    d = tmp_path / "ckpt"
+    d.mkdir()
+    torch.save(sd_old, d / "0_net_ray_marching.pth")
+    torch.save({"epoch_count": 0, "total_steps": 0}, d / "0_states.pth")
+    torch.save(sd_new, d / "200000_net_ray_marching.pth")
+    torch.save({"epoch_count": 5, "total_steps": 200000}, d / "200000_states.pth")
+    orig = PointNerf._init_pointnerf
+
+    def _init(self):
+        self._device = "cpu"
+        orig(self)
+    monkeypatch.setattr(PointNerf, "_init_pointnerf", _init)
+    m = PointNerf(PointNerfConfig(path_point_cloud=d))
+    assert m.neural_points.points_xyz.shape == (500, 3)
+    assert torch.equal(m.neural_points.points_embeding.detach(), sd_new["neural_points.points_embeding"])
+    assert not any(k.startswith("aggregator") for k in m.state_dict())
