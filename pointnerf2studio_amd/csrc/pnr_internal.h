@@ -100,7 +100,7 @@ struct CamRef {
 };
 
 // counter-based uniform in [0, 1) with 24 random bits: two rounds of a 32-bit mix over (seed, ray, sample);
-// restated bit for bit in oracle/pnr_oracle.py::jitter_uniforms
+// exported as pnr_jitter_uniform so hosts (and the test suite) can reproduce the stream
 __host__ __device__ __forceinline__ float pnr_uniform(unsigned seed, unsigned ray, unsigned j)
 {
     unsigned h = seed * 0x9E3779B1u + ray * 0x85EBCA77u + j * 0xC2B2AE3Du + 0x27D4EB2Fu;
