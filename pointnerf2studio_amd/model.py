@@ -111,6 +111,7 @@ class PointNerf(Model):
         self._renderer: Optional[RendererHIP] = None
         self._weights: Optional[WeightsHIP] = None
         self._weights_key = None
+        self._render_calls = 0
         self._init_pointnerf()
 
     def _init_pointnerf(self):
@@ -192,11 +193,16 @@ class PointNerf(Model):
         return self._renderer
 
     def _get_outputs_fused(self, ray_bundle):
-        """Jitter: the reference draws torch.rand jitter even at eval (studio_utils.py:166); the fused path
-        renders the jitter-free mid-points (deterministic; DESIGN.md 'jitter')."""
+        """Jitter: the reference draws torch.rand jitter even at eval (studio_utils.py:166, hard-coded 0.3); the
+        fused path uses the same fraction (`neural_points.jitter`) with the library's counter-based uniforms and
+        a fresh seed per call.  Set `neural_points.jitter = 0` for deterministic mid-point renders."""
         rot, pos = self.neural_points._camera(ray_bundle)
-        out = self._fused_renderer().render(ray_bundle.directions.to(self._device), pos[0], rot[0],
-                                            ray_bundle.nears[0].item(), ray_bundle.fars[0].item())
+        rnd = self._fused_renderer()
+        rnd.opts.jitter = float(self.neural_points.jitter)
+        rnd.opts.seed = self._render_calls & 0xFFFFFFFF
+        self._render_calls += 1
+        out = rnd.render(ray_bundle.directions.to(self._device), pos[0], rot[0],
+                         ray_bundle.nears[0].item(), ray_bundle.fars[0].item())
         return {"coarse_raycolor": out["rgb"], "ray_mask": out["ray_mask"], "depth": out["depth"],
                 "accumulation": out["acc"]}
 

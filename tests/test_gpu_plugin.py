@@ -36,8 +36,13 @@ def _model_and_bundle(oracle, device, N=60000, H=32, W=32, az=35.0):
 def test_eval_get_outputs_uses_fused_path_and_matches_oracle(oracle, gpu_device):
     model, bundle, ref = _model_and_bundle(oracle, gpu_device)
     model.eval()
+    assert model.neural_points.jitter == 0.3      # the reference's hard-coded value
+    with torch.no_grad():
+        jittered = model(bundle)["coarse_raycolor"].clone()
+    model.neural_points.jitter = 0.0              # the oracle reference below is evaluated at jitter 0
     with torch.no_grad():
         out = model(bundle)
+    assert not torch.equal(jittered, out["coarse_raycolor"])
     assert set(out) >= {"coarse_raycolor", "ray_mask"}
     assert out["coarse_raycolor"].shape == (bundle.directions.shape[0], 3) and out["ray_mask"].dtype == torch.int8
     assert torch.equal(out["ray_mask"].cpu(), ref["ray_mask"])
