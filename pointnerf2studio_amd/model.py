@@ -91,6 +91,9 @@ class PointNerfConfig(ModelConfig):
     zero_epsilon: float = 1e-3
     zero_one_loss_weights: float = 0.0001
 
+    # additions of this build (not in the reference): arithmetic of the fused HIP MLP, see include/pnr.h
+    hip_mlp_mode: str = "bf16x3"   # "bf16x3" (3 bf16 MFMA products per fp32 product) or "fp32" (exact)
+
     def __post_init__(self):
         if self.path_point_cloud is not None:
             if not Path(self.path_point_cloud).exists():
@@ -189,7 +192,8 @@ class PointNerf(Model):
             c = self.config
             self._renderer = RendererHIP(scene, self._weights, SR=c.SR, K=c.K, D=c.z_depth_dim,
                                          radius_limit=float(self.neural_points.radius_limit_np),
-                                         vsize_z=c.vsize[2], eval_clamp=True, bg=self._background_color.tolist())
+                                         vsize_z=c.vsize[2], eval_clamp=True, bg=self._background_color.tolist(),
+                                         precision=getattr(c, "hip_mlp_mode", "bf16x3"))
         return self._renderer
 
     def _get_outputs_fused(self, ray_bundle):
