@@ -61,7 +61,16 @@ constexpr int TPB = WAVES * 64;
 constexpr int PF = 6;  // fp32 path: weight loads (1 KiB each per wave) kept in flight
 
 // LeakyReLU(0.1): max(x, 0.1 x) (identical to the select form for finite x, one instruction shorter)
-__device__ __forceinline__ float leaky(float x) { return fmaxf(x, 0.1f * x); }
+// LeakyReLU(0.1) = max(x, 0.1x); fmaxf costs an extra instruction (hipcc canonicalises the operand first:
+// v_max_f32 v, v, v)
+// (kept as one v_mul + one v_max through inline asm: any builtin form is turned back into canonicalise + max)
+__device__ __forceinline__ float leaky(float x)
+{
+    float r;
+    const float y = 0.1f * x;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
 
 struct ShadeParams {
     const float4 *point_rows;  // [N, 11] float4
