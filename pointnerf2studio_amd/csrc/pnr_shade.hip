@@ -599,6 +599,7 @@ struct Ring {
     int cur;
     u32x4 ah, al, bh, bl;
     f32x16 acc0;
+    unsigned long long stall_bar, stall_bias;  // PNR_STAMPS builds only
 };
 
 // One dense layer on bf16 hi/lo splits.  MT output tiles of 32 features.  Weight tiles
@@ -650,7 +651,11 @@ __device__ __forceinline__ void dense_layer_bf16(__amdgpu_buffer_rsrc_t rsrc, in
                 cl = nxt[(2 * (s + 2 - KS) + 1) * 64 + lane];
             }
             if (s == KS - 6) bias_issue((m + 1 < MT) ? bias + 32 * (m + 1) : bias_nx, breg);
-            if (s == KS - 1) ring.acc0 = bias_finish(breg, h);
+            if (s == KS - 1) {
+                const unsigned long long tb0 = stamp();
+                ring.acc0 = bias_finish(breg, h);
+                ring.stall_bias += stamp() - tb0;
+            }
             const bf16x8 wh = __builtin_bit_cast(bf16x8, ring.ah);
             const bf16x8 wl = __builtin_bit_cast(bf16x8, ring.al);
             // the previous tile's accumulators are read two k-steps into this tile at the earliest: its last MFMA
@@ -698,7 +703,9 @@ __device__ __forceinline__ void dense_layer_bf16(__amdgpu_buffer_rsrc_t rsrc, in
                     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 else
                     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                const unsigned long long tb0 = stamp();
                 __builtin_amdgcn_s_barrier();
+                ring.stall_bar += stamp() - tb0;
             }
             // ---- DMA of tile T+3 into the freed slot: two 1-KiB pieces per k-step behind the barrier, so the
             //      scalar address arithmetic hides between MFMAs instead of stalling the matrix pipe in one burst
@@ -785,6 +792,8 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
     const float *__restrict__ b2 = P.wbuf + P.b_off[2];
     const float *__restrict__ b3 = P.wbuf + P.b_off[3];
     Ring ring;
+    ring.stall_bar = 0;
+    ring.stall_bias = 0;
     ring_start<18>(rsrc, w0_, b0, lane, tid, wave_u, lds, ring);
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int tile = t_begin; tile < t_end; ++tile) {
@@ -796,8 +805,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
         {
             float x0[144];
             load_rows<K8, true>(P, tile, lane, wave, S_valid, x0, ctx);
-            const unsigned long long ts0b = stamp();
-            ph[6] += ts0b - ts0;
+            (void)ts0;
 #pragma unroll
             for (int s = 0; s < 18; ++s) split8(&x0[8 * s], xh[s], xl[s]);
         }
@@ -830,6 +838,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
         ph[4] += ts5 - ts4;
         ph[5] += ts6 - ts5;
         ph[7] += 1;
+        ph[6] = ring.stall_bar;
     }
 #if PNR_STAMPS
     if (lane == 0) {

@@ -62,6 +62,38 @@ def make_points(N: int, seed: int = 1234, ranges=CHAIR_RANGES, noise: float = 0.
     }
 
 
+def make_room_points(N: int, seed: int = 4321, size=(8.0, 6.0, 3.0), noise: float = 0.004) -> Dict[str, torch.Tensor]:
+    """N points on the six inner faces of a size[0] x size[1] x size[2] m room shell plus two box-shaped pieces of
+    furniture (ScanNet-style indoor cloud: BASELINE.json configs[4], vsize 0.008, K = 12, near 0.1 / far 8,
+    reference dev_scripts/w_scannet_etf/scene241_points.sh:53-60,91-92).  Same tensor layouts as make_points."""
+    g = torch.Generator().manual_seed(seed)
+    rnd = lambda *s: torch.rand(*s, generator=g)
+    sx, sy, sz = size
+    n_wall = int(N * 0.8)
+    face = torch.randint(0, 6, (n_wall,), generator=g)
+    u, v = rnd(n_wall), rnd(n_wall)
+    jit = (rnd(n_wall) - 0.5) * 2 * noise
+    x = torch.where(face == 0, jit, torch.where(face == 1, sx + jit, u * sx))
+    y = torch.where(face == 2, jit, torch.where(face == 3, sy + jit, torch.where(face < 2, u * sy, v * sy)))
+    z = torch.where(face == 4, jit, torch.where(face == 5, sz + jit, v * sz))
+    walls = torch.stack([x, y, z], -1)
+    n_f = N - n_wall
+    c = torch.tensor([[2.0, 2.0, 0.4], [5.5, 3.5, 0.5]])[torch.randint(0, 2, (n_f,), generator=g)]
+    d = torch.nn.functional.normalize(torch.randn(n_f, 3, generator=g), dim=-1)
+    d = d / d.abs().max(dim=-1, keepdim=True)[0]            # points on a cube surface
+    furn = c + d * torch.tensor([0.6, 0.4, 0.4]) + (rnd(n_f, 3) - 0.5) * 2 * noise
+    xyz = torch.cat([walls, furn], 0)[torch.randperm(N, generator=g)].float().contiguous()
+    eye = torch.tensor([sx / 2, sy / 2, sz / 2])
+    return {
+        "xyz": xyz,
+        "embedding": (rnd(1, N, 32) - 0.5).float(),
+        "conf": (0.1 + 0.9 * rnd(1, N, 1)).float(),
+        "dir": torch.nn.functional.normalize(eye - xyz, dim=-1)[None].float().contiguous(),
+        "color": rnd(1, N, 3).float(),
+        "Rw2c": torch.eye(3),
+    }
+
+
 def make_weights(seed: int = 0, sigma_scale: float = 1.0, bias_scale: float = 0.0) -> Dict[str, torch.Tensor]:
     """Xavier-uniform weights (reference models/helpers/networks.py:72-173: gain of leaky_relu(0.1) for hidden
     layers, 1 for the heads).  `sigma_scale` multiplies the density head so opacities are non-trivial with
@@ -99,6 +131,19 @@ def make_camera(azimuth_deg: float, elevation_deg: float = 30.0, radius: float =
     true_up = torch.linalg.cross(back, right)
     rot = torch.stack([right, true_up, back], dim=1)   # columns = camera axes in world coordinates
     return pos.float(), rot.float().contiguous()
+
+
+def make_inside_camera(pos, yaw_deg: float, pitch_deg: float = 0.0):
+    """Camera at `pos` inside a scene (indoor configs), OpenGL convention, z up.  Returns (campos, camrotc2w)."""
+    yaw, pitch = math.radians(yaw_deg), math.radians(pitch_deg)
+    fwd = torch.tensor([math.cos(pitch) * math.cos(yaw), math.cos(pitch) * math.sin(yaw), math.sin(pitch)],
+                       dtype=torch.float64)
+    back = -fwd
+    up = torch.tensor([0.0, 0.0, 1.0], dtype=torch.float64)
+    right = torch.linalg.cross(up, back)
+    right = right / right.norm()
+    true_up = torch.linalg.cross(back, right)
+    return torch.as_tensor(pos, dtype=torch.float32), torch.stack([right, true_up, back], dim=1).float().contiguous()
 
 
 def make_rays(H: int, W: int, campos: torch.Tensor, camrot: torch.Tensor, camera_angle_x: float = 0.6911112070083618,

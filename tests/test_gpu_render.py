@@ -243,3 +243,48 @@ def test_render_with_jitter_matches_oracle(oracle, gpu_device, precision):
     out_b = RendererHIP(scene, wh, precision=precision, jitter=0.3, seed=8).render(dirs.to(gpu_device), campos, camrot, 2.0, 6.0)
     out_c = RendererHIP(scene, wh, precision=precision, jitter=0.3, seed=7).render(dirs.to(gpu_device), campos, camrot, 2.0, 6.0)
     assert not torch.equal(out_b["rgb"], out["rgb"]) and torch.equal(out_c["rgb"], out["rgb"])
+
+
+def _render_cfg(oracle, device, pts, cfg, campos, camrot, dirs, near, far, precision):
+    w = synthetic.make_weights(0, sigma_scale=300.0, bias_scale=0.1)
+    ref = oracle.render(pts, w, cfg, campos[None].expand(dirs.shape[0], 3), dirs, near, far, camrot)
+    xyz = pts["xyz"].to(device)
+    from pointnerf2studio_amd.renderer import SceneHIP, WeightsHIP, grid_hyperparameters
+    hyp = grid_hyperparameters(xyz, cfg.vsize, cfg.vscale, cfg.kernel_size, cfg.ranges)
+    scene = SceneHIP()
+    scene.build(xyz, hyp.ranges, hyp.scaled_vsize, hyp.scaled_vdim, cfg.kernel_size, cfg.query_size, cfg.P, cfg.max_o)
+    scene.pack_points(xyz, pts["embedding"].to(device), pts["conf"].to(device), pts["dir"].to(device), pts["color"].to(device))
+    wh = WeightsHIP()
+    wh.pack(w, pts["Rw2c"], device)
+    rnd = RendererHIP(scene, wh, SR=cfg.SR, K=cfg.K, D=cfg.z_depth_dim, radius_limit=float(oracle.radius_limit(cfg)),
+                      vsize_z=cfg.vsize[2], precision=precision)
+    return ref, rnd.render(dirs.to(device), campos, camrot, near, far)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_render_lego_style_config(oracle, gpu_device, precision):
+    """BASELINE.json configs[2] parameters at reduced size: lego bounding box and P = 9
+    (reference dev_scripts/w_n360/lego_points.sh:58-62)."""
+    pts = synthetic.make_points(150000, seed=77, ranges=synthetic.LEGO_RANGES)
+    pts["xyz"] = (pts["xyz"] * torch.tensor([0.9, 1.5, 0.9])).contiguous()   # fill the elongated lego box
+    cfg = oracle_cfg(oracle, SR=80, K=8, P=9, ranges=synthetic.LEGO_RANGES, max_o=830000)
+    campos, camrot, dirs = camera_rays(40, 40, az=100.0)
+    ref, out = _render_cfg(oracle, gpu_device, pts, cfg, campos, camrot, dirs, 2.0, 6.0, precision)
+    _check(ref, out)
+    assert ref["stats"]["rays_kept"] > 100
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_render_scannet_style_config(oracle, gpu_device, precision):
+    """BASELINE.json configs[4] parameters at reduced size: indoor room shell, vsize 0.008 (voxel 0.016), K = 12
+    (beyond the reference's KN = 8 buffer), SR = 24, P = 26, near 0.1 / far 8, camera INSIDE the cloud, 4:3 image
+    (reference dev_scripts/w_scannet_etf/scene241_points.sh:53-60,91-92)."""
+    pts = synthetic.make_room_points(400000)
+    cfg = oracle_cfg(oracle, SR=24, K=12, P=26, ranges=[-0.5, -0.5, -0.5, 8.5, 6.5, 3.5], max_o=1000000)
+    cfg.vsize = [0.008, 0.008, 0.008]
+    campos, camrot = synthetic.make_inside_camera([4.0, 3.0, 1.5], yaw_deg=35.0, pitch_deg=-10.0)
+    dirs = synthetic.make_rays(36, 48, campos, camrot, camera_angle_x=1.0)
+    ref, out = _render_cfg(oracle, gpu_device, pts, cfg, campos, camrot, dirs, 0.1, 8.0, precision)
+    _check(ref, out)
+    assert ref["stats"]["rays_kept"] > 0.9 * dirs.shape[0]       # indoors every ray ends on a surface
+    assert out["counters"]["pairs_valid"] > 5000
