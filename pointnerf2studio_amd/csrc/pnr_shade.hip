@@ -178,30 +178,68 @@ struct RowCtx {
 // x0: the lane's 144 layer-1 input values; value i = 8s + j is element j of k-step s in the bf16 path and
 // k-step t = i in the fp32 path.  Lane half h = 0 carries emb[0:16], their encodings and the rotated world
 // distances, h = 1 carries emb[16:32], their encodings and the camera-space distances.
-template <bool K8, bool FAST_PE>
-__device__ __forceinline__ void load_rows(const ShadeParams &P, int tile, int lane, int wave, int S_valid,
-                                          float (&x0)[144], RowCtx &ctx)
+// Gathered inputs of one lane's (sample, neighbour) row.  The three dependent load levels are separate functions
+// so that the bf16x3 kernel can issue them for the NEXT tile between the layers of the current one (one wave per
+// SIMD cannot hide a vs_list -> smp_pidx -> point-row chain of three HBM/L2 latencies any other way).
+struct RowFetch {
+    int v_idx, slot, s, pidx, ray;
+    bool row_ok;
+    float4 a0, e0, e1, e2, e3, c0, c1, loc;
+    float dirx, diry, dirz;
+};
+
+template <bool K8>
+__device__ __forceinline__ void fetch_a(const ShadeParams &P, int tile, int lane, int wave, int S_valid, RowFetch &f)
 {
-    const int j = lane & 31, h = lane >> 5;
+    const int j = lane & 31;
     const int K = K8 ? 8 : P.K;
     const int SPW = 32 / K;
     const int SPT = SPW * WAVES;
     const int sl = j / K;
-    ctx.v_idx = tile * SPT + wave * SPW + sl;
-    ctx.row_ok = (j < SPW * K) && (ctx.v_idx < S_valid);
-    ctx.slot = j - sl * K;
-    const int s = ctx.row_ok ? P.vs_list[ctx.v_idx] : 0;
-    int pidx = ctx.row_ok ? P.smp_pidx[(int64_t)s * K + ctx.slot] : -1;
-    const bool valid = pidx >= 0;
-    pidx = max(pidx, 0);
-    const float4 *row = P.point_rows + (int64_t)pidx * 11;
-    const float4 a0 = row[0];
-    const float4 e0 = row[1 + 4 * h], e1 = row[2 + 4 * h], e2 = row[3 + 4 * h], e3 = row[4 + 4 * h];
-    const float4 c0 = row[9], c1 = row[10];
-    const float4 loc = P.smp_loc[s];
-    const int ray = P.smp_ray[s];
-    const float dirx = P.dirs[3 * (int64_t)ray], diry = P.dirs[3 * (int64_t)ray + 1],
-                dirz = P.dirs[3 * (int64_t)ray + 2];
+    f.v_idx = tile * SPT + wave * SPW + sl;
+    f.row_ok = (j < SPW * K) && (f.v_idx < S_valid);
+    f.slot = j - sl * K;
+    f.s = f.row_ok ? P.vs_list[f.v_idx] : 0;
+}
+
+template <bool K8>
+__device__ __forceinline__ void fetch_b(const ShadeParams &P, RowFetch &f)
+{
+    const int K = K8 ? 8 : P.K;
+    f.pidx = f.row_ok ? P.smp_pidx[(int64_t)f.s * K + f.slot] : -1;
+    f.loc = P.smp_loc[f.s];
+    f.ray = P.smp_ray[f.s];
+}
+
+__device__ __forceinline__ void fetch_c(const ShadeParams &P, int lane, RowFetch &f)
+{
+    const int h = lane >> 5;
+    const float4 *row = P.point_rows + (int64_t)max(f.pidx, 0) * 11;
+    f.a0 = row[0];
+    f.e0 = row[1 + 4 * h];
+    f.e1 = row[2 + 4 * h];
+    f.e2 = row[3 + 4 * h];
+    f.e3 = row[4 + 4 * h];
+    f.c0 = row[9];
+    f.c1 = row[10];
+    f.dirx = P.dirs[3 * (int64_t)f.ray];
+    f.diry = P.dirs[3 * (int64_t)f.ray + 1];
+    f.dirz = P.dirs[3 * (int64_t)f.ray + 2];
+}
+
+template <bool K8, bool FAST_PE>
+__device__ __forceinline__ void compute_rows(const ShadeParams &P, const RowFetch &f, int lane, float (&x0)[144],
+                                             RowCtx &ctx)
+{
+    const int h = lane >> 5;
+    const int K = K8 ? 8 : P.K;
+    ctx.v_idx = f.v_idx;
+    ctx.row_ok = f.row_ok;
+    ctx.slot = f.slot;
+    const bool valid = f.pidx >= 0;
+    const float4 a0 = f.a0, e0 = f.e0, e1 = f.e1, e2 = f.e2, e3 = f.e3, c0 = f.c0, c1 = f.c1, loc = f.loc;
+    const int ray = f.ray;
+    const float dirx = f.dirx, diry = f.diry, dirz = f.dirz;
     const Camera cam = load_cam_lanes(P.cr, cam_id(P.cr, ray));
 
     // dists + inverse-distance weight (studio_model.py:270-286,467-475)
@@ -283,6 +321,17 @@ __device__ __forceinline__ void load_rows(const ShadeParams &P, int tile, int la
     ctx.ex[1] = h ? dv0 : c0.z;
     ctx.ex[2] = h ? dv2 : dv1;
     ctx.ex[3] = h ? 0.f : dot;
+}
+
+template <bool K8, bool FAST_PE>
+__device__ __forceinline__ void load_rows(const ShadeParams &P, int tile, int lane, int wave, int S_valid,
+                                          float (&x0)[144], RowCtx &ctx)
+{
+    RowFetch f;
+    fetch_a<K8>(P, tile, lane, wave, S_valid, f);
+    fetch_b<K8>(P, f);
+    fetch_c(P, lane, f);
+    compute_rows<K8, FAST_PE>(P, f, lane, x0, ctx);
 }
 
 // Bias-initialised accumulator of an output tile.  The tile's 32 biases are wave-uniform: they are fetched through
@@ -796,6 +845,10 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
     ring.stall_bias = 0;
     ring_start<18>(rsrc, w0_, b0, lane, tid, wave_u, lds, ring);
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    RowFetch cur, nxt;
+    fetch_a<K8>(P, t_begin, lane, wave, S_valid, cur);
+    fetch_b<K8>(P, cur);
+    fetch_c(P, lane, cur);
     for (int tile = t_begin; tile < t_end; ++tile) {
         int w0 = w0_, w1 = w1_, w2 = w2_, w3 = w3_;
         asm volatile("" : "+s"(w0), "+s"(w1), "+s"(w2), "+s"(w3));
@@ -804,18 +857,22 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
         bf16x8 xh[18], xl[18];
         {
             float x0[144];
-            load_rows<K8, true>(P, tile, lane, wave, S_valid, x0, ctx);
+            compute_rows<K8, true>(P, cur, lane, x0, ctx);
             (void)ts0;
 #pragma unroll
             for (int s = 0; s < 18; ++s) split8(&x0[8 * s], xh[s], xl[s]);
         }
         const unsigned long long ts1 = stamp();
+        // the next tile's gather, one dependent level per layer boundary (a tile past the end loads row 0: harmless)
+        fetch_a<K8>(P, tile + 1, lane, wave, S_valid, nxt);
         bf16x8 yh[17], yl[17];
         dense_layer_bf16<18, 8, 16, true>(rsrc, w0, w1, b0, b1, lane, tid, wave_u, lds, ring, xh, xl, yh, yl, nullptr);
         const unsigned long long ts2 = stamp();
+        fetch_b<K8>(P, nxt);
         // xh/xl are free again: they receive layer 2's output (+ the 7 extra head inputs as k-step 16)
         dense_layer_bf16<16, 8, 17, true>(rsrc, w1, w2, b1, b2, lane, tid, wave_u, lds, ring, yh, yl, xh, xl, nullptr);
         const unsigned long long ts3 = stamp();
+        fetch_c(P, lane, nxt);
         {
             float v[8] = {ctx.ex[0], ctx.ex[1], ctx.ex[2], ctx.ex[3], 0.f, 0.f, 0.f, 0.f};
             split8(v, xh[16], xl[16]);
@@ -839,6 +896,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
         ph[5] += ts6 - ts5;
         ph[7] += 1;
         ph[6] = ring.stall_bar;
+        cur = nxt;
     }
 #if PNR_STAMPS
     if (lane == 0) {
