@@ -105,7 +105,7 @@ enum {
     PNR_CNT_PAIRS_VALID = 4,    /* M   valid (sample, neighbour) pairs                       */
     PNR_CNT_CANDIDATES = 5,     /* candidates distance-tested                                */
     PNR_CNT_OVERFLOW = 6,       /* != 0: cap_samples was too small, output incomplete        */
-    PNR_CNT_RESERVED = 7,
+    PNR_CNT_POINTS_UNIQUE = 7,  /* U   distinct neighbour points (bf16x3 mode; 0 in fp32 mode)      */
     PNR_NUM_COUNTERS = 8
 };
 
@@ -152,7 +152,13 @@ int pnr_query_raypos(const pnr_scene_t *scene, const float *d_raypos, int64_t R,
                      void *stream);
 
 /* ---- fused render: NeuralPoints.forward + PointNerf.get_outputs for one ray bundle -------------- */
+/* Workspace of a PNR_PRECISION_FP32 render (scene independent), and of a render with the given options on the
+ * given (built) scene: PNR_PRECISION_BF16X3 adds the per-call table of the factorised first layer, one 1-KiB row
+ * per distinct neighbour point (at most min(points in voxel lists, cap_samples * K) rows), and two int32 per
+ * scene point.  pnr_render_workspace_bytes_for returns 0 (and sets the error string) on invalid arguments. */
 size_t pnr_render_workspace_bytes(int64_t R, int64_t cap_samples, int32_t K);
+size_t pnr_render_workspace_bytes_for(const pnr_scene_t *scene, const pnr_render_opts_t *opts, int64_t R,
+                                      int64_t cap_samples);
 /* d_dirs [R,3] ray directions, d_tmid [2,D]: row 0 = coarse-sample mid-point ray parameters at jitter 0, row 1 =
  * segment lengths tvals[j+1] - tvals[j] (diff_ray_marching.py:307-323 evaluated on the host).  With
  * opts->jitter > 0 every ray draws u_j = pnr_jitter_uniform(seed, ray, j) and follows the reference's arithmetic:
@@ -204,7 +210,9 @@ enum {
     PNR_STAGE_SHADE_PAIRS = 2, /* gather + mlp_base + mlp_head + density + K-aggregation   */
     PNR_STAGE_SHADE_COLOR = 3, /* colour MLP                                               */
     PNR_STAGE_COMPOSITE = 4,   /* ray_dist + alpha composite + background fill             */
-    PNR_NUM_STAGES = 5
+    PNR_STAGE_POINT_PART = 5,  /* bf16x3: first-layer partial products of the distinct neighbour points (runs
+                                  between KNN and SHADE_PAIRS; 0 in fp32 mode)                */
+    PNR_NUM_STAGES = 6
 };
 int pnr_profile_enable(int enable);
 int64_t pnr_profile_calls(void);

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("PNR_LIB") or os.path.join(PKG_DIR, "libpnr_hip.so")
 
 NUM_COUNTERS = 8
 COUNTER_NAMES = ["rays_hit", "rays_kept", "samples_selected", "samples_valid", "pairs_valid", "candidates",
-                 "overflow", "reserved"]
+                 "overflow", "points_unique"]
 POINT_ROW_FLOATS = 44
 MAX_K = 32
 MAX_D = 512
@@ -26,11 +26,12 @@ EXPORTED_SYMBOLS = [
     "pnr_scene_create", "pnr_scene_destroy", "pnr_scene_build", "pnr_scene_info", "pnr_points_pack",
     "pnr_weights_create", "pnr_weights_destroy", "pnr_weights_pack",
     "pnr_query_workspace_bytes", "pnr_query_raypos",
-    "pnr_render_workspace_bytes", "pnr_render", "pnr_render_views", "pnr_render_taps",
+    "pnr_render_workspace_bytes", "pnr_render_workspace_bytes_for", "pnr_render", "pnr_render_views",
+    "pnr_render_taps",
     "pnr_profile_enable", "pnr_profile_calls", "pnr_profile_read",
 ]
-NUM_STAGES = 5
-STAGE_NAMES = ["select", "knn", "shade_pairs", "shade_color", "composite"]
+NUM_STAGES = 6
+STAGE_NAMES = ["select", "knn", "shade_pairs", "shade_color", "composite", "point_part"]
 
 
 class GridParams(C.Structure):
@@ -89,6 +90,8 @@ def load() -> C.CDLL:
     lib.pnr_query_raypos.argtypes = [vp, vp, i64, i32, i32, i32, f32, vp, vp, vp, vp, vp, sz, vp]
     lib.pnr_render_workspace_bytes.restype = sz
     lib.pnr_render_workspace_bytes.argtypes = [i64, i64, i32]
+    lib.pnr_render_workspace_bytes_for.restype = sz
+    lib.pnr_render_workspace_bytes_for.argtypes = [vp, C.POINTER(RenderOpts), i64, i64]
     lib.pnr_render.argtypes = [vp, vp, vp, i64, C.POINTER(CameraC), vp, C.POINTER(RenderOpts), vp, vp, vp, vp, vp,
                                vp, sz, i64, vp]
     lib.pnr_render_views.argtypes = [vp, vp, vp, i64, C.POINTER(CameraC), i32, vp, i64, vp, C.POINTER(RenderOpts), vp, vp,
@@ -97,11 +100,11 @@ def load() -> C.CDLL:
     lib.pnr_profile_enable.argtypes = [C.c_int]
     lib.pnr_profile_calls.restype = C.c_int64
     lib.pnr_profile_calls.argtypes = []
-    lib.pnr_profile_read.argtypes = [C.c_int64, C.POINTER(C.c_float * 5)]
+    lib.pnr_profile_read.argtypes = [C.c_int64, C.POINTER(C.c_float * NUM_STAGES)]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("pnr_last_error", "pnr_query_workspace_bytes", "pnr_render_workspace_bytes",
-                        "pnr_profile_calls", "pnr_jitter_uniform"):
+                        "pnr_render_workspace_bytes_for", "pnr_profile_calls", "pnr_jitter_uniform"):
             fn.restype = C.c_int
     _lib = lib
     return lib

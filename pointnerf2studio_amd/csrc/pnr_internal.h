@@ -180,6 +180,8 @@ struct pnr_weights {
     // offsets into buf
     size_t w_off[9] = {0};    // fp32 A-operand order (layers) / plain (heads)
     size_t w16_off[9] = {0};  // bf16 hi/lo tiles (layers)
+    size_t w16a_off = 0;      // mlp_base layer 0, point-only inputs [0:224]: 8 tiles x 14 k-steps
+    size_t w16b_off = 0;      // mlp_base layer 0, pair inputs [224:284]: 4 ring tiles x (2 row blocks x 4 k-steps)
     size_t b_off[9] = {0};
     float Rw2c[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
 };
@@ -209,13 +211,22 @@ struct RenderWs {
     float *smp_sigma;  // [cap] by valid index
     float *agg;        // [cap, 256] by valid index
     float4 *smp_out;   // [cap]
-    int *n_sel;        // device ints: [0]=S_sel (clamped to cap), [1]=S_valid, [2]=R
+    int *n_sel;        // device ints: [0]=S_sel (clamped to cap), [1]=S_valid, [2]=R, [3]=U unique neighbour points
     unsigned long long *shards;  // statistics counters, SHARDS x 128-byte lines per counter (see shard_add)
     Camera *cams;                // [PNR_MAX_CAMS] cameras of the call
     void *scan_temp;
-    size_t total;
+    size_t total;       // bytes without the point-part buffers below
+    // bf16x3 mode, factorised first layer (see k_point_part): only when carved with N > 0
+    int *pt_flag;       // [N]    1 = point is a neighbour of some sample of this call
+    int *pt_rank;       // [N+1]  exclusive scan of pt_flag = row of the point in pt_table; [N] = U
+    int *pt_list;       // [u_cap] unique neighbour points, ascending point index
+    void *pt_scan_temp;
+    float *pt_table;    // [u_cap, 256] W1[:, 0:224] . [emb, PE(emb)] + b1 in accumulator order
+    int64_t u_cap;
+    size_t total_pt;    // bytes including them
 };
-RenderWs carve_render_ws(void *base, int64_t R, int64_t cap, int K);
+// N = 0: no point-part buffers (query-only and fp32 workspaces)
+RenderWs carve_render_ws(void *base, int64_t R, int64_t cap, int K, int64_t N = 0, int64_t n_list = 0);
 
 // Statistics counters (rays hit, pairs, candidates, rays kept) are summed with atomics that nothing waits for.
 // One word saturates at ~88 atomics/us on MI355X: 128k waves adding to ONE counter cost 1.5 ms of a 20 ms frame.
@@ -238,9 +249,10 @@ int launch_select_expand(const GridView &g, const CamRef &cr, const float *d_dir
                          int64_t R, int D, int SR, int64_t cap, RenderWs &ws, int64_t *d_counters,
                          hipStream_t stream);
 int launch_knn(const GridView &g, int K, float radius_limit, RenderWs &ws, int64_t cap, int64_t *d_counters,
-               hipStream_t stream);
+               hipStream_t stream, int64_t N = 0);
 int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr, const float *d_dirs, int K,
-                 int precision, RenderWs &ws, int64_t cap, hipStream_t stream, hipEvent_t ev_between);
+                 int precision, RenderWs &ws, int64_t cap, hipStream_t stream, hipEvent_t ev_points,
+                 hipEvent_t ev_between);
 int launch_composite(const CamRef &cr, const pnr_render_opts_t &opts, int64_t R, RenderWs &ws, float *d_rgb,
                      float *d_depth, float *d_acc, int8_t *d_ray_mask, int64_t *d_counters,
                      hipStream_t stream);

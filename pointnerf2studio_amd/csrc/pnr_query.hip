@@ -21,7 +21,7 @@ constexpr int TPB = 256;
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
-RenderWs carve_render_ws(void *base, int64_t R, int64_t cap, int K)
+RenderWs carve_render_ws(void *base, int64_t R, int64_t cap, int K, int64_t N, int64_t n_list)
 {
     RenderWs ws{};
     size_t off = 0;
@@ -49,6 +49,15 @@ RenderWs carve_render_ws(void *base, int64_t R, int64_t cap, int K)
     ws.smp_sigma = (float *)take((size_t)cap * sizeof(float));
     ws.agg = (float *)take((size_t)cap * 256 * sizeof(float));
     ws.total = off;
+    if (N > 0) {
+        ws.u_cap = std::max<int64_t>(1, std::min<int64_t>(n_list, cap * (int64_t)K));
+        ws.pt_flag = (int *)take((size_t)N * sizeof(int));
+        ws.pt_rank = (int *)take((size_t)(N + 1) * sizeof(int));
+        ws.pt_list = (int *)take((size_t)ws.u_cap * sizeof(int));
+        ws.pt_table = (float *)take((size_t)ws.u_cap * 256 * sizeof(float));
+        ws.pt_scan_temp = take(scan_temp_bytes(N + 1));
+    }
+    ws.total_pt = off;
     return ws;
 }
 
@@ -248,7 +257,7 @@ __global__ void __launch_bounds__(TPB) k_knn(GridView g, int K, float radius_lim
                                               const float4 *__restrict__ smp_loc, const int *__restrict__ smp_ray,
                                               const int *__restrict__ n_sel, int *__restrict__ smp_pidx,
                                               int *__restrict__ smp_valid, int *__restrict__ ray_flag,
-                                              unsigned long long *__restrict__ shards)
+                                              unsigned long long *__restrict__ shards, int *__restrict__ pt_flag)
 {
     const int S = n_sel[0];
     for (int64_t s = (int64_t)blockIdx.x * TPB + threadIdx.x; s < S; s += (int64_t)gridDim.x * TPB) {
@@ -322,6 +331,12 @@ __global__ void __launch_bounds__(TPB) k_knn(GridView g, int K, float radius_lim
 #pragma unroll
         for (int i = 0; i < KMAX; ++i)
             if (i < K) smp_pidx[s * K + i] = out[i];
+        if (pt_flag) {
+            // the set of points this call's shading touches (every writer stores the same value)
+#pragma unroll
+            for (int i = 0; i < KMAX; ++i)
+                if (i < K && out[i] >= 0) pt_flag[out[i]] = 1;
+        }
         const int nn = min(kid, K);
         smp_valid[s] = nn > 0;
         if (nn > 0) {
@@ -413,26 +428,48 @@ int launch_select_expand(const GridView &g, const CamRef &cr, const float *d_dir
     return PNR_OK;
 }
 
+// vs_list-style compaction of the flagged points; publishes U
+__global__ void __launch_bounds__(TPB) k_list_points(int64_t N, const int *__restrict__ pt_flag,
+                                                      const int *__restrict__ pt_rank, int *__restrict__ pt_list,
+                                                      int *__restrict__ n_sel, int64_t *__restrict__ counters)
+{
+    const int64_t p0 = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (p0 == 0) {
+        n_sel[3] = pt_rank[N];
+        counters[PNR_CNT_POINTS_UNIQUE] = pt_rank[N];
+    }
+    for (int64_t p = p0; p < N; p += (int64_t)gridDim.x * TPB)
+        if (pt_flag[p]) pt_list[pt_rank[p]] = (int)p;
+}
+
 int launch_knn(const GridView &g, int K, float radius_limit, RenderWs &ws, int64_t cap, int64_t *d_counters,
-               hipStream_t stream)
+               hipStream_t stream, int64_t N)
 {
     unsigned long long *acc = acc_ptr(ws);
+    int *pt_flag = (N > 0) ? ws.pt_flag : nullptr;
+    if (pt_flag) PNR_HIP_CHECK(hipMemsetAsync(pt_flag, 0, (size_t)N * sizeof(int), stream));
     const float r2 = radius_limit * radius_limit;  // fp32, as cu:410
     // grid-stride over the device-side sample count; enough workgroups to fill the chip
     const unsigned grid = (unsigned)std::min<int64_t>(nblk(cap), 256 * 32);
     if (K <= 8)
         hipLaunchKernelGGL(k_knn<8>, dim3(grid), dim3(TPB), 0, stream, g, K, r2, ws.smp_loc, ws.smp_ray, ws.n_sel,
-                           ws.smp_pidx, ws.smp_valid, ws.ray_flag, acc);
+                           ws.smp_pidx, ws.smp_valid, ws.ray_flag, acc, pt_flag);
     else if (K <= 16)
         hipLaunchKernelGGL(k_knn<16>, dim3(grid), dim3(TPB), 0, stream, g, K, r2, ws.smp_loc, ws.smp_ray, ws.n_sel,
-                           ws.smp_pidx, ws.smp_valid, ws.ray_flag, acc);
+                           ws.smp_pidx, ws.smp_valid, ws.ray_flag, acc, pt_flag);
     else
         hipLaunchKernelGGL(k_knn<32>, dim3(grid), dim3(TPB), 0, stream, g, K, r2, ws.smp_loc, ws.smp_ray, ws.n_sel,
-                           ws.smp_pidx, ws.smp_valid, ws.ray_flag, acc);
+                           ws.smp_pidx, ws.smp_valid, ws.ray_flag, acc, pt_flag);
     int rc = scan_exclusive_i32(ws.smp_valid, ws.smp_voff, cap, ws.n_sel, nullptr, ws.scan_temp, stream);
     if (rc != PNR_OK) return rc;
     hipLaunchKernelGGL(k_compact_valid, dim3(grid), dim3(TPB), 0, stream, ws.smp_valid, ws.smp_voff, ws.n_sel,
                        ws.vs_list, d_counters, acc);
+    if (pt_flag) {
+        rc = scan_exclusive_i32(ws.pt_flag, ws.pt_rank, N, nullptr, nullptr, ws.pt_scan_temp, stream);
+        if (rc != PNR_OK) return rc;
+        hipLaunchKernelGGL(k_list_points, dim3((unsigned)std::min<int64_t>(nblk(N), 256 * 32)), dim3(TPB), 0, stream, N,
+                           ws.pt_flag, ws.pt_rank, ws.pt_list, ws.n_sel, d_counters);
+    }
     PNR_HIP_CHECK(hipGetLastError());
     return PNR_OK;
 }

@@ -150,6 +150,19 @@ extern "C" size_t pnr_render_workspace_bytes(int64_t R, int64_t cap_samples, int
     return carve_render_ws(nullptr, R, cap_samples, K).total;
 }
 
+extern "C" size_t pnr_render_workspace_bytes_for(const pnr_scene_t *scene, const pnr_render_opts_t *opts, int64_t R,
+                                                 int64_t cap_samples)
+{
+    if (!scene || !opts || !scene->built) {
+        set_error("pnr_render_workspace_bytes_for: null argument or scene not built");
+        return 0;
+    }
+    if (R < 1) R = 1;
+    if (cap_samples < 1) cap_samples = 1;
+    if (opts->precision != PNR_PRECISION_BF16X3) return carve_render_ws(nullptr, R, cap_samples, opts->K).total;
+    return carve_render_ws(nullptr, R, cap_samples, opts->K, scene->N, scene->info[2]).total_pt;
+}
+
 static int render_views(const pnr_scene_t *scene, const pnr_weights_t *weights, const float *d_dirs, int64_t R,
                         const pnr_camera_t *cams, int32_t n_cams, const int32_t *d_ray_cam, int64_t rays_per_cam,
                         const float *d_tmid, const pnr_render_opts_t *opts, float *d_rgb, float *d_depth, float *d_acc,
@@ -180,12 +193,15 @@ static int render_views(const pnr_scene_t *scene, const pnr_weights_t *weights, 
                 "%s: unknown precision %d", who, opts->precision);
     PNR_REQUIRE(cap_samples >= 1 && cap_samples < (int64_t)0x7FFFFFF0 / std::max(opts->K, 1),
                 "%s: cap_samples=%lld out of range", who, (long long)cap_samples);
-    const size_t need = pnr_render_workspace_bytes(R, cap_samples, opts->K);
+    const size_t need = pnr_render_workspace_bytes_for(scene, opts, R, cap_samples);
     if (workspace_bytes < need) {
-        set_error("%s: workspace of %zu bytes < %zu required", who, workspace_bytes, need);
+        set_error("%s: workspace of %zu bytes < %zu required (pnr_render_workspace_bytes_for)", who, workspace_bytes,
+                  need);
         return PNR_ERR_WORKSPACE;
     }
-    RenderWs ws = carve_render_ws(d_workspace, R, cap_samples, opts->K);
+    const bool factored = opts->precision == PNR_PRECISION_BF16X3;
+    RenderWs ws = factored ? carve_render_ws(d_workspace, R, cap_samples, opts->K, scene->N, scene->info[2])
+                           : carve_render_ws(d_workspace, R, cap_samples, opts->K);
     CamSet set{};
     for (int c = 0; c < n_cams; ++c) {
         for (int i = 0; i < 3; ++i) set.c[c].o[i] = cams[c].campos[i];
@@ -209,11 +225,13 @@ static int render_views(const pnr_scene_t *scene, const pnr_weights_t *weights, 
                                   stream);
     if (rc != PNR_OK) return rc;
     if (prof) PNR_HIP_CHECK(hipEventRecord(g_ev[1], stream));
-    rc = launch_knn(scene->grid, opts->K, opts->radius_limit, ws, cap_samples, d_counters, stream);
+    rc = launch_knn(scene->grid, opts->K, opts->radius_limit, ws, cap_samples, d_counters, stream,
+                    factored ? scene->N : 0);
     if (rc != PNR_OK) return rc;
     if (prof) PNR_HIP_CHECK(hipEventRecord(g_ev[2], stream));
+    // events in time order: 0 select 1 knn 2 point-part 6 shade-pairs 3 shade-colour 4 composite 5
     rc = launch_shade(scene, weights, cr, d_dirs, opts->K, opts->precision, ws, cap_samples, stream,
-                      prof ? g_ev[3] : nullptr);
+                      prof ? g_ev[6] : nullptr, prof ? g_ev[3] : nullptr);
     if (rc != PNR_OK) return rc;
     if (prof) PNR_HIP_CHECK(hipEventRecord(g_ev[4], stream));
     rc = launch_composite(cr, *opts, R, ws, d_rgb, d_depth, d_acc, d_ray_mask, d_counters, stream);
@@ -266,8 +284,10 @@ extern "C" int pnr_profile_read(int64_t call, float ms[PNR_NUM_STAGES])
         return PNR_ERR_STATE;
     }
     hipEvent_t *g_ev = g_evs[call % PNR_PROFILE_SLOTS];
-    PNR_HIP_CHECK(hipEventSynchronize(g_ev[PNR_NUM_STAGES]));
-    for (int i = 0; i < PNR_NUM_STAGES; ++i) PNR_HIP_CHECK(hipEventElapsedTime(&ms[i], g_ev[i], g_ev[i + 1]));
+    PNR_HIP_CHECK(hipEventSynchronize(g_ev[5]));
+    static const int first[PNR_NUM_STAGES] = {0, 1, 6, 3, 4, 2}, last[PNR_NUM_STAGES] = {1, 2, 3, 4, 5, 6};
+    for (int i = 0; i < PNR_NUM_STAGES; ++i)
+        PNR_HIP_CHECK(hipEventElapsedTime(&ms[i], g_ev[first[i]], g_ev[last[i]]));
     return PNR_OK;
 }
 

@@ -92,6 +92,12 @@ struct ShadeParams {
     float4 *smp_out;   // [S_sel]
     int K;
     long long dbg_off;  // PNR_STAMPS builds: float offset into smp_sigma of the stamp area
+    // bf16x3 mode: factorised first layer
+    size_t w16a_off, w16b_off;
+    const int *pt_rank;     // [N+1] point index -> row of pt_table
+    const int *pt_list;     // [U] rows -> point index
+    float4 *pt_table;       // [u_cap, 8 row blocks, 2 lane halves, 4] float4
+    int u_cap;
 };
 
 __device__ __forceinline__ float4 load_w(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff)
@@ -182,7 +188,7 @@ struct RowCtx {
 // so that the bf16x3 kernel can issue them for the NEXT tile between the layers of the current one (one wave per
 // SIMD cannot hide a vs_list -> smp_pidx -> point-row chain of three HBM/L2 latencies any other way).
 struct RowFetch {
-    int v_idx, slot, s, pidx, ray;
+    int v_idx, slot, s, pidx, ray, urow;
     bool row_ok;
     float4 a0, e0, e1, e2, e3, c0, c1, loc;
     float dirx, diry, dirz;
@@ -199,14 +205,18 @@ __device__ __forceinline__ void fetch_a(const ShadeParams &P, int tile, int lane
     f.v_idx = tile * SPT + wave * SPW + sl;
     f.row_ok = (j < SPW * K) && (f.v_idx < S_valid);
     f.slot = j - sl * K;
-    f.s = f.row_ok ? P.vs_list[f.v_idx] : 0;
+    // unconditional loads at clamped indices: a branch here would end the basic block, and hipcc then sinks the
+    // hi/lo split of the previous layer out of the MFMA shadows into the block behind the branch
+    const int sv = P.vs_list[f.row_ok ? f.v_idx : 0];
+    f.s = f.row_ok ? sv : 0;
 }
 
 template <bool K8>
 __device__ __forceinline__ void fetch_b(const ShadeParams &P, RowFetch &f)
 {
     const int K = K8 ? 8 : P.K;
-    f.pidx = f.row_ok ? P.smp_pidx[(int64_t)f.s * K + f.slot] : -1;
+    const int pv = P.smp_pidx[(int64_t)f.s * K + f.slot];
+    f.pidx = f.row_ok ? pv : -1;
     f.loc = P.smp_loc[f.s];
     f.ray = P.smp_ray[f.s];
 }
@@ -227,42 +237,24 @@ __device__ __forceinline__ void fetch_c(const ShadeParams &P, int lane, RowFetch
     f.dirz = P.dirs[3 * (int64_t)f.ray + 2];
 }
 
-template <bool K8, bool FAST_PE>
-__device__ __forceinline__ void compute_rows(const ShadeParams &P, const RowFetch &f, int lane, float (&x0)[144],
-                                             RowCtx &ctx)
+// bf16x3 mode: the embedding is not needed per pair (its first-layer contribution comes from pt_table)
+__device__ __forceinline__ void fetch_c_pair(const ShadeParams &P, RowFetch &f)
 {
-    const int h = lane >> 5;
-    const int K = K8 ? 8 : P.K;
-    ctx.v_idx = f.v_idx;
-    ctx.row_ok = f.row_ok;
-    ctx.slot = f.slot;
-    const bool valid = f.pidx >= 0;
-    const float4 a0 = f.a0, e0 = f.e0, e1 = f.e1, e2 = f.e2, e3 = f.e3, c0 = f.c0, c1 = f.c1, loc = f.loc;
-    const int ray = f.ray;
-    const float dirx = f.dirx, diry = f.diry, dirz = f.dirz;
-    const Camera cam = load_cam_lanes(P.cr, cam_id(P.cr, ray));
+    const int p = max(f.pidx, 0);
+    const float4 *row = P.point_rows + (int64_t)p * 11;
+    f.a0 = row[0];
+    f.c0 = row[9];
+    f.c1 = row[10];
+    f.urow = min(P.pt_rank[p], P.u_cap - 1);
+    f.dirx = P.dirs[3 * (int64_t)f.ray];
+    f.diry = P.dirs[3 * (int64_t)f.ray + 1];
+    f.dirz = P.dirs[3 * (int64_t)f.ray + 2];
+}
 
-    // dists + inverse-distance weight (studio_model.py:270-286,467-475)
-    const float dwx = a0.x - loc.x, dwy = a0.y - loc.y, dwz = a0.z - loc.z;
-    const float nrm = sqrtf(dwx * dwx + dwy * dwy + dwz * dwz);
-    float wgt = valid ? 1.0f / fmaxf(nrm, 1e-6f) : 0.f;
-    const float wsum = seg_sum<K8>(wgt, K, lane);
-    ctx.wgt = wgt / fmaxf(wsum, 1e-8f);
-
-    float dd[3];
-    if (h == 0) {
-        rot_rows(P.Rw2c, dwx, dwy, dwz, dd[0], dd[1], dd[2]);  // dists[:3] @ Rw2c^T   (studio_model.py:313)
-    } else {
-        float pcx, pcy, pcz, scx, scy, scz;
-        to_cam(cam, a0.x, a0.y, a0.z, pcx, pcy, pcz);
-        to_cam(cam, loc.x, loc.y, loc.z, scx, scy, scz);
-        const float ppx = pcx / pcz, ppy = pcy / pcz, spx = scx / scz, spy = scy / scz;
-        dd[0] = ppx * pcz - spx * scz;
-        dd[1] = ppy * pcz - spy * scz;
-        dd[2] = pcz - scz;
-    }
-    const float e[16] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w,
-                         e2.x, e2.y, e2.z, e2.w, e3.x, e3.y, e3.z, e3.w};
+// the lane's point-only layer-1 inputs: 16 embedding channels and their encodings (x0[0:112])
+template <bool FAST_PE>
+__device__ __forceinline__ void point_inputs(const float (&e)[16], float *x0)
+{
 #pragma unroll
     for (int d = 0; d < 16; ++d) x0[d] = e[d];
 #pragma unroll
@@ -287,6 +279,42 @@ __device__ __forceinline__ void compute_rows(const ShadeParams &P, const RowFetc
             x0[16 + (d * 3 + f) * 2 + 1] = cs;
         }
     }
+}
+
+// the lane's pair inputs: weight, encoded distances (xq[0:32] = x0[112:144]) and the extra head inputs
+template <bool K8, bool FAST_PE>
+__device__ __forceinline__ void pair_inputs(const ShadeParams &P, const RowFetch &f, int lane, float *xq, RowCtx &ctx)
+{
+    const int h = lane >> 5;
+    const int K = K8 ? 8 : P.K;
+    ctx.v_idx = f.v_idx;
+    ctx.row_ok = f.row_ok;
+    ctx.slot = f.slot;
+    const bool valid = f.pidx >= 0;
+    const float4 a0 = f.a0, c0 = f.c0, c1 = f.c1, loc = f.loc;
+    const int ray = f.ray;
+    const float dirx = f.dirx, diry = f.diry, dirz = f.dirz;
+    const Camera cam = load_cam_lanes(P.cr, cam_id(P.cr, ray));
+
+    // dists + inverse-distance weight (studio_model.py:270-286,467-475)
+    const float dwx = a0.x - loc.x, dwy = a0.y - loc.y, dwz = a0.z - loc.z;
+    const float nrm = sqrtf(dwx * dwx + dwy * dwy + dwz * dwz);
+    float wgt = valid ? 1.0f / fmaxf(nrm, 1e-6f) : 0.f;
+    const float wsum = seg_sum<K8>(wgt, K, lane);
+    ctx.wgt = wgt / fmaxf(wsum, 1e-8f);
+
+    float dd[3];
+    if (h == 0) {
+        rot_rows(P.Rw2c, dwx, dwy, dwz, dd[0], dd[1], dd[2]);  // dists[:3] @ Rw2c^T   (studio_model.py:313)
+    } else {
+        float pcx, pcy, pcz, scx, scy, scz;
+        to_cam(cam, a0.x, a0.y, a0.z, pcx, pcy, pcz);
+        to_cam(cam, loc.x, loc.y, loc.z, scx, scy, scz);
+        const float ppx = pcx / pcz, ppy = pcy / pcz, spx = scx / scz, spy = scy / scz;
+        dd[0] = ppx * pcz - spx * scz;
+        dd[1] = ppy * pcz - spy * scz;
+        dd[2] = pcz - scz;
+    }
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         float sn = 0.f, cs = 1.f;
@@ -304,12 +332,12 @@ __device__ __forceinline__ void compute_rows(const ShadeParams &P, const RowFetc
             } else {
                 sincosf(dd[d] * (float)(1 << f), &sn, &cs);
             }
-            x0[112 + (d * 5 + f) * 2 + 0] = sn;
-            x0[112 + (d * 5 + f) * 2 + 1] = cs;
+            xq[(d * 5 + f) * 2 + 0] = sn;
+            xq[(d * 5 + f) * 2 + 1] = cs;
         }
     }
-    x0[142] = 0.f;
-    x0[143] = 0.f;
+    xq[30] = 0.f;
+    xq[31] = 0.f;
 
     // [color(3), dir @ Rw2c^T - view (3), <dir @ Rw2c^T, view> (1)]   (studio_model.py:322-335)
     float sdx, sdy, sdz, vx, vy, vz;
@@ -321,6 +349,16 @@ __device__ __forceinline__ void compute_rows(const ShadeParams &P, const RowFetc
     ctx.ex[1] = h ? dv0 : c0.z;
     ctx.ex[2] = h ? dv2 : dv1;
     ctx.ex[3] = h ? 0.f : dot;
+}
+
+template <bool K8, bool FAST_PE>
+__device__ __forceinline__ void compute_rows(const ShadeParams &P, const RowFetch &f, int lane, float (&x0)[144],
+                                             RowCtx &ctx)
+{
+    const float e[16] = {f.e0.x, f.e0.y, f.e0.z, f.e0.w, f.e1.x, f.e1.y, f.e1.z, f.e1.w,
+                         f.e2.x, f.e2.y, f.e2.z, f.e2.w, f.e3.x, f.e3.y, f.e3.z, f.e3.w};
+    point_inputs<FAST_PE>(e, x0);
+    pair_inputs<K8, FAST_PE>(P, f, lane, x0 + 112, ctx);
 }
 
 template <bool K8, bool FAST_PE>
@@ -364,6 +402,32 @@ __device__ __forceinline__ f32x16 bias_finish(BiasRegs &r, int h)
             acc[4 * q + i] = h ? fhi : flo;
         }
     return acc;
+}
+
+__device__ __forceinline__ void bias_wait(BiasRegs &r)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r.a), "+s"(r.b)::"memory");
+}
+
+// accumulator values 4q .. 4q+3 of the next tile (rows 8q + 4h + i): every lane takes the h = 0 row from the
+// SGPRs, then the upper lane half is overwritten under a half exec mask -- 2 VALU per value instead of the
+// 2 v_mov + v_cndmask a select on two SGPRs costs (one constant-bus operand per VALU on gfx9).
+// The wave runs the dense layers with all 64 lanes active, so exec_lo is restored to -1.
+__device__ __forceinline__ void bias_quarter(const BiasRegs &r, int q4, f32x16 &acc)
+{
+#pragma unroll
+    for (int i = 0; i < 4; i += 2) {
+        const int lo = 8 * q4 + i, hi = lo + 4;
+        const int l0 = lo < 16 ? r.a[lo] : r.b[lo - 16], l1 = lo + 1 < 16 ? r.a[lo + 1] : r.b[lo + 1 - 16];
+        const int h0 = hi < 16 ? r.a[hi] : r.b[hi - 16], h1 = hi + 1 < 16 ? r.a[hi + 1] : r.b[hi + 1 - 16];
+        float a0, a1;
+        asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3\n\ts_mov_b32 exec_lo, 0\n\tv_mov_b32 %0, %4\n\t"
+                     "v_mov_b32 %1, %5\n\ts_mov_b32 exec_lo, -1"
+                     : "=&v"(a0), "=&v"(a1)
+                     : "s"(l0), "s"(l1), "s"(h0), "s"(h1));
+        acc[4 * q4 + i] = a0;
+        acc[4 * q4 + i + 1] = a1;
+    }
 }
 
 // density head + weighted K-aggregation + stores (studio_model.py:337-353)
@@ -669,7 +733,14 @@ struct Ring {
 //   * with SPLIT_OUT the activation + hi/lo split of the PREVIOUS output tile (16 values -> two k-steps of the
 //     next layer's operands) is cut in three and placed BETWEEN the three MFMAs of the first 8 k-steps (an
 //     in-order wave cannot issue VALU work placed behind an MFMA that waits for the matrix pipe).
-template <int KS, int MT, int KS_NX, bool SPLIT_OUT>
+// wait until at most N of the wave's vector-memory operations (LDS-DMA pieces included) are outstanding
+template <int N>
+__device__ __forceinline__ void wait_vm()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int KS, int MT, int KS_NX, bool SPLIT_OUT, bool NX_BIAS = true>
 __device__ __forceinline__ void dense_layer_bf16(__amdgpu_buffer_rsrc_t rsrc, int wbase, int wnx,
                                                  const float *__restrict__ bias, const float *__restrict__ bias_nx,
                                                  int lane, int tid, int wave_u, u32x4 *lds,
@@ -690,6 +761,19 @@ __device__ __forceinline__ void dense_layer_bf16(__amdgpu_buffer_rsrc_t rsrc, in
         f32x16 acc = ring.acc0;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
+            // the scalar bias loads of the next tile (issued S_BI) are awaited BEFORE this k-step's fragment reads
+            // are issued: SMEM returns out of order, so the wait is lgkmcnt(0) and would otherwise expose the
+            // LDS latency of the reads just issued
+            constexpr int S_BF = KS - 4, S_BI = KS >= 12 ? KS - 8 : 0;
+            // NX_BIAS = false: the next layer initialises its accumulators itself (pt_table rows)
+            const bool want_bias = NX_BIAS || m + 1 < MT;
+            if (s == S_BI && want_bias) bias_issue((m + 1 < MT) ? bias + 32 * (m + 1) : bias_nx, breg);
+            if (s == S_BF && want_bias) {
+                const unsigned long long tb0 = stamp();
+                bias_wait(breg);
+                ring.stall_bias += stamp() - tb0;
+            }
+            __builtin_amdgcn_sched_barrier(0);
             // fragments of k-step s+2: of this tile, or of the next tile (published by the mid-tile barrier)
             u32x4 ch, cl;
             if (s + 2 < KS) {
@@ -698,12 +782,6 @@ __device__ __forceinline__ void dense_layer_bf16(__amdgpu_buffer_rsrc_t rsrc, in
             } else {
                 ch = nxt[(2 * (s + 2 - KS)) * 64 + lane];
                 cl = nxt[(2 * (s + 2 - KS) + 1) * 64 + lane];
-            }
-            if (s == KS - 6) bias_issue((m + 1 < MT) ? bias + 32 * (m + 1) : bias_nx, breg);
-            if (s == KS - 1) {
-                const unsigned long long tb0 = stamp();
-                ring.acc0 = bias_finish(breg, h);
-                ring.stall_bias += stamp() - tb0;
             }
             const bf16x8 wh = __builtin_bit_cast(bf16x8, ring.ah);
             const bf16x8 wl = __builtin_bit_cast(bf16x8, ring.al);
@@ -730,6 +808,7 @@ __device__ __forceinline__ void dense_layer_bf16(__amdgpu_buffer_rsrc_t rsrc, in
                 r0 = v0 - (float)h0;
                 r1 = v1 - (float)h1;
             }
+            if (s >= S_BF && want_bias) bias_quarter(breg, s - S_BF, ring.acc0);
             __builtin_amdgcn_sched_barrier(0);
             if (!(PNR_ABLATE & 2)) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[s], acc, 0, 0, 0);
             if (do_split) {
@@ -746,19 +825,17 @@ __device__ __forceinline__ void dense_layer_bf16(__amdgpu_buffer_rsrc_t rsrc, in
             constexpr int S_MID = KS / 2 - 1;
             if (s == S_MID && !(PNR_ABLATE & 8)) {
                 // ---- mid-tile: tile T+1 has landed everywhere, slot of tile T-1 is free ---------------------------
-                if ((m + 2 < MT ? R_SAME : R_NX) == 9)
-                    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-                else if ((m + 2 < MT ? R_SAME : R_NX) == 8)
-                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                if (m + 2 < MT)
+                    wait_vm<R_SAME>();
                 else
-                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    wait_vm<R_NX>();
                 const unsigned long long tb0 = stamp();
-                __builtin_amdgcn_s_barrier();
+                if (!(PNR_ABLATE & 64)) __builtin_amdgcn_s_barrier();
                 ring.stall_bar += stamp() - tb0;
             }
             // ---- DMA of tile T+3 into the freed slot: two 1-KiB pieces per k-step behind the barrier, so the
             //      scalar address arithmetic hides between MFMAs instead of stalling the matrix pipe in one burst
-            if (s > S_MID && !(PNR_ABLATE & 8)) {
+            if (s > S_MID && !(PNR_ABLATE & (8 | 32))) {
                 constexpr int R3 = 0;
                 (void)R3;
                 const int rounds = (m + 3 < MT) ? R_SAME : R_NX;
@@ -796,6 +873,126 @@ __device__ __forceinline__ void dense_layer_bf16(__amdgpu_buffer_rsrc_t rsrc, in
     }
 }
 
+// The pair half of mlp_base layer 0 (bf16x3 mode): inputs [224:284] = the 60 encoded distances (4 k-steps), the
+// point half W1[:, 0:224] . [emb, PE(emb)] + b1 arrives as the initial accumulator (`pin`, gathered from
+// pt_table).  A ring tile holds TWO row blocks of 32 features x 4 k-steps (8 fragment pairs, 16 KiB), so that the
+// barrier / DMA cadence stays at one per 8 k-steps.  The hi/lo split of row block B-1 runs between the MFMAs of
+// k-steps 1..3 of block B (6 + 6 + 4 values): this layer is VALU-paced, not MFMA-paced.
+template <int KS_NX>
+__device__ __forceinline__ void dense_layer1b_bf16(__amdgpu_buffer_rsrc_t rsrc, int wbase, int wnx,
+                                                   const float *__restrict__ bias_nx, int lane, int tid, int wave_u,
+                                                   u32x4 *lds, Ring &ring, const bf16x8 *xh, const bf16x8 *xl,
+                                                   const f32x16 *pin, bf16x8 *yh, bf16x8 *yl)
+{
+    constexpr int KS = 8, MT = 4;
+    constexpr int R_SAME = 4, R_NX = (KS_NX + 1) / 2;
+    f32x16 prev, acc;
+    BiasRegs breg;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const u32x4 *cur = lds + ring.cur * STAGE_U4;
+        const int nxs = ring.cur + 1 >= RING ? ring.cur + 1 - RING : ring.cur + 1;
+        const u32x4 *nxt = lds + nxs * STAGE_U4;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int xs = s & 3, B = 2 * m + (s >> 2);
+            const bool last = m + 1 == MT;
+            if (last && s == 0) bias_issue(bias_nx, breg);
+            if (last && s == 4) bias_wait(breg);
+            __builtin_amdgcn_sched_barrier(0);
+            u32x4 ch, cl;
+            if (s + 2 < KS) {
+                ch = cur[(2 * (s + 2)) * 64 + lane];
+                cl = cur[(2 * (s + 2) + 1) * 64 + lane];
+            } else {
+                ch = nxt[(2 * (s + 2 - KS)) * 64 + lane];
+                cl = nxt[(2 * (s + 2 - KS) + 1) * 64 + lane];
+            }
+            if (xs == 0) acc = pin[B];
+            const bf16x8 wh = __builtin_bit_cast(bf16x8, ring.ah);
+            const bf16x8 wl = __builtin_bit_cast(bf16x8, ring.al);
+            // value pairs of the previous row block handled in this k-step
+            const bool do_split = B > 0 && xs >= 1 && !(PNR_ABLATE & 16);
+            const int p0 = 3 * (xs - 1), np = xs == 3 ? 2 : 3;
+            float v0[3], v1[3], r0[3], r1[3];
+            __bf16 h0[3], h1[3];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[xs], acc, 0, 0, 0);
+            if (do_split) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (q < np) {
+                        v0[q] = leaky(prev[2 * (p0 + q)]);
+                        v1[q] = leaky(prev[2 * (p0 + q) + 1]);
+                        h0[q] = (__bf16)v0[q];
+                        h1[q] = (__bf16)v1[q];
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[xs], acc, 0, 0, 0);
+            if (do_split) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (q < np) {
+                        r0[q] = v0[q] - (float)h0[q];
+                        r1[q] = v1[q] - (float)h1[q];
+                    }
+            }
+            if (last && s >= 4) bias_quarter(breg, s - 4, ring.acc0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[xs], acc, 0, 0, 0);
+            if (do_split) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (q < np) {
+                        const int sp = p0 + q;
+                        const int kk = 2 * (B - 1) + sp / 4, j0 = (2 * sp) % 8;
+                        yh[kk][j0] = h0[q];
+                        yh[kk][j0 + 1] = h1[q];
+                        yl[kk][j0] = (__bf16)r0[q];
+                        yl[kk][j0 + 1] = (__bf16)r1[q];
+                    }
+            }
+            ring.ah = ring.bh;
+            ring.al = ring.bl;
+            ring.bh = ch;
+            ring.bl = cl;
+            if (s == 3 && !(PNR_ABLATE & 8)) {
+                if (m + 2 < MT)
+                    wait_vm<R_SAME>();
+                else
+                    wait_vm<R_NX>();
+                if (!(PNR_ABLATE & 64)) __builtin_amdgcn_s_barrier();
+            }
+            if (s > 3 && !(PNR_ABLATE & (8 | 32))) {
+                const int rounds = (m + 3 < MT) ? R_SAME : R_NX;
+                const int per = (rounds + 3) / 4;  // pieces per k-step (1..3)
+                const int first = per * (s - 4);
+                int slot3 = ring.cur + 3;
+                slot3 = slot3 >= RING ? slot3 - RING : slot3;
+                const int off3 = (m + 3 < MT) ? wbase + (m + 3) * KS * 2048 : wnx + (m + 3 - MT) * KS_NX * 2048;
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (q < per && first + q < rounds) stage_dma_one(rsrc, off3, tid, wave_u, lds, slot3, first + q);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (xs == 3) prev = acc;
+        }
+        ring.cur = nxs;
+    }
+    if (!(PNR_ABLATE & 16)) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float v0 = leaky(prev[2 * s]), v1 = leaky(prev[2 * s + 1]);
+            const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
+            const int kk = 2 * 7 + s / 4, j0 = (2 * s) % 8;
+            yh[kk][j0] = h0;
+            yh[kk][j0 + 1] = h1;
+            yl[kk][j0] = (__bf16)(v0 - (float)h0);
+            yl[kk][j0 + 1] = (__bf16)(v1 - (float)h1);
+        }
+    }
+}
+
 // first three tiles of a chain into slots 0..2, fragments of k-steps 0 and 1 and the first accumulator
 template <int KS0>
 __device__ __forceinline__ void ring_start(__amdgpu_buffer_rsrc_t rsrc, int w_first, const float *__restrict__ bias0,
@@ -812,9 +1009,71 @@ __device__ __forceinline__ void ring_start(__amdgpu_buffer_rsrc_t rsrc, int w_fi
     ring.al = lds[1 * 64 + lane];
     ring.bh = lds[2 * 64 + lane];
     ring.bl = lds[3 * 64 + lane];
-    BiasRegs breg;
-    bias_issue(bias0, breg);
-    ring.acc0 = bias_finish(breg, lane >> 5);
+    if (bias0) {
+        BiasRegs breg;
+        bias_issue(bias0, breg);
+        ring.acc0 = bias_finish(breg, lane >> 5);
+    }
+}
+
+// Point half of mlp_base layer 0 for the U distinct neighbour points of the call (bf16x3 mode):
+//   pt_table[u] = W1[:, 0:224] . [emb_u, PE(emb_u, 3)] + b1          (studio_model.py:309-317, inputs [0:224])
+// The 224 point-only inputs of the 284 are the same for every sample that has the point as a neighbour (~10 pairs
+// per point and frame at BASELINE configs[1]), so this contraction is done once per point and call instead of
+// once per pair; k_shade_pairs_bf16 starts its first layer from the gathered row and multiplies only the 60
+// encoded distances.  Rows are stored in accumulator order [row block][lane half][16] so that a lane picks up its
+// 16 values of a row block with four 16-byte loads.  One wave = 32 points on the MFMA columns, as in the pair kernel.
+__global__ void __launch_bounds__(TPB, 1) k_point_part(ShadeParams P)
+{
+    __shared__ u32x4 lds[LDS_U4];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int j = lane & 31, h = lane >> 5;
+    const int U = min(P.n_sel[3], P.u_cap);
+    constexpr int PPT = 32 * WAVES;
+    const int ntiles = (U + PPT - 1) / PPT;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wbuf), 0, (int)P.wbytes, 0x00020000);
+    const int wa_ = (int)(P.w16a_off * 4);
+    if ((int)blockIdx.x >= ntiles) return;
+    const float *__restrict__ b0 = P.wbuf + P.b_off[0];
+    Ring ring;
+    ring.stall_bar = 0;
+    ring.stall_bias = 0;
+    ring_start<14>(rsrc, wa_, b0, lane, tid, wave_u, lds, ring);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int wa = wa_;
+        asm volatile("" : "+s"(wa));
+        const int u = tile * PPT + wave * 32 + j;
+        const bool ok = u < U;
+        const int pidx = P.pt_list[ok ? u : 0];
+        const float4 *row = P.point_rows + (int64_t)pidx * 11;
+        const float4 e0 = row[1 + 4 * h], e1 = row[2 + 4 * h], e2 = row[3 + 4 * h], e3 = row[4 + 4 * h];
+        bf16x8 xh[14], xl[14];
+        {
+            const float e[16] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w,
+                                 e2.x, e2.y, e2.z, e2.w, e3.x, e3.y, e3.z, e3.w};
+            float x0[112];
+            point_inputs<true>(e, x0);
+#pragma unroll
+            for (int s = 0; s < 14; ++s) split8(&x0[8 * s], xh[s], xl[s]);
+        }
+        float o[128];
+        dense_layer_bf16<14, 8, 14, false>(rsrc, wa, wa, b0, b0, lane, tid, wave_u, lds, ring, xh, xl, nullptr, nullptr,
+                                           o);
+        if (ok) {
+            float4 *dst = P.pt_table + (int64_t)u * 64 + 4 * h;
+#pragma unroll
+            for (int B = 0; B < 8; ++B)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    dst[8 * B + q] = make_float4(o[16 * B + 4 * q], o[16 * B + 4 * q + 1], o[16 * B + 4 * q + 2],
+                                                 o[16 * B + 4 * q + 3]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 template <bool K8>
@@ -833,46 +1092,61 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
     const int t_end = (int)(((int64_t)ntiles * (blockIdx.x + 1)) / gridDim.x);
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wbuf), 0, (int)P.wbytes, 0x00020000);
-    const int w0_ = (int)(P.w16_off[0] * 4), w1_ = (int)(P.w16_off[1] * 4), w2_ = (int)(P.w16_off[2] * 4),
+    const int wb_ = (int)(P.w16b_off * 4), w1_ = (int)(P.w16_off[1] * 4), w2_ = (int)(P.w16_off[2] * 4),
               w3_ = (int)(P.w16_off[3] * 4);
     if (t_begin >= t_end) return;  // uniform per workgroup
-    const float *__restrict__ b0 = P.wbuf + P.b_off[0];
     const float *__restrict__ b1 = P.wbuf + P.b_off[1];
     const float *__restrict__ b2 = P.wbuf + P.b_off[2];
     const float *__restrict__ b3 = P.wbuf + P.b_off[3];
     Ring ring;
     ring.stall_bar = 0;
     ring.stall_bias = 0;
-    ring_start<18>(rsrc, w0_, b0, lane, tid, wave_u, lds, ring);
+    ring_start<8>(rsrc, wb_, nullptr, lane, tid, wave_u, lds, ring);
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     RowFetch cur, nxt;
     fetch_a<K8>(P, t_begin, lane, wave, S_valid, cur);
     fetch_b<K8>(P, cur);
-    fetch_c(P, lane, cur);
+    fetch_c_pair(P, cur);
     for (int tile = t_begin; tile < t_end; ++tile) {
-        int w0 = w0_, w1 = w1_, w2 = w2_, w3 = w3_;
-        asm volatile("" : "+s"(w0), "+s"(w1), "+s"(w2), "+s"(w3));
+        int wb = wb_, w1 = w1_, w2 = w2_, w3 = w3_;
+        asm volatile("" : "+s"(wb), "+s"(w1), "+s"(w2), "+s"(w3));
         const unsigned long long ts0 = stamp();
-        RowCtx ctx;
-        bf16x8 xh[18], xl[18];
+        // point halves of layer 1 (pt_table rows, accumulator order): issued first, they land while the distances
+        // are encoded
+        f32x16 pin[8];
         {
-            float x0[144];
-            compute_rows<K8, true>(P, cur, lane, x0, ctx);
-            (void)ts0;
+            const float4 *trow = P.pt_table + (int64_t)cur.urow * 64 + 4 * (lane >> 5);
 #pragma unroll
-            for (int s = 0; s < 18; ++s) split8(&x0[8 * s], xh[s], xl[s]);
+            for (int B = 0; B < 8; ++B)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = trow[8 * B + q];
+                    pin[B][4 * q] = v.x;
+                    pin[B][4 * q + 1] = v.y;
+                    pin[B][4 * q + 2] = v.z;
+                    pin[B][4 * q + 3] = v.w;
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        RowCtx ctx;
+        bf16x8 xqh[4], xql[4];
+        {
+            float xq[32];
+            pair_inputs<K8, true>(P, cur, lane, xq, ctx);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) split8(&xq[8 * s], xqh[s], xql[s]);
         }
         const unsigned long long ts1 = stamp();
         // the next tile's gather, one dependent level per layer boundary (a tile past the end loads row 0: harmless)
         fetch_a<K8>(P, tile + 1, lane, wave, S_valid, nxt);
-        bf16x8 yh[17], yl[17];
-        dense_layer_bf16<18, 8, 16, true>(rsrc, w0, w1, b0, b1, lane, tid, wave_u, lds, ring, xh, xl, yh, yl, nullptr);
+        bf16x8 xh[17], xl[17], yh[17], yl[17];
+        dense_layer1b_bf16<16>(rsrc, wb, w1, b1, lane, tid, wave_u, lds, ring, xqh, xql, pin, yh, yl);
         const unsigned long long ts2 = stamp();
         fetch_b<K8>(P, nxt);
-        // xh/xl are free again: they receive layer 2's output (+ the 7 extra head inputs as k-step 16)
+        // layer 2's output (+ the 7 extra head inputs as k-step 16) goes to xh/xl
         dense_layer_bf16<16, 8, 17, true>(rsrc, w1, w2, b1, b2, lane, tid, wave_u, lds, ring, yh, yl, xh, xl, nullptr);
         const unsigned long long ts3 = stamp();
-        fetch_c(P, lane, nxt);
+        fetch_c_pair(P, nxt);
         {
             float v[8] = {ctx.ex[0], ctx.ex[1], ctx.ex[2], ctx.ex[3], 0.f, 0.f, 0.f, 0.f};
             split8(v, xh[16], xl[16]);
@@ -880,9 +1154,10 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
         dense_layer_bf16<17, 8, 16, true>(rsrc, w2, w3, b2, b3, lane, tid, wave_u, lds, ring, xh, xl, yh, yl, nullptr);
         const unsigned long long ts4 = stamp();
         float o[128];
-        // the chain wraps around: the next pair tile starts again with layer 0
-        dense_layer_bf16<16, 8, 18, false>(rsrc, w3, w0, b3, b0, lane, tid, wave_u, lds, ring, yh, yl, nullptr, nullptr,
-                                           o);
+        // the chain wraps around: the next pair tile starts again with the pair half of layer 0, whose accumulators
+        // come from pt_table (no bias prefetch)
+        dense_layer_bf16<16, 8, 8, false, false>(rsrc, w3, wb, b3, nullptr, lane, tid, wave_u, lds, ring, yh, yl,
+                                                 nullptr, nullptr, o);
         const unsigned long long ts5 = stamp();
 #pragma unroll
         for (int i = 0; i < 128; ++i) o[i] = leaky(o[i]);
@@ -1070,18 +1345,20 @@ __global__ void k_pack_layer(const float *__restrict__ W, int n_out, int n_in, i
     }
 }
 
-__global__ void k_pack_layer_bf16(const float *__restrict__ W, int n_out, int n_in, int kind, int ks,
+__global__ void k_pack_layer_bf16(const float *__restrict__ W, int n_out, int n_in, int kind, int ks, int kx, int s0,
                                   unsigned short *__restrict__ dst)
 {
-    // dst[(((m*KS + s)*2 + plane)*64 + lane)*8 + j] = {hi, lo}(W[32m + (lane&31)][feat16(s, lane>>5, j)])
-    const int mt = n_out / 32;
+    // dst[(((m*KS + s)*2 + plane)*64 + lane)*8 + j] = {hi, lo}(W[32 rb + (lane&31)][feat16(s0 + s % kx, lane>>5, j)])
+    // a ring tile m holds ks / kx row blocks rb = m * (ks / kx) + s / kx of kx k-steps each (kx == ks: one)
+    const int mt = n_out / 32 / (ks / kx);
     const int64_t total = (int64_t)mt * ks * 64 * 8;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
         const int64_t ms = i >> 9;
         const int s = (int)(ms % ks), m = (int)(ms / ks);
-        const int f = feat16_of(kind, s, lane >> 5, j, n_in);
-        const float w = (f >= 0 && f < n_in) ? W[(int64_t)(32 * m + (lane & 31)) * n_in + f] : 0.f;
+        const int f = feat16_of(kind, s0 + s % kx, lane >> 5, j, n_in);
+        const int rb = m * (ks / kx) + s / kx;
+        const float w = (f >= 0 && f < n_in) ? W[(int64_t)(32 * rb + (lane & 31)) * n_in + f] : 0.f;
         const __bf16 hb = (__bf16)w;
         const __bf16 lb = (__bf16)(w - (float)hb);
         const int64_t base = ((ms * 2) * 64 + lane) * 8 + j;
@@ -1097,7 +1374,8 @@ __global__ void k_copy(const float *__restrict__ src, int n, float *__restrict__
 }
 
 int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr, const float *d_dirs, int K,
-                 int precision, RenderWs &ws, int64_t cap, hipStream_t stream, hipEvent_t ev_between)
+                 int precision, RenderWs &ws, int64_t cap, hipStream_t stream, hipEvent_t ev_points,
+                 hipEvent_t ev_between)
 {
     ShadeParams P{};
     P.point_rows = reinterpret_cast<const float4 *>(scene->point_rows);
@@ -1121,6 +1399,12 @@ int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr,
     P.smp_out = ws.smp_out;
     P.K = K;
     P.dbg_off = cap - 8192;
+    P.w16a_off = w->w16a_off;
+    P.w16b_off = w->w16b_off;
+    P.pt_rank = ws.pt_rank;
+    P.pt_list = ws.pt_list;
+    P.pt_table = reinterpret_cast<float4 *>(ws.pt_table);
+    P.u_cap = (int)ws.u_cap;
     int dev = 0, cus = 256;
     PNR_HIP_CHECK(hipGetDevice(&dev));
     PNR_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -1130,6 +1414,16 @@ int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr,
     const int64_t max_tiles = (cap + spt - 1) / spt;
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cus, max_tiles));
     const bool bf = precision == PNR_PRECISION_BF16X3;
+    if (bf) {
+        if (!ws.pt_table) {
+            set_error("launch_shade: bf16x3 mode needs the point-part workspace");
+            return PNR_ERR_WORKSPACE;
+        }
+        const int64_t ptiles = (ws.u_cap + 32 * WAVES - 1) / (32 * WAVES);
+        hipLaunchKernelGGL(k_point_part, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(cus, ptiles))), dim3(TPB),
+                           0, stream, P);
+    }
+    if (ev_points) PNR_HIP_CHECK(hipEventRecord(ev_points, stream));
     if (K == 8) {
         if (bf)
             hipLaunchKernelGGL(k_shade_pairs_bf16<true>, dim3(grid), dim3(TPB), 0, stream, P);
@@ -1193,6 +1487,11 @@ extern "C" int pnr_weights_pack(pnr_weights_t *w, const float *const d_w[9], con
         // [mt][ks][2 planes][64 lanes][8 bf16] = mt * ks * 2048 bytes = mt * ks * 512 floats
         off += ks16[i] ? pad((size_t)(n_out[i] / 32) * ks16[i] * 512) : 0;
     }
+    // mlp_base layer 0 split for the bf16x3 mode: point-only k-steps 0..13 and pair k-steps 14..17
+    w->w16a_off = off;
+    off += pad((size_t)8 * 14 * 512);
+    w->w16b_off = off;
+    off += pad((size_t)4 * 8 * 512);
     for (int i = 0; i < 9; ++i) {
         w->b_off[i] = off;
         off += pad((size_t)n_out[i]);
@@ -1210,7 +1509,7 @@ extern "C" int pnr_weights_pack(pnr_weights_t *w, const float *const d_w[9], con
             hipLaunchKernelGGL(k_pack_layer, dim3(256), dim3(256), 0, stream, d_w[i], n_out[i], n_in[i], kind[i],
                                ksp[i], w->buf + w->w_off[i]);
             hipLaunchKernelGGL(k_pack_layer_bf16, dim3(256), dim3(256), 0, stream, d_w[i], n_out[i], n_in[i], kind[i],
-                               ks16[i], reinterpret_cast<unsigned short *>(w->buf + w->w16_off[i]));
+                               ks16[i], ks16[i], 0, reinterpret_cast<unsigned short *>(w->buf + w->w16_off[i]));
         } else {
             int n = n_out[i] * n_in[i];
             hipLaunchKernelGGL(k_copy, dim3((n + 255) / 256), dim3(256), 0, stream, d_w[i], n, w->buf + w->w_off[i]);
@@ -1218,6 +1517,10 @@ extern "C" int pnr_weights_pack(pnr_weights_t *w, const float *const d_w[9], con
         hipLaunchKernelGGL(k_copy, dim3((n_out[i] + 255) / 256), dim3(256), 0, stream, d_b[i], n_out[i],
                            w->buf + w->b_off[i]);
     }
+    hipLaunchKernelGGL(k_pack_layer_bf16, dim3(256), dim3(256), 0, stream, d_w[0], 256, 284, (int)L_BASE0, 14, 14, 0,
+                       reinterpret_cast<unsigned short *>(w->buf + w->w16a_off));
+    hipLaunchKernelGGL(k_pack_layer_bf16, dim3(256), dim3(256), 0, stream, d_w[0], 256, 284, (int)L_BASE0, 8, 4, 14,
+                       reinterpret_cast<unsigned short *>(w->buf + w->w16b_off));
     PNR_HIP_CHECK(hipGetLastError());
     PNR_HIP_CHECK(hipMemcpyAsync(w->Rw2c, d_Rw2c, 9 * sizeof(float), hipMemcpyDeviceToHost, stream));
     PNR_HIP_CHECK(hipStreamSynchronize(stream));

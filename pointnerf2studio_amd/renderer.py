@@ -242,8 +242,10 @@ class RendererHIP:
 
     def _workspace(self, R: int, cap: int, dev):
         key = (R, cap, self.opts.K)
-        if self._ws is None or self._ws_key != key:
-            nbytes = self.lib.pnr_render_workspace_bytes(R, cap, self.opts.K)
+        nbytes = self.lib.pnr_render_workspace_bytes_for(self.scene.handle, C.byref(self.opts), R, cap)
+        if nbytes == 0:
+            raise RuntimeError("pnr_render_workspace_bytes_for: " + self.lib.pnr_last_error().decode())
+        if self._ws is None or self._ws_key != key or self._ws.numel() < nbytes:
             self._ws = None
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             self._ws_key = key

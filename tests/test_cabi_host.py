@@ -57,6 +57,9 @@ def test_workspace_sizes_are_monotonic(lib):
     assert b - a >= 10000 * 1024
     q = lib.pnr_query_workspace_bytes(1000, 400, 80, 8)
     assert 0 < q < lib.pnr_render_workspace_bytes(1000, 80000, 8)
+    # the scene-dependent size (bf16x3 point table) needs a built scene: fails loudly without one
+    assert lib.pnr_render_workspace_bytes_for(None, None, 1000, 10000) == 0
+    assert b"pnr_render_workspace_bytes_for" in lib.pnr_last_error()
 
 
 def test_host_tensors_are_rejected_not_silently_computed():
