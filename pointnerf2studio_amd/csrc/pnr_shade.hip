@@ -188,7 +188,7 @@ struct RowCtx {
 // so that the bf16x3 kernel can issue them for the NEXT tile between the layers of the current one (one wave per
 // SIMD cannot hide a vs_list -> smp_pidx -> point-row chain of three HBM/L2 latencies any other way).
 struct RowFetch {
-    int v_idx, slot, s, pidx, ray, urow;
+    int v_idx, slot, s, pidx, ray, urow, cid;
     bool row_ok;
     float4 a0, e0, e1, e2, e3, c0, c1, loc;
     float dirx, diry, dirz;
@@ -207,14 +207,15 @@ __device__ __forceinline__ void fetch_a(const ShadeParams &P, int tile, int lane
     f.slot = j - sl * K;
     // unconditional loads at clamped indices: a branch here would end the basic block, and hipcc then sinks the
     // hi/lo split of the previous layer out of the MFMA shadows into the block behind the branch
-    const int sv = P.vs_list[f.row_ok ? f.v_idx : 0];
-    f.s = f.row_ok ? sv : 0;
+    // (the select on row_ok happens in fetch_b: here it would put a wait for this load right behind its issue)
+    f.s = P.vs_list[f.row_ok ? f.v_idx : 0];
 }
 
 template <bool K8>
 __device__ __forceinline__ void fetch_b(const ShadeParams &P, RowFetch &f)
 {
     const int K = K8 ? 8 : P.K;
+    f.s = f.row_ok ? f.s : 0;
     const int pv = P.smp_pidx[(int64_t)f.s * K + f.slot];
     f.pidx = f.row_ok ? pv : -1;
     f.loc = P.smp_loc[f.s];
@@ -237,6 +238,57 @@ __device__ __forceinline__ void fetch_c(const ShadeParams &P, int lane, RowFetch
     f.dirz = P.dirs[3 * (int64_t)f.ray + 2];
 }
 
+// Camera of a wavefront whose rays all belong to camera cid0, through the scalar cache.  (hipcc emits VECTOR loads
+// for load_cam even at a uniform address -- the kernel stores to global memory -- and vector loads return in
+// order: behind the 32 pt_table gathers of the tile they would expose the whole gather latency.)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ Camera load_cam_scalar(const CamRef &cr, int cid0)
+{
+    const float *p = reinterpret_cast<const float *>(cr.cams + cid0);
+    i32x4 a, b, c;
+    asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x10\n\ts_load_dwordx4 %2, %3, 0x20\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b), "=&s"(c)
+                 : "s"(p)
+                 : "memory");
+    Camera cam;
+    cam.o[0] = __int_as_float(a.x);
+    cam.o[1] = __int_as_float(a.y);
+    cam.o[2] = __int_as_float(a.z);
+    cam.R[0] = __int_as_float(a.w);
+    cam.R[1] = __int_as_float(b.x);
+    cam.R[2] = __int_as_float(b.y);
+    cam.R[3] = __int_as_float(b.z);
+    cam.R[4] = __int_as_float(b.w);
+    cam.R[5] = __int_as_float(c.x);
+    cam.R[6] = __int_as_float(c.y);
+    cam.R[7] = __int_as_float(c.z);
+    cam.R[8] = __int_as_float(c.w);
+    return cam;
+}
+__device__ __forceinline__ Camera load_cam_wave(const CamRef &cr, int cid)
+{
+    const int cid0 = __builtin_amdgcn_readfirstlane(cid);
+    if (__all(cid == cid0)) return load_cam_scalar(cr, cid0);
+    // a wavefront straddling two ray bundles (rare): per-lane loads, retired inside this branch so that the join
+    // carries no pending vector load (hipcc would wait vmcnt(0) there on every tile)
+    Camera c = load_cam(cr, cid);
+    asm volatile("" ::"v"(c.o[0]), "v"(c.o[1]), "v"(c.o[2]), "v"(c.R[0]), "v"(c.R[1]), "v"(c.R[2]), "v"(c.R[3]),
+                 "v"(c.R[4]), "v"(c.R[5]), "v"(c.R[6]), "v"(c.R[7]), "v"(c.R[8]));
+    return c;
+}
+
+// branch-free camera index of a ray (cam_id() branches; a branch between the layers would split their basic block)
+__device__ __forceinline__ int cam_id_flat(const CamRef &cr, const int *valid_ints, int ray)
+{
+    const int *src = cr.ray_cam ? cr.ray_cam + ray : valid_ints;
+    const int listed = *src;
+    const unsigned rpc = (unsigned)max((long long)1, (long long)cr.rays_per_cam);
+    const int by_div = (int)((unsigned)ray / rpc);
+    const int cid = cr.ray_cam ? listed : by_div;
+    return cr.n_cams <= 1 ? 0 : cid;
+}
+
 // bf16x3 mode: the embedding is not needed per pair (its first-layer contribution comes from pt_table)
 __device__ __forceinline__ void fetch_c_pair(const ShadeParams &P, RowFetch &f)
 {
@@ -246,6 +298,7 @@ __device__ __forceinline__ void fetch_c_pair(const ShadeParams &P, RowFetch &f)
     f.c0 = row[9];
     f.c1 = row[10];
     f.urow = min(P.pt_rank[p], P.u_cap - 1);
+    f.cid = cam_id_flat(P.cr, P.n_sel, f.ray);
     f.dirx = P.dirs[3 * (int64_t)f.ray];
     f.diry = P.dirs[3 * (int64_t)f.ray + 1];
     f.dirz = P.dirs[3 * (int64_t)f.ray + 2];
@@ -283,7 +336,8 @@ __device__ __forceinline__ void point_inputs(const float (&e)[16], float *x0)
 
 // the lane's pair inputs: weight, encoded distances (xq[0:32] = x0[112:144]) and the extra head inputs
 template <bool K8, bool FAST_PE>
-__device__ __forceinline__ void pair_inputs(const ShadeParams &P, const RowFetch &f, int lane, float *xq, RowCtx &ctx)
+__device__ __forceinline__ void pair_inputs(const ShadeParams &P, const RowFetch &f, const Camera &cam, int lane,
+                                            float *xq, RowCtx &ctx)
 {
     const int h = lane >> 5;
     const int K = K8 ? 8 : P.K;
@@ -292,9 +346,7 @@ __device__ __forceinline__ void pair_inputs(const ShadeParams &P, const RowFetch
     ctx.slot = f.slot;
     const bool valid = f.pidx >= 0;
     const float4 a0 = f.a0, c0 = f.c0, c1 = f.c1, loc = f.loc;
-    const int ray = f.ray;
     const float dirx = f.dirx, diry = f.diry, dirz = f.dirz;
-    const Camera cam = load_cam_lanes(P.cr, cam_id(P.cr, ray));
 
     // dists + inverse-distance weight (studio_model.py:270-286,467-475)
     const float dwx = a0.x - loc.x, dwy = a0.y - loc.y, dwz = a0.z - loc.z;
@@ -358,7 +410,8 @@ __device__ __forceinline__ void compute_rows(const ShadeParams &P, const RowFetc
     const float e[16] = {f.e0.x, f.e0.y, f.e0.z, f.e0.w, f.e1.x, f.e1.y, f.e1.z, f.e1.w,
                          f.e2.x, f.e2.y, f.e2.z, f.e2.w, f.e3.x, f.e3.y, f.e3.z, f.e3.w};
     point_inputs<FAST_PE>(e, x0);
-    pair_inputs<K8, FAST_PE>(P, f, lane, x0 + 112, ctx);
+    const Camera cam = load_cam_lanes(P.cr, cam_id(P.cr, f.ray));
+    pair_inputs<K8, FAST_PE>(P, f, cam, lane, x0 + 112, ctx);
 }
 
 template <bool K8, bool FAST_PE>
@@ -384,7 +437,8 @@ struct BiasRegs {
 
 __device__ __forceinline__ void bias_issue(const float *bias32, BiasRegs &r)
 {
-    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=s"(r.a), "=s"(r.b) : "s"(bias32) : "memory");
+    // early-clobber outputs: a destination tuple must not overlap the address pair the second load still reads
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=&s"(r.a), "=&s"(r.b) : "s"(bias32) : "memory");
 }
 
 __device__ __forceinline__ f32x16 bias_finish(BiasRegs &r, int h)
@@ -421,9 +475,11 @@ __device__ __forceinline__ void bias_quarter(const BiasRegs &r, int q4, f32x16 &
         const int l0 = lo < 16 ? r.a[lo] : r.b[lo - 16], l1 = lo + 1 < 16 ? r.a[lo + 1] : r.b[lo + 1 - 16];
         const int h0 = hi < 16 ? r.a[hi] : r.b[hi - 16], h1 = hi + 1 < 16 ? r.a[hi + 1] : r.b[hi + 1 - 16];
         float a0, a1;
-        asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3\n\ts_mov_b32 exec_lo, 0\n\tv_mov_b32 %0, %4\n\t"
-                     "v_mov_b32 %1, %5\n\ts_mov_b32 exec_lo, -1"
-                     : "=&v"(a0), "=&v"(a1)
+        // straight into accumulator registers (hipcc keeps MFMA accumulators of this kernel in AGPRs: a VGPR result
+        // would cost a v_accvgpr_write per value at the tile boundary)
+        asm volatile("v_accvgpr_write_b32 %0, %2\n\tv_accvgpr_write_b32 %1, %3\n\ts_mov_b32 exec_lo, 0\n\t"
+                     "v_accvgpr_write_b32 %0, %4\n\tv_accvgpr_write_b32 %1, %5\n\ts_mov_b32 exec_lo, -1"
+                     : "=&a"(a0), "=&a"(a1)
                      : "s"(l0), "s"(l1), "s"(h0), "s"(h1));
         acc[4 * q4 + i] = a0;
         acc[4 * q4 + i + 1] = a1;
@@ -740,12 +796,19 @@ __device__ __forceinline__ void wait_vm()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int KS, int MT, int KS_NX, bool SPLIT_OUT, bool NX_BIAS = true>
+struct NoHook {
+    __device__ __forceinline__ void operator()(int, int) const {}
+};
+
+// `hook(m, s)` runs at the end of k-step s of tile m, inside that k-step's scheduling region: the place for loads
+// that must be issued a few at a time between MFMAs (a burst of scattered loads blocks the wave at issue).
+template <int KS, int MT, int KS_NX, bool SPLIT_OUT, bool NX_BIAS = true, bool OUT_LEAKY = false,
+          typename Hook = NoHook>
 __device__ __forceinline__ void dense_layer_bf16(__amdgpu_buffer_rsrc_t rsrc, int wbase, int wnx,
                                                  const float *__restrict__ bias, const float *__restrict__ bias_nx,
                                                  int lane, int tid, int wave_u, u32x4 *lds,
                                                  Ring &ring, const bf16x8 *xh, const bf16x8 *xl, bf16x8 *yh,
-                                                 bf16x8 *yl, float *outf)
+                                                 bf16x8 *yl, float *outf, Hook hook = Hook())
 {
     static_assert(KS >= 8, "the split of the previous tile is spread over 8 k-steps");
     static_assert(MT >= 3, "the DMA runs three tiles ahead");
@@ -802,6 +865,12 @@ __device__ __forceinline__ void dense_layer_bf16(__amdgpu_buffer_rsrc_t rsrc, in
                 h0 = (__bf16)v0;
                 h1 = (__bf16)v1;
             }
+            // without SPLIT_OUT the previous tile's accumulators leave for `outf` the same way (two per k-step, in
+            // the MFMA shadow) instead of in one burst behind the tile's last MFMA, which would wait for it to retire
+            if (!SPLIT_OUT && m > 0 && s >= S0 && s < S0 + 8) {
+                outf[(m - 1) * 16 + 2 * sp] = OUT_LEAKY ? leaky(prev[2 * sp]) : prev[2 * sp];
+                outf[(m - 1) * 16 + 2 * sp + 1] = OUT_LEAKY ? leaky(prev[2 * sp + 1]) : prev[2 * sp + 1];
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (!(PNR_ABLATE & 2)) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[s], acc, 0, 0, 0);
             if (do_split) {
@@ -849,15 +918,15 @@ __device__ __forceinline__ void dense_layer_bf16(__amdgpu_buffer_rsrc_t rsrc, in
                 for (int q = 0; q < 3; ++q)
                     if (q < per && first + q < rounds) stage_dma_one(rsrc, off3, tid, wave_u, lds, slot3, first + q);
             }
+            hook(m, s);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (SPLIT_OUT) {
-            prev = acc;
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) outf[m * 16 + r] = acc[r];
-        }
+        prev = acc;
         ring.cur = nxs;
+    }
+    if (!SPLIT_OUT) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) outf[(MT - 1) * 16 + r] = OUT_LEAKY ? leaky(prev[r]) : prev[r];
     }
     if (SPLIT_OUT && !(PNR_ABLATE & 16)) {
 #pragma unroll
@@ -1107,17 +1176,30 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
     fetch_a<K8>(P, t_begin, lane, wave, S_valid, cur);
     fetch_b<K8>(P, cur);
     fetch_c_pair(P, cur);
+    f32x16 pin_pre[4];
     for (int tile = t_begin; tile < t_end; ++tile) {
         int wb = wb_, w1 = w1_, w2 = w2_, w3 = w3_;
         asm volatile("" : "+s"(wb), "+s"(w1), "+s"(w2), "+s"(w3));
         const unsigned long long ts0 = stamp();
-        // point halves of layer 1 (pt_table rows, accumulator order): issued first, they land while the distances
-        // are encoded
+        const Camera cam = load_cam_wave(P.cr, cur.cid);
+        // first level of the next tile's gather chain (a tile past the end loads row 0: harmless); the other two
+        // levels follow at the layer boundaries
+        fetch_a<K8>(P, tile + 1, lane, wave, S_valid, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        // Point halves of layer 1 (pt_table rows, accumulator order).  A lane reads 512 B in 32 scattered 16-byte
+        // loads; 4 waves x 32 of them keep the CU's texture-address unit busy for ~7k cycles (tools/ub_gather.hip)
+        // and block the issuing wave meanwhile.  Row blocks 0..3 were therefore issued two at a time between the
+        // MFMAs of the previous tile's last layer (pin_pre); row blocks 4..7 are issued here and land while the
+        // distances are encoded and the first half of layer 1 runs.
         f32x16 pin[8];
         {
             const float4 *trow = P.pt_table + (int64_t)cur.urow * 64 + 4 * (lane >> 5);
 #pragma unroll
-            for (int B = 0; B < 8; ++B)
+            for (int B = 0; B < 8; ++B) {
+                if (B < 4 && tile != t_begin) {
+                    pin[B] = pin_pre[B];
+                    continue;
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float4 v = trow[8 * B + q];
@@ -1126,19 +1208,19 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
                     pin[B][4 * q + 2] = v.z;
                     pin[B][4 * q + 3] = v.w;
                 }
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long tsg = stamp();
         RowCtx ctx;
         bf16x8 xqh[4], xql[4];
         {
             float xq[32];
-            pair_inputs<K8, true>(P, cur, lane, xq, ctx);
+            pair_inputs<K8, true>(P, cur, cam, lane, xq, ctx);
 #pragma unroll
             for (int s = 0; s < 4; ++s) split8(&xq[8 * s], xqh[s], xql[s]);
         }
         const unsigned long long ts1 = stamp();
-        // the next tile's gather, one dependent level per layer boundary (a tile past the end loads row 0: harmless)
-        fetch_a<K8>(P, tile + 1, lane, wave, S_valid, nxt);
         bf16x8 xh[17], xl[17], yh[17], yl[17];
         dense_layer1b_bf16<16>(rsrc, wb, w1, b1, lane, tid, wave_u, lds, ring, xqh, xql, pin, yh, yl);
         const unsigned long long ts2 = stamp();
@@ -1156,12 +1238,29 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
         float o[128];
         // the chain wraps around: the next pair tile starts again with the pair half of layer 0, whose accumulators
         // come from pt_table (no bias prefetch)
-        dense_layer_bf16<16, 8, 8, false, false>(rsrc, w3, wb, b3, nullptr, lane, tid, wave_u, lds, ring, yh, yl,
-                                                 nullptr, nullptr, o);
-        const unsigned long long ts5 = stamp();
+        // ... and the next tile's pt_table row blocks 0..3: three 16-byte loads per tile of this layer (tiles 0..5),
+        // right behind the mid-tile barrier (its counted vmcnt then never waits for a load younger than one tile)
+        const float4 *trow_nx = P.pt_table + (int64_t)nxt.urow * 64 + 4 * (lane >> 5);
+        auto gather_hook = [&](int m, int s) {
+            if (s == 8) {
 #pragma unroll
-        for (int i = 0; i < 128; ++i) o[i] = leaky(o[i]);
-        finish_rows<K8>(P, lane, o, ctx);
+                for (int g = 3 * m; g < 3 * m + 3 && g < 16; ++g) {
+                    const float4 v = trow_nx[8 * (g >> 2) + (g & 3)];
+                    pin_pre[g >> 2][4 * (g & 3)] = v.x;
+                    pin_pre[g >> 2][4 * (g & 3) + 1] = v.y;
+                    pin_pre[g >> 2][4 * (g & 3) + 2] = v.z;
+                    pin_pre[g >> 2][4 * (g & 3) + 3] = v.w;
+                }
+            }
+        };
+        dense_layer_bf16<16, 8, 8, false, false, true>(rsrc, w3, wb, b3, nullptr, lane, tid, wave_u, lds, ring, yh, yl,
+                                                       nullptr, nullptr, o, gather_hook);
+        const unsigned long long ts5 = stamp();
+        // Retire the next tile's prefetched loads HERE, ahead of the epilogue's stores (vector memory returns in
+        // order and the last of them was issued a layer ago: the wait is free).  Left to the first use at the top of
+        // the next iteration, hipcc waits vmcnt(0) across the back edge: for the stores just issued.
+        asm volatile("" ::"v"(nxt.dirz), "v"(nxt.urow), "v"(pin_pre[3][15]));
+        finish_rows<K8>(P, lane, o, ctx);  // o: LeakyReLU already applied inside the layer
         const unsigned long long ts6 = stamp();
         ph[0] += ts1 - ts0;
         ph[1] += ts2 - ts1;
@@ -1170,7 +1269,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
         ph[4] += ts5 - ts4;
         ph[5] += ts6 - ts5;
         ph[7] += 1;
-        ph[6] = ring.stall_bar;
+        ph[6] += tsg - ts0;  // (PNR_STAMPS builds) issue time of the gathers; ring.stall_bar holds the barrier stalls
         cur = nxt;
     }
 #if PNR_STAMPS
@@ -1251,9 +1350,8 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_color_bf16(ShadeParams P)
         dense_layer_bf16<18, 4, 8, true>(rsrc, w5, w6, b5, b6, lane, tid, wave_u, lds, ring, xh, xl, yh, yl, nullptr);
         dense_layer_bf16<8, 4, 8, true>(rsrc, w6, w7, b6, b7, lane, tid, wave_u, lds, ring, yh, yl, xh, xl, nullptr);
         float o[64];
-        dense_layer_bf16<8, 4, 18, false>(rsrc, w7, w5, b7, b5, lane, tid, wave_u, lds, ring, xh, xl, nullptr, nullptr, o);
-#pragma unroll
-        for (int i = 0; i < 64; ++i) o[i] = leaky(o[i]);
+        dense_layer_bf16<8, 4, 18, false, true, true>(rsrc, w7, w5, b7, b5, lane, tid, wave_u, lds, ring, xh, xl, nullptr,
+                                                      nullptr, o);
         float rgb[3];
         color_head(P, lane, o, rgb);
         if (ok && h == 0) P.smp_out[s] = make_float4(P.smp_sigma[v_idx], rgb[0], rgb[1], rgb[2]);

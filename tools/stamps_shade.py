@@ -35,7 +35,7 @@ sigma_off = total - ((agg_bytes + 255) // 256 * 256) - sigma_bytes
 raw = rnd._ws[sigma_off + (cap - 8192) * 4: sigma_off + cap * 4].view(torch.int64).view(-1, 8)[:256].cpu().double()
 raw = raw[raw[:, 7] > 0]
 per_tile = raw[:, :7] / raw[:, 7:8]
-names = ["prologue(total)", "layer1", "layer2", "layer3", "layer4", "epilogue", "  barrier stalls (in layers)"]
+names = ["prologue(total)", "layer1", "layer2", "layer3", "layer4", "epilogue", "  of prologue: camera + gather issue"]
 m = per_tile.mean(0)
 tot = m[:6].sum()
 print(f"waves sampled {raw.shape[0]}, tiles/wave {raw[:,7].mean():.1f}, s_memtime ticks per tile {tot:.0f}")
