@@ -93,7 +93,7 @@ struct ShadeParams {
     int K;
     long long dbg_off;  // PNR_STAMPS builds: float offset into smp_sigma of the stamp area
     // bf16x3 mode: factorised first layer
-    size_t w16a_off, w16b_off;
+    size_t w16a_off, w16b_off, w4acc_off;
     const int *pt_rank;     // [N+1] point index -> row of pt_table
     const int *pt_list;     // [U] rows -> point index
     float4 *pt_table;       // [u_cap, 8 row blocks, 2 lane halves, 4] float4
@@ -148,6 +148,13 @@ __device__ __forceinline__ void fast_sincos(float x, float &sn, float &cs)
     const float ss = (q & 1) ? c0 : s0, cc = (q & 1) ? s0 : c0;
     sn = (q & 2) ? -ss : ss;
     cs = ((q + 1) & 2) ? -cc : cc;
+}
+
+// v + (v of the lane DPP control CTRL selects): 0xB1 / 0x4E = quad_perm xor 1 / xor 2, 0x141 = row_half_mirror
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v)
+{
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 
 // sum over the K lanes of one sample (lanes [g*K, g*K+K) inside each 32-lane half)
@@ -799,16 +806,24 @@ __device__ __forceinline__ void wait_vm()
 struct NoHook {
     __device__ __forceinline__ void operator()(int, int) const {}
 };
+// default sink of a layer without SPLIT_OUT: value r (accumulator register) of output tile `tile` -> out[tile*16 + r]
+struct StoreOut {
+    float *out;
+    __device__ __forceinline__ void operator()(int tile, int r, float v) const { out[tile * 16 + r] = v; }
+};
 
 // `hook(m, s)` runs at the end of k-step s of tile m, inside that k-step's scheduling region: the place for loads
 // that must be issued a few at a time between MFMAs (a burst of scattered loads blocks the wave at issue).
+// Without SPLIT_OUT every finished accumulator value goes through `sink(tile, r, value)` (after LeakyReLU with
+// OUT_LEAKY), 16 / KS values per k-step of the NEXT tile, behind that k-step's third MFMA: whatever the sink does
+// runs in the MFMA shadow instead of in an epilogue.
 template <int KS, int MT, int KS_NX, bool SPLIT_OUT, bool NX_BIAS = true, bool OUT_LEAKY = false,
-          typename Hook = NoHook>
+          typename Sink = StoreOut, typename Hook = NoHook>
 __device__ __forceinline__ void dense_layer_bf16(__amdgpu_buffer_rsrc_t rsrc, int wbase, int wnx,
                                                  const float *__restrict__ bias, const float *__restrict__ bias_nx,
                                                  int lane, int tid, int wave_u, u32x4 *lds,
                                                  Ring &ring, const bf16x8 *xh, const bf16x8 *xl, bf16x8 *yh,
-                                                 bf16x8 *yl, float *outf, Hook hook = Hook())
+                                                 bf16x8 *yl, Sink sink, Hook hook = Hook())
 {
     static_assert(KS >= 8, "the split of the previous tile is spread over 8 k-steps");
     static_assert(MT >= 3, "the DMA runs three tiles ahead");
@@ -865,12 +880,6 @@ __device__ __forceinline__ void dense_layer_bf16(__amdgpu_buffer_rsrc_t rsrc, in
                 h0 = (__bf16)v0;
                 h1 = (__bf16)v1;
             }
-            // without SPLIT_OUT the previous tile's accumulators leave for `outf` the same way (two per k-step, in
-            // the MFMA shadow) instead of in one burst behind the tile's last MFMA, which would wait for it to retire
-            if (!SPLIT_OUT && m > 0 && s >= S0 && s < S0 + 8) {
-                outf[(m - 1) * 16 + 2 * sp] = OUT_LEAKY ? leaky(prev[2 * sp]) : prev[2 * sp];
-                outf[(m - 1) * 16 + 2 * sp + 1] = OUT_LEAKY ? leaky(prev[2 * sp + 1]) : prev[2 * sp + 1];
-            }
             __builtin_amdgcn_sched_barrier(0);
             if (!(PNR_ABLATE & 2)) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[s], acc, 0, 0, 0);
             if (do_split) {
@@ -886,6 +895,12 @@ __device__ __forceinline__ void dense_layer_bf16(__amdgpu_buffer_rsrc_t rsrc, in
                 yh[kk][j0 + 1] = h1;
                 yl[kk][j0] = (__bf16)r0;
                 yl[kk][j0 + 1] = (__bf16)r1;
+            }
+            if (!SPLIT_OUT && m > 0) {
+                // the previous tile's last MFMA was issued >= 96 cycles ago: its accumulators have retired
+#pragma unroll
+                for (int r = (s * 16) / KS; r < ((s + 1) * 16) / KS; ++r)
+                    sink(m - 1, r, OUT_LEAKY ? leaky(prev[r]) : prev[r]);
             }
             ring.ah = ring.bh;
             ring.al = ring.bl;
@@ -926,7 +941,7 @@ __device__ __forceinline__ void dense_layer_bf16(__amdgpu_buffer_rsrc_t rsrc, in
     }
     if (!SPLIT_OUT) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) outf[(MT - 1) * 16 + r] = OUT_LEAKY ? leaky(prev[r]) : prev[r];
+        for (int r = 0; r < 16; ++r) sink(MT - 1, r, OUT_LEAKY ? leaky(prev[r]) : prev[r]);
     }
     if (SPLIT_OUT && !(PNR_ABLATE & 16)) {
 #pragma unroll
@@ -1131,7 +1146,7 @@ __global__ void __launch_bounds__(TPB, 1) k_point_part(ShadeParams P)
         }
         float o[128];
         dense_layer_bf16<14, 8, 14, false>(rsrc, wa, wa, b0, b0, lane, tid, wave_u, lds, ring, xh, xl, nullptr, nullptr,
-                                           o);
+                                           StoreOut{o});
         if (ok) {
             float4 *dst = P.pt_table + (int64_t)u * 64 + 4 * h;
 #pragma unroll
@@ -1148,7 +1163,7 @@ __global__ void __launch_bounds__(TPB, 1) k_point_part(ShadeParams P)
 template <bool K8>
 __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
 {
-    __shared__ u32x4 lds[LDS_U4];
+    __shared__ u32x4 lds[LDS_U4 + 64];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -1167,6 +1182,15 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
     const float *__restrict__ b1 = P.wbuf + P.b_off[1];
     const float *__restrict__ b2 = P.wbuf + P.b_off[2];
     const float *__restrict__ b3 = P.wbuf + P.b_off[3];
+    // density-head weights in accumulator order (pnr_weights_pack: w4acc[(t * 2 + h) * 16 + r] =
+    // w4[32t + 8(r>>2) + 4h + (r&3)]) behind the ring, fetched by LDS-DMA like everything else in LDS: ONE plain LDS
+    // store anywhere in the kernel makes hipcc guard every fragment read with s_waitcnt vmcnt(0)
+    u32x4 *w4tab = lds + LDS_U4;
+    if (wave_u == 0) {
+        typedef __attribute__((address_space(3))) void *lds_ptr_t;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)w4tab, 16, lane * 16, (int)(P.w4acc_off * 4), 0, 0);
+    }
+    const float b4 = P.wbuf[P.b_off[4]];
     Ring ring;
     ring.stall_bar = 0;
     ring.stall_bias = 0;
@@ -1176,7 +1200,6 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
     fetch_a<K8>(P, t_begin, lane, wave, S_valid, cur);
     fetch_b<K8>(P, cur);
     fetch_c_pair(P, cur);
-    f32x16 pin_pre[4];
     for (int tile = t_begin; tile < t_end; ++tile) {
         int wb = wb_, w1 = w1_, w2 = w2_, w3 = w3_;
         asm volatile("" : "+s"(wb), "+s"(w1), "+s"(w2), "+s"(w3));
@@ -1188,18 +1211,14 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
         __builtin_amdgcn_sched_barrier(0);
         // Point halves of layer 1 (pt_table rows, accumulator order).  A lane reads 512 B in 32 scattered 16-byte
         // loads; 4 waves x 32 of them keep the CU's texture-address unit busy for ~7k cycles (tools/ub_gather.hip)
-        // and block the issuing wave meanwhile.  Row blocks 0..3 were therefore issued two at a time between the
-        // MFMAs of the previous tile's last layer (pin_pre); row blocks 4..7 are issued here and land while the
-        // distances are encoded and the first half of layer 1 runs.
+        // and block the issuing wave meanwhile, wherever they are issued: spreading half of them between the MFMAs of
+        // the previous tile's last layer moved the cost there, cycle for cycle.  They land while the distances are
+        // encoded.
         f32x16 pin[8];
         {
             const float4 *trow = P.pt_table + (int64_t)cur.urow * 64 + 4 * (lane >> 5);
 #pragma unroll
-            for (int B = 0; B < 8; ++B) {
-                if (B < 4 && tile != t_begin) {
-                    pin[B] = pin_pre[B];
-                    continue;
-                }
+            for (int B = 0; B < 8; ++B)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float4 v = trow[8 * B + q];
@@ -1208,7 +1227,6 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
                     pin[B][4 * q + 2] = v.z;
                     pin[B][4 * q + 3] = v.w;
                 }
-            }
         }
         __builtin_amdgcn_sched_barrier(0);
         const unsigned long long tsg = stamp();
@@ -1226,48 +1244,94 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
         const unsigned long long ts2 = stamp();
         fetch_b<K8>(P, nxt);
         // layer 2's output (+ the 7 extra head inputs as k-step 16) goes to xh/xl
-        dense_layer_bf16<16, 8, 17, true>(rsrc, w1, w2, b1, b2, lane, tid, wave_u, lds, ring, yh, yl, xh, xl, nullptr);
+        dense_layer_bf16<16, 8, 17, true>(rsrc, w1, w2, b1, b2, lane, tid, wave_u, lds, ring, yh, yl, xh, xl, StoreOut{nullptr});
         const unsigned long long ts3 = stamp();
         fetch_c_pair(P, nxt);
         {
             float v[8] = {ctx.ex[0], ctx.ex[1], ctx.ex[2], ctx.ex[3], 0.f, 0.f, 0.f, 0.f};
             split8(v, xh[16], xl[16]);
         }
-        dense_layer_bf16<17, 8, 16, true>(rsrc, w2, w3, b2, b3, lane, tid, wave_u, lds, ring, xh, xl, yh, yl, nullptr);
+        dense_layer_bf16<17, 8, 16, true>(rsrc, w2, w3, b2, b3, lane, tid, wave_u, lds, ring, xh, xl, yh, yl, StoreOut{nullptr});
         const unsigned long long ts4 = stamp();
-        float o[128];
-        // the chain wraps around: the next pair tile starts again with the pair half of layer 0, whose accumulators
-        // come from pt_table (no bias prefetch)
-        // ... and the next tile's pt_table row blocks 0..3: three 16-byte loads per tile of this layer (tiles 0..5),
-        // right behind the mid-tile barrier (its counted vmcnt then never waits for a load younger than one tile)
-        const float4 *trow_nx = P.pt_table + (int64_t)nxt.urow * 64 + 4 * (lane >> 5);
-        auto gather_hook = [&](int m, int s) {
-            if (s == 8) {
+        // Last layer.  The chain wraps around: the next pair tile starts again with the pair half of layer 0, whose
+        // accumulators come from pt_table (no bias prefetch).
+        if (K8) {
+            // K = 8: density head and K-aggregation (studio_model.py:337-353) run inside the layer, one finished
+            // value per k-step in the MFMA shadow.  Value r of output tile t (feature 32t + 8(r>>2) + 4h + (r&3)) is
+            // multiplied with its head weight (w4tab: accumulator order, 16 per lane half and tile, fetched four at a
+            // time three k-steps ahead), weighted, summed over the sample's 8 lanes, and kept by the lane whose
+            // neighbour slot equals t: afterwards every lane stores one 32-feature tile of its sample's 256.
+            float part = 0.f;
+            float mine[16];
+            float4 wv[4];
+            // (inline asm: hipcc guards a plain LDS read with s_waitcnt vmcnt(0) while LDS-DMA is in flight, which
+            // would drain the weight pipeline four times per tile.  The read is consumed 13 k-steps = 26 younger
+            // fragment reads later; LDS returns in order and every fragment read is awaited by the compiler.)
+            const unsigned w4a = (unsigned)(uintptr_t)w4tab + 64u * (lane >> 5);  // LDS byte address
+            auto hook = [&](int m, int s) {
+                if ((s & 3) == 3)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2"
+                                 : "=v"(wv[s >> 2])
+                                 : "v"(w4a), "n"(128 * m + 16 * (s >> 2)));
+            };
+            // The three DPP steps of the 8-lane sum form a pipeline over consecutive values (p1..p3): a DPP operand
+            // written by the instruction just before it costs two wait states (s_nop), here every DPP reads a
+            // register written one k-step earlier.
+            float p1 = 0.f, p2 = 0.f, p3 = 0.f;
+            auto stage = [&](int L) {  // value L leaves the pipeline
+                const float a = dpp_add<0x141>(p3);
+                if (L >= 0) mine[L & 15] = (ctx.slot == (L >> 4)) ? a : ((L >> 4) == 0 ? 0.f : mine[L & 15]);
+                p3 = dpp_add<0x4E>(p2);
+                p2 = dpp_add<0xB1>(p1);
+            };
+            auto sink = [&](int t, int r, float v) {
+                const float4 w = wv[r >> 2];
+                const float wr = (r & 3) == 0 ? w.x : (r & 3) == 1 ? w.y : (r & 3) == 2 ? w.z : w.w;
+                part += v * wr;
+                stage(16 * t + r - 3);
+                p1 = v * ctx.wgt;
+                // (an opaque use: hipcc otherwise sinks the whole chain into the block of the stores behind the layer)
+                asm volatile("" : "+v"(p1), "+v"(p2), "+v"(p3), "+v"(part));
+                if (16 * t + r >= 3) asm volatile("" : "+v"(mine[(16 * t + r - 3) & 15]));
+            };
+            dense_layer_bf16<16, 8, 8, false, false, true>(rsrc, w3, wb, b3, nullptr, lane, tid, wave_u, lds, ring, yh,
+                                                           yl, nullptr, nullptr, sink, hook);
+            stage(125);
+            p1 = 0.f;
+            stage(126);
+            stage(127);
+            const unsigned long long ts5 = stamp();
+            ph[4] += ts5 - ts4;
+            // Retire the next tile's prefetched loads HERE, ahead of the stores (vector memory returns in order and
+            // the last of them was issued a layer ago: the wait is free).  Left to the first use at the top of the
+            // next iteration, hipcc waits vmcnt(0) across the back edge: for the stores just issued.
+            asm volatile("" ::"v"(nxt.dirz), "v"(nxt.urow));
+            part += __shfl_xor(part, 32, 64);
+            const float alpha = fmaxf(part + b4, 0.f);
+            const float sigma = seg_sum<true>(alpha * ctx.wgt, 8, lane);
+            if (ctx.row_ok) {
+                if (ctx.slot == 0 && lane < 32) P.smp_sigma[ctx.v_idx] = sigma;
+                float4 *dst = reinterpret_cast<float4 *>(P.agg + (int64_t)ctx.v_idx * 256 + 32 * ctx.slot +
+                                                         4 * (lane >> 5));
 #pragma unroll
-                for (int g = 3 * m; g < 3 * m + 3 && g < 16; ++g) {
-                    const float4 v = trow_nx[8 * (g >> 2) + (g & 3)];
-                    pin_pre[g >> 2][4 * (g & 3)] = v.x;
-                    pin_pre[g >> 2][4 * (g & 3) + 1] = v.y;
-                    pin_pre[g >> 2][4 * (g & 3) + 2] = v.z;
-                    pin_pre[g >> 2][4 * (g & 3) + 3] = v.w;
-                }
+                for (int q = 0; q < 4; ++q)
+                    dst[2 * q] = make_float4(mine[4 * q], mine[4 * q + 1], mine[4 * q + 2], mine[4 * q + 3]);
             }
-        };
-        dense_layer_bf16<16, 8, 8, false, false, true>(rsrc, w3, wb, b3, nullptr, lane, tid, wave_u, lds, ring, yh, yl,
-                                                       nullptr, nullptr, o, gather_hook);
-        const unsigned long long ts5 = stamp();
-        // Retire the next tile's prefetched loads HERE, ahead of the epilogue's stores (vector memory returns in
-        // order and the last of them was issued a layer ago: the wait is free).  Left to the first use at the top of
-        // the next iteration, hipcc waits vmcnt(0) across the back edge: for the stores just issued.
-        asm volatile("" ::"v"(nxt.dirz), "v"(nxt.urow), "v"(pin_pre[3][15]));
-        finish_rows<K8>(P, lane, o, ctx);  // o: LeakyReLU already applied inside the layer
-        const unsigned long long ts6 = stamp();
+            ph[5] += stamp() - ts5;
+        } else {
+            float o[128];
+            dense_layer_bf16<16, 8, 8, false, false, true>(rsrc, w3, wb, b3, nullptr, lane, tid, wave_u, lds, ring, yh,
+                                                           yl, nullptr, nullptr, StoreOut{o});
+            const unsigned long long ts5 = stamp();
+            ph[4] += ts5 - ts4;
+            asm volatile("" ::"v"(nxt.dirz), "v"(nxt.urow));
+            finish_rows<K8>(P, lane, o, ctx);  // o: LeakyReLU already applied inside the layer
+            ph[5] += stamp() - ts5;
+        }
         ph[0] += ts1 - ts0;
         ph[1] += ts2 - ts1;
         ph[2] += ts3 - ts2;
         ph[3] += ts4 - ts3;
-        ph[4] += ts5 - ts4;
-        ph[5] += ts6 - ts5;
         ph[7] += 1;
         ph[6] += tsg - ts0;  // (PNR_STAMPS builds) issue time of the gathers; ring.stall_bar holds the barrier stalls
         cur = nxt;
@@ -1347,11 +1411,11 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_color_bf16(ShadeParams P)
             split8(v17, xh[17], xl[17]);
         }
         bf16x8 yh[8], yl[8];
-        dense_layer_bf16<18, 4, 8, true>(rsrc, w5, w6, b5, b6, lane, tid, wave_u, lds, ring, xh, xl, yh, yl, nullptr);
-        dense_layer_bf16<8, 4, 8, true>(rsrc, w6, w7, b6, b7, lane, tid, wave_u, lds, ring, yh, yl, xh, xl, nullptr);
+        dense_layer_bf16<18, 4, 8, true>(rsrc, w5, w6, b5, b6, lane, tid, wave_u, lds, ring, xh, xl, yh, yl, StoreOut{nullptr});
+        dense_layer_bf16<8, 4, 8, true>(rsrc, w6, w7, b6, b7, lane, tid, wave_u, lds, ring, yh, yl, xh, xl, StoreOut{nullptr});
         float o[64];
         dense_layer_bf16<8, 4, 18, false, true, true>(rsrc, w7, w5, b7, b5, lane, tid, wave_u, lds, ring, xh, xl, nullptr,
-                                                      nullptr, o);
+                                                      nullptr, StoreOut{o});
         float rgb[3];
         color_head(P, lane, o, rgb);
         if (ok && h == 0) P.smp_out[s] = make_float4(P.smp_sigma[v_idx], rgb[0], rgb[1], rgb[2]);
@@ -1465,6 +1529,13 @@ __global__ void k_pack_layer_bf16(const float *__restrict__ W, int n_out, int n_
     }
 }
 
+// density head weights in accumulator order: dst[(t * 2 + h) * 16 + r] = w4[32t + 8(r>>2) + 4h + (r&3)]
+__global__ void k_pack_head_acc(const float *__restrict__ w4, float *__restrict__ dst)
+{
+    const int i = threadIdx.x, t = i >> 5, h = (i >> 4) & 1, r = i & 15;
+    dst[i] = w4[32 * t + 8 * (r >> 2) + 4 * h + (r & 3)];
+}
+
 __global__ void k_copy(const float *__restrict__ src, int n, float *__restrict__ dst)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1499,6 +1570,7 @@ int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr,
     P.dbg_off = cap - 8192;
     P.w16a_off = w->w16a_off;
     P.w16b_off = w->w16b_off;
+    P.w4acc_off = w->w4acc_off;
     P.pt_rank = ws.pt_rank;
     P.pt_list = ws.pt_list;
     P.pt_table = reinterpret_cast<float4 *>(ws.pt_table);
@@ -1590,6 +1662,8 @@ extern "C" int pnr_weights_pack(pnr_weights_t *w, const float *const d_w[9], con
     off += pad((size_t)8 * 14 * 512);
     w->w16b_off = off;
     off += pad((size_t)4 * 8 * 512);
+    w->w4acc_off = off;
+    off += pad(256);
     for (int i = 0; i < 9; ++i) {
         w->b_off[i] = off;
         off += pad((size_t)n_out[i]);
@@ -1617,6 +1691,7 @@ extern "C" int pnr_weights_pack(pnr_weights_t *w, const float *const d_w[9], con
     }
     hipLaunchKernelGGL(k_pack_layer_bf16, dim3(256), dim3(256), 0, stream, d_w[0], 256, 284, (int)L_BASE0, 14, 14, 0,
                        reinterpret_cast<unsigned short *>(w->buf + w->w16a_off));
+    hipLaunchKernelGGL(k_pack_head_acc, dim3(1), dim3(256), 0, stream, d_w[4], w->buf + w->w4acc_off);
     hipLaunchKernelGGL(k_pack_layer_bf16, dim3(256), dim3(256), 0, stream, d_w[0], 256, 284, (int)L_BASE0, 8, 4, 14,
                        reinterpret_cast<unsigned short *>(w->buf + w->w16b_off));
     PNR_HIP_CHECK(hipGetLastError());
