@@ -47,7 +47,7 @@ RenderWs carve_render_ws(void *base, int64_t R, int64_t cap, int K, int64_t N, i
     ws.scan_temp = take(scan_temp_bytes(std::max<int64_t>(R, cap) + 1));
     // shade-only buffers last so that the query-only workspace is a prefix
     ws.smp_sigma = (float *)take((size_t)cap * sizeof(float));
-    ws.agg = (float *)take((size_t)cap * 256 * sizeof(float));
+    ws.agg = (float *)take((size_t)(cap + 32) * 256 * sizeof(float));  // packed layout: whole 32-sample blocks
     ws.total = off;
     if (N > 0) {
         ws.u_cap = std::max<int64_t>(1, std::min<int64_t>(n_list, cap * (int64_t)K));

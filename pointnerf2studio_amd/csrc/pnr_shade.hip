@@ -31,6 +31,7 @@ namespace pnr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // diagnostic builds only (never shipped): bit0 cheap PE, bit1 no MFMA, bit2 no staging, bit3 no barrier, bit4 no split
@@ -93,7 +94,7 @@ struct ShadeParams {
     int K;
     long long dbg_off;  // PNR_STAMPS builds: float offset into smp_sigma of the stamp area
     // bf16x3 mode: factorised first layer
-    size_t w16a_off, w16b_off, w4acc_off;
+    size_t w16a_off, w16b_off, w4acc_off, w8acc_off;
     const int *pt_rank;     // [N+1] point index -> row of pt_table
     const int *pt_list;     // [U] rows -> point index
     float4 *pt_table;       // [u_cap, 8 row blocks, 2 lane halves, 4] float4
@@ -493,8 +494,19 @@ __device__ __forceinline__ void bias_quarter(const BiasRegs &r, int q4, f32x16 &
     }
 }
 
+// bf16x3 mode: layout of the aggregated features between the pair and the colour kernel.  The colour kernel's lane
+// (j, h) of the wave that owns samples 32b .. 32b+31 needs, for k-step k, features 16k + 8h + {0..7} of sample
+// 32b + j: stored as two float4 (hp = 0, 1) at float4 index ((b*16 + k)*2 + hp)*64 + j + 32h, so each of its 32
+// loads is one contiguous KiB per wave (row-major rows cost 32 scattered 16-byte loads per lane: ~7k cycles of the
+// CU's texture-address unit per tile, tools/ub_gather.hip).  The pair kernel's lane holding features
+// 32t + 8q + 4hp + {0..3} writes chunk (k = 2t + (q>>1), hp, h = q&1).
+__device__ __forceinline__ int64_t agg_idx4(int v, int k, int hp, int h)
+{
+    return ((((int64_t)(v >> 5) * 16 + k) * 2 + hp) * 64) + (v & 31) + 32 * h;
+}
+
 // density head + weighted K-aggregation + stores (studio_model.py:337-353)
-template <bool K8>
+template <bool K8, bool PACKED>
 __device__ __forceinline__ void finish_rows(const ShadeParams &P, int lane, const float (&hC)[128],
                                             const RowCtx &ctx)
 {
@@ -538,7 +550,12 @@ __device__ __forceinline__ void finish_rows(const ShadeParams &P, int lane, cons
             o.y = seg_sum<K8>(hC[m * 16 + 4 * q + 1] * ctx.wgt, K, lane);
             o.z = seg_sum<K8>(hC[m * 16 + 4 * q + 2] * ctx.wgt, K, lane);
             o.w = seg_sum<K8>(hC[m * 16 + 4 * q + 3] * ctx.wgt, K, lane);
-            if (writer) *reinterpret_cast<float4 *>(dst + 32 * m + 8 * q + 4 * h) = o;
+            if (writer) {
+                if (PACKED)
+                    reinterpret_cast<float4 *>(P.agg)[agg_idx4(ctx.v_idx, 2 * m + (q >> 1), h, q & 1)] = o;
+                else
+                    *reinterpret_cast<float4 *>(dst + 32 * m + 8 * q + 4 * h) = o;
+            }
         }
 }
 
@@ -563,6 +580,44 @@ __device__ __forceinline__ void color_head(const ShadeParams &P, int lane, const
             }
         part += __shfl_xor(part, 32, 64);
         const float z = part + b8[c];
+        const float sg = 1.0f / (1.0f + expf(-z));
+        rgb[c] = sg * (1.0f + 2.0f * 0.001f) - 0.001f;
+    }
+}
+
+// the same with the weights from the LDS table w8tab[((c * 4 + t) * 2 + h) * 16 + r] (accumulator order).  Inline asm
+// reads (hipcc would guard plain ones with s_waitcnt vmcnt(0) while the next tile's weight DMA is in flight), all
+// twelve per colour in flight at once.
+__device__ __forceinline__ void color_head_lds(const ShadeParams &P, const u32x4 *w8tab, int lane, const float (&hA)[64],
+                                               float (&rgb)[3])
+{
+    const int h = lane >> 5;
+    const float *b8 = P.wbuf + P.b_off[8];
+    const unsigned base = (unsigned)(uintptr_t)w8tab + 64u * h;
+    float part[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        f32x4 wv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wv[i]) : "v"(base), "n"(512 * c + 128 * (i >> 2) + 16 * (i & 3)));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            // the opaque "+v" keeps the multiplies behind the wait above
+            asm volatile("" : "+v"(wv[i]));
+            acc += hA[4 * i + 0] * wv[i].x;
+            acc += hA[4 * i + 1] * wv[i].y;
+            acc += hA[4 * i + 2] * wv[i].z;
+            acc += hA[4 * i + 3] * wv[i].w;
+        }
+        part[c] = acc;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float pc = part[c] + __shfl_xor(part[c], 32, 64);
+        const float z = pc + b8[c];
         const float sg = 1.0f / (1.0f + expf(-z));
         rgb[c] = sg * (1.0f + 2.0f * 0.001f) - 0.001f;
     }
@@ -667,7 +722,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
         dense_layer<128, 8>(rsrc, w3, b3, lane, hA, hC);
 #pragma unroll
         for (int i = 0; i < 128; ++i) hC[i] = leaky(hC[i]);
-        finish_rows<K8>(P, lane, hC, ctx);
+        finish_rows<K8, false>(P, lane, hC, ctx);
     }
 }
 
@@ -1263,7 +1318,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
             // neighbour slot equals t: afterwards every lane stores one 32-feature tile of its sample's 256.
             float part = 0.f;
             float mine[16];
-            float4 wv[4];
+            f32x4 wv[4];
             // (inline asm: hipcc guards a plain LDS read with s_waitcnt vmcnt(0) while LDS-DMA is in flight, which
             // would drain the weight pipeline four times per tile.  The read is consumed 13 k-steps = 26 younger
             // fragment reads later; LDS returns in order and every fragment read is awaited by the compiler.)
@@ -1285,7 +1340,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
                 p2 = dpp_add<0xB1>(p1);
             };
             auto sink = [&](int t, int r, float v) {
-                const float4 w = wv[r >> 2];
+                const f32x4 w = wv[r >> 2];
                 const float wr = (r & 3) == 0 ? w.x : (r & 3) == 1 ? w.y : (r & 3) == 2 ? w.z : w.w;
                 part += v * wr;
                 stage(16 * t + r - 3);
@@ -1311,11 +1366,11 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
             const float sigma = seg_sum<true>(alpha * ctx.wgt, 8, lane);
             if (ctx.row_ok) {
                 if (ctx.slot == 0 && lane < 32) P.smp_sigma[ctx.v_idx] = sigma;
-                float4 *dst = reinterpret_cast<float4 *>(P.agg + (int64_t)ctx.v_idx * 256 + 32 * ctx.slot +
-                                                         4 * (lane >> 5));
+                float4 *agg4 = reinterpret_cast<float4 *>(P.agg);
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    dst[2 * q] = make_float4(mine[4 * q], mine[4 * q + 1], mine[4 * q + 2], mine[4 * q + 3]);
+                    agg4[agg_idx4(ctx.v_idx, 2 * ctx.slot + (q >> 1), lane >> 5, q & 1)] =
+                        make_float4(mine[4 * q], mine[4 * q + 1], mine[4 * q + 2], mine[4 * q + 3]);
             }
             ph[5] += stamp() - ts5;
         } else {
@@ -1325,7 +1380,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
             const unsigned long long ts5 = stamp();
             ph[4] += ts5 - ts4;
             asm volatile("" ::"v"(nxt.dirz), "v"(nxt.urow));
-            finish_rows<K8>(P, lane, o, ctx);  // o: LeakyReLU already applied inside the layer
+            finish_rows<K8, true>(P, lane, o, ctx);  // o: LeakyReLU already applied inside the layer
             ph[5] += stamp() - ts5;
         }
         ph[0] += ts1 - ts0;
@@ -1351,7 +1406,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
 
 __global__ void __launch_bounds__(TPB, 1) k_shade_color_bf16(ShadeParams P)
 {
-    __shared__ u32x4 lds[LDS_U4];
+    __shared__ u32x4 lds[LDS_U4 + 128];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -1367,40 +1422,66 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_color_bf16(ShadeParams P)
     const float *__restrict__ b5 = P.wbuf + P.b_off[5];
     const float *__restrict__ b6 = P.wbuf + P.b_off[6];
     const float *__restrict__ b7 = P.wbuf + P.b_off[7];
+    // colour head weights (3 x 128) in accumulator order behind the ring, by LDS-DMA (see w4tab in the pair kernel)
+    u32x4 *w8tab = lds + LDS_U4;
+    if (wave_u < 2) {
+        typedef __attribute__((address_space(3))) void *lds_ptr_t;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(w8tab + wave_u * 64), 16, tid * 16,
+                                                 (int)(P.w8acc_off * 4), 0, 0);
+    }
     Ring ring;
     ring_start<18>(rsrc, w5_, b5, lane, tid, wave_u, lds, ring);
+    const float4 *agg4 = reinterpret_cast<const float4 *>(P.agg);
+    // sample -> ray -> direction of the first tile; the chain of the next tile is issued while this one computes
+    int s_nx, ray_nx;
+    float dnx[3];
+    {
+        const int v0 = blockIdx.x * SPT + wave * 32 + j;
+        s_nx = P.vs_list[v0 < S_valid ? v0 : 0];
+        ray_nx = P.smp_ray[s_nx];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) dnx[d] = P.dirs[3 * (int64_t)ray_nx + d];
+    }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int w5 = w5_, w6 = w6_, w7 = w7_;
         asm volatile("" : "+s"(w5), "+s"(w6), "+s"(w7));
         const int v_idx = tile * SPT + wave * 32 + j;
         const bool ok = v_idx < S_valid;
-        const int s = ok ? P.vs_list[v_idx] : 0;
-        const int ray = P.smp_ray[s];
-        const float *src = P.agg + (int64_t)(ok ? v_idx : 0) * 256;
+        const int s = s_nx;
+        const float dir[3] = {dnx[0], dnx[1], dnx[2]};
+        const int v_nx = v_idx + (int)gridDim.x * SPT;
+        s_nx = P.vs_list[v_nx < S_valid ? v_nx : 0];
         bf16x8 xh[18], xl[18];
+        const int64_t a_base = (((int64_t)(tile * WAVES + wave) * 16) * 2) * 64 + lane;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            // k-step k: this lane half supplies features 16k + 8h .. 16k + 8h + 7
-            const float4 a = *reinterpret_cast<const float4 *>(src + 16 * k + 8 * h);
-            const float4 b = *reinterpret_cast<const float4 *>(src + 16 * k + 8 * h + 4);
+            // k-step k: this lane half supplies features 16k + 8h .. 16k + 8h + 7 (agg_idx4: one contiguous KiB per load)
+            const float4 a = agg4[a_base + (2 * k) * 64];
+            const float4 b = agg4[a_base + (2 * k + 1) * 64];
             const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
             split8(v, xh[k], xl[k]);
         }
+        ray_nx = P.smp_ray[s_nx];
         {
             float vx, vy, vz;
-            rot_rows(P.Rw2c, P.dirs[3 * (int64_t)ray], P.dirs[3 * (int64_t)ray + 1], P.dirs[3 * (int64_t)ray + 2], vx,
-                     vy, vz);
+            rot_rows(P.Rw2c, dir[0], dir[1], dir[2], vx, vy, vz);
             const float vv[3] = {vx, vy, vz};
             float p[24];  // [sin(d*4+f) (12) | cos (12)]
 #pragma unroll
-            for (int d = 0; d < 3; ++d)
+            for (int d = 0; d < 3; ++d) {
+                float sn, cs;
+                fast_sincos(vv[d], sn, cs);
 #pragma unroll
                 for (int f = 0; f < 4; ++f) {
-                    float sn, cs;
-                    sincosf(vv[d] * (float)(1 << f), &sn, &cs);
+                    if (f > 0) {
+                        const float s2 = 2.0f * sn * cs, c2 = (cs - sn) * (cs + sn);
+                        sn = s2;
+                        cs = c2;
+                    }
                     p[d * 4 + f] = sn;
                     p[12 + d * 4 + f] = cs;
                 }
+            }
             float v16[8], v17[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -1410,6 +1491,8 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_color_bf16(ShadeParams P)
             split8(v16, xh[16], xl[16]);
             split8(v17, xh[17], xl[17]);
         }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) dnx[d] = P.dirs[3 * (int64_t)ray_nx + d];
         bf16x8 yh[8], yl[8];
         dense_layer_bf16<18, 4, 8, true>(rsrc, w5, w6, b5, b6, lane, tid, wave_u, lds, ring, xh, xl, yh, yl, StoreOut{nullptr});
         dense_layer_bf16<8, 4, 8, true>(rsrc, w6, w7, b6, b7, lane, tid, wave_u, lds, ring, yh, yl, xh, xl, StoreOut{nullptr});
@@ -1417,7 +1500,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_color_bf16(ShadeParams P)
         dense_layer_bf16<8, 4, 18, false, true, true>(rsrc, w7, w5, b7, b5, lane, tid, wave_u, lds, ring, xh, xl, nullptr,
                                                       nullptr, StoreOut{o});
         float rgb[3];
-        color_head(P, lane, o, rgb);
+        color_head_lds(P, w8tab, lane, o, rgb);
         if (ok && h == 0) P.smp_out[s] = make_float4(P.smp_sigma[v_idx], rgb[0], rgb[1], rgb[2]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1536,6 +1619,15 @@ __global__ void k_pack_head_acc(const float *__restrict__ w4, float *__restrict_
     dst[i] = w4[32 * t + 8 * (r >> 2) + 4 * h + (r & 3)];
 }
 
+// colour head weights [3,128] in accumulator order: dst[((c * 4 + t) * 2 + h) * 16 + r] = w8[c][32t + 8(r>>2) + 4h + (r&3)]
+__global__ void k_pack_color_head_acc(const float *__restrict__ w8, float *__restrict__ dst)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 384) return;
+    const int c = i >> 7, t = (i >> 5) & 3, h = (i >> 4) & 1, r = i & 15;
+    dst[i] = w8[c * 128 + 32 * t + 8 * (r >> 2) + 4 * h + (r & 3)];
+}
+
 __global__ void k_copy(const float *__restrict__ src, int n, float *__restrict__ dst)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1571,6 +1663,7 @@ int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr,
     P.w16a_off = w->w16a_off;
     P.w16b_off = w->w16b_off;
     P.w4acc_off = w->w4acc_off;
+    P.w8acc_off = w->w8acc_off;
     P.pt_rank = ws.pt_rank;
     P.pt_list = ws.pt_list;
     P.pt_table = reinterpret_cast<float4 *>(ws.pt_table);
@@ -1664,6 +1757,8 @@ extern "C" int pnr_weights_pack(pnr_weights_t *w, const float *const d_w[9], con
     off += pad((size_t)4 * 8 * 512);
     w->w4acc_off = off;
     off += pad(256);
+    w->w8acc_off = off;
+    off += pad(512);
     for (int i = 0; i < 9; ++i) {
         w->b_off[i] = off;
         off += pad((size_t)n_out[i]);
@@ -1692,6 +1787,7 @@ extern "C" int pnr_weights_pack(pnr_weights_t *w, const float *const d_w[9], con
     hipLaunchKernelGGL(k_pack_layer_bf16, dim3(256), dim3(256), 0, stream, d_w[0], 256, 284, (int)L_BASE0, 14, 14, 0,
                        reinterpret_cast<unsigned short *>(w->buf + w->w16a_off));
     hipLaunchKernelGGL(k_pack_head_acc, dim3(1), dim3(256), 0, stream, d_w[4], w->buf + w->w4acc_off);
+    hipLaunchKernelGGL(k_pack_color_head_acc, dim3(2), dim3(256), 0, stream, d_w[8], w->buf + w->w8acc_off);
     hipLaunchKernelGGL(k_pack_layer_bf16, dim3(256), dim3(256), 0, stream, d_w[0], 256, 284, (int)L_BASE0, 8, 4, 14,
                        reinterpret_cast<unsigned short *>(w->buf + w->w16b_off));
     PNR_HIP_CHECK(hipGetLastError());
