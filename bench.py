@@ -44,6 +44,11 @@ from pointnerf2studio_amd.distributed import gather_views, make_shard  # noqa: E
 from pointnerf2studio_amd.renderer import (RendererHIP, SceneHIP, WeightsHIP, grid_hyperparameters)  # noqa: E402
 
 FLOPS_PER_PAIR = 542_720       # 2 * (284*256 + 256*256 + 263*256 + 256*256 + 256)   SURVEY.md section 8d
+# bf16x3 mode: mlp_base layer 0 is factorised; k_shade_pairs_bf16 multiplies the 60 pair inputs only, the 224
+# point-only inputs are contracted once per distinct neighbour point by k_point_part
+FLOPS_PER_PAIR_BF16_KERNEL = 428_032   # 2 * (60*256 + 256*256 + 263*256 + 256*256 + 256)
+FLOPS_PER_POINT_PART = 114_688         # 2 * 224*256
+MFMA_FLOPS_PER_PAIR_BF16 = 1_302_528   # executed: 1272 x v_mfma_f32_32x32x16_bf16 (32768 FLOP) per 32 pairs
 FLOPS_PER_SAMPLE = 137_984     # 2 * (280*128 + 2*128*128 + 128*3)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X dense bf16 matrix peak (no 2:1 sparsity)
@@ -99,6 +104,7 @@ def main():
     ap.add_argument("--points", type=int, default=None, help="override the number of points")
     ap.add_argument("--cpu-rays-side", type=int, default=64, help="side of the CPU-baseline window (0 = skip)")
     ap.add_argument("--sigma-scale", type=float, default=300.0)
+    ap.add_argument("--no-other-mode", action="store_true", help="skip the 2-step run of the other arithmetic mode")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="diagnostic, single process: shard as rank --emulate-rank of this many ranks, no collectives")
     ap.add_argument("--emulate-rank", type=int, default=0)
@@ -233,26 +239,45 @@ def main():
         return float(t.item()), acc, cnt, max(recorded - lo, 1)
 
     def roofline(mode, acc_ms, cnt, n_launch):
-        pairs, samples = cnt[4], cnt[3]
+        pairs, samples, upoints = cnt[4], cnt[3], cnt[7]
         t_pairs = acc_ms[2] / 1e3
-        achieved = pairs * FLOPS_PER_PAIR / t_pairs / 1e12 if t_pairs > 0 else 0.0
         bf = mode == "bf16x3"
+        per_pair = FLOPS_PER_PAIR_BF16_KERNEL if bf else FLOPS_PER_PAIR
+        achieved = pairs * per_pair / t_pairs / 1e12 if t_pairs > 0 else 0.0
         peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
         kernel = "k_shade_pairs_bf16" if bf else "k_shade_pairs"
+        if bf:
+            executed = pairs * MFMA_FLOPS_PER_PAIR_BF16 / t_pairs / 1e12 if t_pairs > 0 else 0.0
+            alg_bytes = pairs * 8 + upoints * 1072 + samples * 1064
+            bytes_note = "pairs*8 + distinct points*1072 + samples*1064"
+        else:
+            executed = achieved
+            alg_bytes = pairs * 164 + samples * 1028
+            bytes_note = "pairs*164 + samples*1028"
         r = {
             "bound": "mfma", "kernel": kernel, "mode": mode,
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-            "peak_note": ("dense bf16 MFMA peak; the kernel executes 3 bf16 MFMA products per algorithmic fp32 product, "
-                          "so executed FLOP/s = 3 x achieved" if bf else "dense fp32 MFMA peak"),
-            "executed_mfma_frac": (3 * achieved / peak) if bf else achieved / peak,
+            "peak_note": ("dense bf16 MFMA peak.  achieved = algorithmic fp32 FLOPs of THIS kernel (mlp_base layer 0 is "
+                          "factorised: its 224 point-only inputs are contracted once per distinct neighbour point by "
+                          "k_point_part, stage point_part) / its launch time; the kernel executes 3 bf16 MFMA products "
+                          "per algorithmic product on padded tiles: executed_mfma_frac prices those"
+                          if bf else "dense fp32 MFMA peak"),
+            "executed_mfma_frac": executed / peak,
             "traffic": pmc_traffic_bytes(kernel),
             "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
-                            "profiles/r01/pmc_hbm_traffic.json; algorithmic bytes = pairs*164 + samples*1028)",
-            "algorithmic_bytes_per_launch": (pairs * 164 + samples * 1028) / n_launch,
+                            f"profiles/r01/pmc_hbm_traffic.json; algorithmic bytes = {bytes_note})",
+            "algorithmic_bytes_per_launch": alg_bytes / n_launch,
             "avg_launch_ms": acc_ms[2] / n_launch,
             "valid_pairs_per_launch": pairs / n_launch,
-            "flops_per_pair": FLOPS_PER_PAIR,
+            "flops_per_pair": per_pair,
         }
+        if bf:
+            t_both = (acc_ms[2] + acc_ms[5]) / 1e3
+            r["distinct_points_per_launch"] = upoints / n_launch
+            r["point_part_ms"] = acc_ms[5] / n_launch
+            r["reference_flops_per_pair"] = FLOPS_PER_PAIR
+            # the reference's per-pair arithmetic (542,720 FLOP) over the time of both kernels that replace it
+            r["reference_equivalent_tflops"] = pairs * FLOPS_PER_PAIR / t_both / 1e12 if t_both > 0 else 0.0
         return r
 
     run_steps(rnd, 0, args.warmup)
@@ -262,7 +287,7 @@ def main():
 
     # the other arithmetic mode, for the record (same workload, 2 steps, not part of `value`)
     alt = None
-    if world == 1 and not emulate:
+    if world == 1 and not emulate and not args.no_other_mode:
         alt_mode = "fp32" if args.precision == "bf16x3" else "bf16x3"
         rnd_alt = RendererHIP(scene, wh, SR=SR, K=K, D=400, radius_limit=4 * max(VSIZE[0], VSIZE[1]),
                               vsize_z=VSIZE[2], precision=alt_mode)

@@ -1182,14 +1182,30 @@ __global__ void __launch_bounds__(TPB, 1) k_point_part(ShadeParams P)
     ring.stall_bar = 0;
     ring.stall_bias = 0;
     ring_start<14>(rsrc, wa_, b0, lane, tid, wave_u, lds, ring);
+    // embeddings of the first tile; those of the next tile are fetched while this one is multiplied
+    float4 en[4];
+    int pidx_nx;
+    {
+        const int u0 = blockIdx.x * PPT + wave * 32 + j;
+        const float4 *row = P.point_rows + (int64_t)P.pt_list[u0 < U ? u0 : 0] * 11 + 1 + 4 * h;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) en[i] = row[i];
+        const int u1 = u0 + (int)gridDim.x * PPT;
+        pidx_nx = P.pt_list[u1 < U ? u1 : 0];
+    }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int wa = wa_;
         asm volatile("" : "+s"(wa));
         const int u = tile * PPT + wave * 32 + j;
         const bool ok = u < U;
-        const int pidx = P.pt_list[ok ? u : 0];
-        const float4 *row = P.point_rows + (int64_t)pidx * 11;
-        const float4 e0 = row[1 + 4 * h], e1 = row[2 + 4 * h], e2 = row[3 + 4 * h], e3 = row[4 + 4 * h];
+        const float4 e0 = en[0], e1 = en[1], e2 = en[2], e3 = en[3];
+        {
+            const float4 *row = P.point_rows + (int64_t)pidx_nx * 11 + 1 + 4 * h;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) en[i] = row[i];
+            const int u2 = u + 2 * (int)gridDim.x * PPT;
+            pidx_nx = P.pt_list[u2 < U ? u2 : 0];
+        }
         bf16x8 xh[14], xl[14];
         {
             const float e[16] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w,
@@ -1227,8 +1243,21 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
     const int SPT = (32 / K) * WAVES;
     const int S_valid = P.n_sel[1];
     const int ntiles = (S_valid + SPT - 1) / SPT;
+    // XCD-aware tile order.  Workgroup b runs on XCD b % 8 (round-robin dispatch), one workgroup per CU.  In every
+    // round of gridDim.x tiles XCD x takes the 32 CONSECUTIVE tiles [x * G/8, (x+1) * G/8) of the round, one per
+    // CU: the CUs behind one L2 then work on ~45 neighbouring rays at the same time, and the pt_table / point rows
+    // those rays share (a point serves ~7 pairs) are fetched into that L2 once instead of once per pair.  With a
+    // contiguous tile range per workgroup the 32 CUs of an XCD stream 4 MB of unrelated rows through the 4 MB L2 per
+    // tile time and nearly every gather misses (rocprofv3 FETCH_SIZE: 14.9 GB per launch for 10.8 GB gathered).
+#ifdef PNR_AB_CONTIG_TILES  // diagnostic A/B builds only: one contiguous tile range per workgroup
+    const int G = 1;
     const int t_begin = (int)(((int64_t)ntiles * blockIdx.x) / gridDim.x);
     const int t_end = (int)(((int64_t)ntiles * (blockIdx.x + 1)) / gridDim.x);
+#else
+    const int G = gridDim.x;
+    const int pos = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    const int t_begin = pos, t_end = ntiles;
+#endif
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wbuf), 0, (int)P.wbytes, 0x00020000);
     const int wb_ = (int)(P.w16b_off * 4), w1_ = (int)(P.w16_off[1] * 4), w2_ = (int)(P.w16_off[2] * 4),
@@ -1255,14 +1284,14 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
     fetch_a<K8>(P, t_begin, lane, wave, S_valid, cur);
     fetch_b<K8>(P, cur);
     fetch_c_pair(P, cur);
-    for (int tile = t_begin; tile < t_end; ++tile) {
+    for (int tile = t_begin; tile < t_end; tile += G) {
         int wb = wb_, w1 = w1_, w2 = w2_, w3 = w3_;
         asm volatile("" : "+s"(wb), "+s"(w1), "+s"(w2), "+s"(w3));
         const unsigned long long ts0 = stamp();
         const Camera cam = load_cam_wave(P.cr, cur.cid);
         // first level of the next tile's gather chain (a tile past the end loads row 0: harmless); the other two
         // levels follow at the layer boundaries
-        fetch_a<K8>(P, tile + 1, lane, wave, S_valid, nxt);
+        fetch_a<K8>(P, tile + G, lane, wave, S_valid, nxt);
         __builtin_amdgcn_sched_barrier(0);
         // Point halves of layer 1 (pt_table rows, accumulator order).  A lane reads 512 B in 32 scattered 16-byte
         // loads; 4 waves x 32 of them keep the CU's texture-address unit busy for ~7k cycles (tools/ub_gather.hip)

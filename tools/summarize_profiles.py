@@ -1,0 +1,68 @@
+"""Host side of tools/collect_profiles.sh: turns gpurun_out/prof_final/ into the files kept under profiles/<round>/.
+Usage: python tools/summarize_profiles.py gpurun_out/prof_final profiles/r01"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+src, dst = sys.argv[1], sys.argv[2]
+os.makedirs(dst, exist_ok=True)
+
+
+def one(pattern):
+    hits = glob.glob(os.path.join(src, pattern), recursive=True)
+    if not hits:
+        raise SystemExit(f"missing {pattern} under {src}")
+    return hits[0]
+
+
+for name, out in (("bench_default.json", "bench_cfg1_n1_bf16x3.json"), ("bench_fp32.json", "bench_cfg1_n1_fp32.json"),
+                  ("bench_under_rocprof.json", "bench_cfg1_n1_bf16x3_under_rocprof.json")):
+    shutil.copy(os.path.join(src, name), os.path.join(dst, out))
+
+# kernel stats: keep our kernels (pnr::) and the few largest others
+rows = list(csv.DictReader(open(one("trace/**/*kernel_stats.csv"))))
+keep = [r for r in rows if "pnr::" in r["Name"]] + [r for r in rows if "pnr::" not in r["Name"]][:8]
+with open(os.path.join(dst, "kernel_stats_bench_cfg1_bf16x3.csv"), "w", newline="") as f:
+    w = csv.DictWriter(f, fieldnames=rows[0].keys())
+    w.writeheader()
+    w.writerows(keep)
+# per-dispatch durations of the two dominant kernels (to compare with the HIP-event figure of the same run)
+trace = list(csv.DictReader(open(one("trace/**/*kernel_trace.csv"))))
+disp = defaultdict(list)
+for r in trace:
+    n = r["Kernel_Name"]
+    if "k_shade_pairs" in n or "k_point_part" in n or "k_shade_color" in n:
+        disp[n.split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+json.dump({k: v for k, v in disp.items()}, open(os.path.join(dst, "dispatch_ms_bench_cfg1_bf16x3.json"), "w"), indent=1)
+
+# PMC passes
+out = {"command": "rocprofv3 --pmc <COUNTER> --output-format csv -- python bench.py --steps 2 --warmup 1 --cpu-rays-side 0 "
+                  "(one pass per counter)",
+       "units": "FETCH_SIZE / WRITE_SIZE are reported in KiB; bytes = value * 1024",
+       "gfx950_correction": "FETCH_SIZE reads 1/2 of the bytes of a wide 16-B/lane read (MI355X_MICROARCH.md, HBM): "
+                            "hbm_read_bytes = 2 * FETCH_SIZE * 1024 for the kernels below marked corrected",
+       "kernels": {}}
+for counter, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(one(f"{d}/**/*counter_collection.csv"))):
+        if r["Counter_Name"] == counter and "pnr::" in r["Kernel_Name"]:
+            acc[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        e = out["kernels"].setdefault(k, {})
+        e[f"{counter}_KiB_avg_per_launch"] = sum(v) / len(v)
+        e[f"launches_{counter}"] = len(v)
+        if "k_shade" in k or "k_point_part" in k:
+            # the timed launches are the last ones; warm-up / sizing launches render smaller windows
+            last = v[-2:]
+            e[f"{counter}_KiB_timed_launches"] = last
+for k, e in out["kernels"].items():
+    if "FETCH_SIZE_KiB_timed_launches" in e and "WRITE_SIZE_KiB_timed_launches" in e:
+        f = sum(e["FETCH_SIZE_KiB_timed_launches"]) / len(e["FETCH_SIZE_KiB_timed_launches"])
+        w = sum(e["WRITE_SIZE_KiB_timed_launches"]) / len(e["WRITE_SIZE_KiB_timed_launches"])
+        e["hbm_bytes_per_launch_corrected"] = (2 * f + w) * 1024
+json.dump(out, open(os.path.join(dst, "pmc_hbm_traffic.json"), "w"), indent=1)
+print("wrote", sorted(os.listdir(dst)))
