@@ -39,7 +39,7 @@ extern "C" {
 #define PNR_FEAT_DIM 32          /* point_features_dim  (studio_model.py:79)            */
 #define PNR_MAX_K 32             /* neighbours per sample; the reference breaks at K>8 (cu:14) */
 #define PNR_MAX_D 512            /* coarse samples per ray (z_depth_dim, default 400)   */
-#define PNR_POINT_ROW_FLOATS 44  /* packed point row: xyz conf | emb[32] | color dir pad */
+#define PNR_POINT_ROW_FLOATS 48  /* packed point row (192 B): xyz conf | color dir pad (64 B) | emb[32] */
 #define PNR_MAX_CAMS 16          /* cameras per pnr_render_views call                    */
 
 typedef enum {
@@ -124,7 +124,7 @@ int pnr_scene_build(pnr_scene_t *scene, const float *d_xyz, int64_t N, const pnr
  * [4]=device bytes held, [5]=N, [6]=points inside the grid, [7]=voxel dropped by compat (-1 none) */
 int pnr_scene_info(const pnr_scene_t *scene, int64_t info[8]);
 /* Packs the per-point tensors (studio_utils.py:84-90 layouts: xyz [N,3], embedding [N,32], conf [N],
- * dir [N,3], color [N,3]) into 176-byte rows so one neighbour costs one contiguous gather. */
+ * dir [N,3], color [N,3]) into 192-byte rows so one neighbour costs one contiguous gather. */
 int pnr_points_pack(pnr_scene_t *scene, const float *d_xyz, const float *d_embedding, const float *d_conf,
                     const float *d_dir, const float *d_color, int64_t N, void *stream);
 

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("PNR_LIB") or os.path.join(PKG_DIR, "libpnr_hip.so")
 NUM_COUNTERS = 8
 COUNTER_NAMES = ["rays_hit", "rays_kept", "samples_selected", "samples_valid", "pairs_valid", "candidates",
                  "overflow", "points_unique"]
-POINT_ROW_FLOATS = 44
+POINT_ROW_FLOATS = 48
 MAX_K = 32
 MAX_D = 512
 MAX_CAMS = 16

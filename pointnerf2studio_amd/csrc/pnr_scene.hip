@@ -168,29 +168,34 @@ __global__ void __launch_bounds__(TPB) k_select_first_p(const int *__restrict__ 
 }
 
 // ---- packed point rows --------------------------------------------------------------------------------
-// row = [x y z conf | emb[0:32] | color[3] dir[3] 0 0]  (44 floats, 176 bytes, 16-byte aligned pieces)
+// row = [x y z conf | color[3] dir[3] 0 0 | 0 0 0 0 | emb[0:32]]  (48 floats, 192 bytes, 16-byte aligned pieces)
 __global__ void __launch_bounds__(TPB) k_pack_points(const float *__restrict__ xyz, const float *__restrict__ emb,
                                                       const float *__restrict__ conf, const float *__restrict__ dir,
                                                       const float *__restrict__ color, int64_t N,
                                                       float *__restrict__ rows)
 {
-    // one thread per (point, float4 chunk): 11 chunks per row, coalesced 16-byte stores
+    // one thread per (point, float4 chunk): 12 chunks per 192-byte row, coalesced 16-byte stores.  The 48 bytes a
+    // (sample, neighbour) pair needs in bf16x3 mode (position + conf, colour, direction) lead the row inside one
+    // 64-byte segment, which never straddles a 128-byte line at this stride; the embedding (read per pair only in
+    // fp32 mode, per distinct point by k_point_part) follows.
     int64_t t = (int64_t)blockIdx.x * TPB + threadIdx.x;
-    int64_t i = t / 11;
-    int c = (int)(t - i * 11);
+    int64_t i = t / 12;
+    int c = (int)(t - i * 12);
     if (i >= N) return;
     float4 v;
     if (c == 0) {
         v = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], conf ? conf[i] : 1.0f);
-    } else if (c <= 8) {
-        const float *e = emb + i * PNR_FEAT_DIM + (c - 1) * 4;
-        v = make_float4(e[0], e[1], e[2], e[3]);
-    } else if (c == 9) {
+    } else if (c == 1) {
         v = make_float4(color[3 * i], color[3 * i + 1], color[3 * i + 2], dir[3 * i]);
-    } else {
+    } else if (c == 2) {
         v = make_float4(dir[3 * i + 1], dir[3 * i + 2], 0.f, 0.f);
+    } else if (c == 3) {
+        v = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        const float *e = emb + i * PNR_FEAT_DIM + (c - 4) * 4;
+        v = make_float4(e[0], e[1], e[2], e[3]);
     }
-    reinterpret_cast<float4 *>(rows)[i * 11 + c] = v;
+    reinterpret_cast<float4 *>(rows)[i * 12 + c] = v;
 }
 
 static inline unsigned nblk(int64_t n) { return (unsigned)((n + TPB - 1) / TPB); }
@@ -433,7 +438,7 @@ extern "C" int pnr_points_pack(pnr_scene_t *scene, const float *d_xyz, const flo
         scene->bytes += (size_t)N * PNR_POINT_ROW_FLOATS * sizeof(float);
         scene->packed_N = N;
     }
-    hipLaunchKernelGGL(k_pack_points, dim3(nblk(N * 11)), dim3(TPB), 0, stream, d_xyz, d_embedding, d_conf, d_dir,
+    hipLaunchKernelGGL(k_pack_points, dim3(nblk(N * 12)), dim3(TPB), 0, stream, d_xyz, d_embedding, d_conf, d_dir,
                        d_color, N, scene->point_rows);
     PNR_HIP_CHECK(hipGetLastError());
     scene->packed = true;

@@ -12,7 +12,7 @@
 //     the VGPR file.  The k-order this implies is baked into the packed weights (pnr_weights_pack).
 //   * One wavefront owns 32 rows (4 samples x K=8 neighbours) and all 256 features; one wave per SIMD,
 //     four waves per CU, persistent grid over contiguous tile ranges.
-//   * The gather reads one 176-byte packed row per neighbour; the two lanes that share a row (l, l+32)
+//   * The gather reads one 192-byte packed row per neighbour; the two lanes that share a row (l, l+32)
 //     split its features, so no positional encoding is computed twice.
 //   * K-aggregation is a segmented butterfly over the 8 lanes of a sample, in registers.
 // Two arithmetic modes (pnr_render_opts_t.precision):
@@ -74,7 +74,7 @@ __device__ __forceinline__ float leaky(float x)
 }
 
 struct ShadeParams {
-    const float4 *point_rows;  // [N, 11] float4
+    const float4 *point_rows;  // [N, 12] float4: a0 | c0 | c1 | pad | emb[8]
     const float *wbuf;         // packed weights (fp32 A-operand order, bf16x3 tiles, plain heads, biases)
     size_t wbytes;
     size_t w_off[9];    // float offsets: fp32-packed layers / plain heads
@@ -233,14 +233,14 @@ __device__ __forceinline__ void fetch_b(const ShadeParams &P, RowFetch &f)
 __device__ __forceinline__ void fetch_c(const ShadeParams &P, int lane, RowFetch &f)
 {
     const int h = lane >> 5;
-    const float4 *row = P.point_rows + (int64_t)max(f.pidx, 0) * 11;
+    const float4 *row = P.point_rows + (int64_t)max(f.pidx, 0) * 12;
     f.a0 = row[0];
-    f.e0 = row[1 + 4 * h];
-    f.e1 = row[2 + 4 * h];
-    f.e2 = row[3 + 4 * h];
-    f.e3 = row[4 + 4 * h];
-    f.c0 = row[9];
-    f.c1 = row[10];
+    f.c0 = row[1];
+    f.c1 = row[2];
+    f.e0 = row[4 + 4 * h];
+    f.e1 = row[5 + 4 * h];
+    f.e2 = row[6 + 4 * h];
+    f.e3 = row[7 + 4 * h];
     f.dirx = P.dirs[3 * (int64_t)f.ray];
     f.diry = P.dirs[3 * (int64_t)f.ray + 1];
     f.dirz = P.dirs[3 * (int64_t)f.ray + 2];
@@ -301,10 +301,10 @@ __device__ __forceinline__ int cam_id_flat(const CamRef &cr, const int *valid_in
 __device__ __forceinline__ void fetch_c_pair(const ShadeParams &P, RowFetch &f)
 {
     const int p = max(f.pidx, 0);
-    const float4 *row = P.point_rows + (int64_t)p * 11;
+    const float4 *row = P.point_rows + (int64_t)p * 12;
     f.a0 = row[0];
-    f.c0 = row[9];
-    f.c1 = row[10];
+    f.c0 = row[1];
+    f.c1 = row[2];
     f.urow = min(P.pt_rank[p], P.u_cap - 1);
     f.cid = cam_id_flat(P.cr, P.n_sel, f.ray);
     f.dirx = P.dirs[3 * (int64_t)f.ray];
@@ -1187,7 +1187,7 @@ __global__ void __launch_bounds__(TPB, 1) k_point_part(ShadeParams P)
     int pidx_nx;
     {
         const int u0 = blockIdx.x * PPT + wave * 32 + j;
-        const float4 *row = P.point_rows + (int64_t)P.pt_list[u0 < U ? u0 : 0] * 11 + 1 + 4 * h;
+        const float4 *row = P.point_rows + (int64_t)P.pt_list[u0 < U ? u0 : 0] * 12 + 4 + 4 * h;
 #pragma unroll
         for (int i = 0; i < 4; ++i) en[i] = row[i];
         const int u1 = u0 + (int)gridDim.x * PPT;
@@ -1200,7 +1200,7 @@ __global__ void __launch_bounds__(TPB, 1) k_point_part(ShadeParams P)
         const bool ok = u < U;
         const float4 e0 = en[0], e1 = en[1], e2 = en[2], e3 = en[3];
         {
-            const float4 *row = P.point_rows + (int64_t)pidx_nx * 11 + 1 + 4 * h;
+            const float4 *row = P.point_rows + (int64_t)pidx_nx * 12 + 4 + 4 * h;
 #pragma unroll
             for (int i = 0; i < 4; ++i) en[i] = row[i];
             const int u2 = u + 2 * (int)gridDim.x * PPT;

@@ -150,6 +150,38 @@ def test_render_capacity_overflow_regrows(oracle, gpu_device):
     _check(ref, out)
 
 
+def test_factorised_first_layer_bookkeeping(oracle, gpu_device):
+    """bf16x3 mode contracts the point-only inputs of mlp_base layer 0 once per DISTINCT neighbour point of the call:
+    the published count equals the number of distinct indices in the neighbour lists (integer work: exact), the
+    exact fp32 mode does not use the table (count 0, scene-independent workspace size), and both modes agree."""
+    import ctypes as C
+    pts = small_scene(60000)
+    cfg = oracle_cfg(oracle)
+    w = synthetic.make_weights(0, sigma_scale=300.0, bias_scale=0.1)
+    campos, camrot, dirs = camera_rays(32, 32, az=35.0)
+    scene, wh, hyp, info = build_hip(pts, cfg, gpu_device, weights=w)
+    d = dirs.to(gpu_device)
+    outs = {}
+    for precision in ("bf16x3", "fp32"):
+        rnd = RendererHIP(scene, wh, precision=precision)
+        o = rnd.render(d, campos, camrot, 2.0, 6.0)
+        t = rnd.taps(d.shape[0])
+        S = int(o["counters"]["samples_selected"])
+        pidx = t["smp_pidx"][:S]
+        distinct = int(torch.unique(pidx[pidx >= 0]).numel())
+        if precision == "bf16x3":
+            assert o["counters"]["points_unique"] == distinct > 0
+        else:
+            assert o["counters"]["points_unique"] == 0
+        n_for = rnd.lib.pnr_render_workspace_bytes_for(scene.handle, C.byref(rnd.opts), d.shape[0], rnd.cap_samples)
+        n_base = rnd.lib.pnr_render_workspace_bytes(d.shape[0], rnd.cap_samples, rnd.opts.K)
+        assert (n_for > n_base) if precision == "bf16x3" else (n_for == n_base)
+        outs[precision] = (o["rgb"].clone(), o["depth"].clone(), o["ray_mask"].clone())
+    assert torch.equal(outs["bf16x3"][2], outs["fp32"][2])
+    assert (outs["bf16x3"][0] - outs["fp32"][0]).abs().max().item() <= 2e-5
+    assert (outs["bf16x3"][1] - outs["fp32"][1]).abs().max().item() <= 2e-5
+
+
 def test_render_full_size_properties(gpu_device):
     """Size-independent properties at a larger size than the oracle can check quickly (1M points, 400x400):
     determinism (bitwise equal re-render), tiling invariance (rendering the image in two halves gives the
