@@ -182,6 +182,30 @@ def test_factorised_first_layer_bookkeeping(oracle, gpu_device):
     assert (outs["bf16x3"][1] - outs["fp32"][1]).abs().max().item() <= 2e-5
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_render_edge_cases(oracle, gpu_device, precision):
+    """Empty and ragged inputs: a frame in which no ray meets the cloud (every kernel of the chain sees zero units),
+    a single ray, and a ray count that fills neither a wavefront nor a 128-pair tile."""
+    pts = small_scene(40000)
+    cfg = oracle_cfg(oracle)
+    w = synthetic.make_weights(0, sigma_scale=300.0, bias_scale=0.1)
+    scene, wh, hyp, info = build_hip(pts, cfg, gpu_device, weights=w)
+    rnd = RendererHIP(scene, wh, precision=precision)
+    campos, camrot, dirs = camera_rays(24, 24, az=35.0)
+    # (a) all rays point away from the cloud: background colour, empty mask, zero counters
+    away = (-dirs).contiguous().to(gpu_device)
+    o = rnd.render(away, campos, camrot, 2.0, 6.0)
+    assert o["counters"]["rays_hit"] == 0 and o["counters"]["pairs_valid"] == 0 and o["counters"]["points_unique"] == 0
+    assert int(o["ray_mask"].sum()) == 0 and torch.all(o["rgb"] == 1.0) and torch.all(o["acc"] == 0.0)
+    # (b) ragged ray counts against the oracle (also right after an empty frame: no state carries over)
+    for n in (1, 37, 131):
+        idx = torch.linspace(0, dirs.shape[0] - 1, n).long()
+        d = dirs[idx].contiguous()
+        ref = oracle.render(pts, w, cfg, campos[None].expand(n, 3), d, 2.0, 6.0, camrot)
+        out = rnd.render(d.to(gpu_device), campos, camrot, 2.0, 6.0)
+        _check(ref, out)
+
+
 def test_render_full_size_properties(gpu_device):
     """Size-independent properties at a larger size than the oracle can check quickly (1M points, 400x400):
     determinism (bitwise equal re-render), tiling invariance (rendering the image in two halves gives the
