@@ -347,6 +347,149 @@ __global__ void __launch_bounds__(TPB) k_knn(GridView g, int K, float radius_lim
     }
 }
 
+// The same search with the dependent loads batched (kernel sizes <= 3, i.e. every configuration the reference ships).
+// k_knn above walks cell by cell and candidate by candidate: brick record -> voxel list bounds -> one candidate at a
+// time, ~90 dependent L2 round trips per sample, and a wavefront pays the longest chain of its 64 samples.  Here a
+// thread handles one x-slab (up to 9 cells) at a time: the 9 brick records are loaded together, then the list bounds
+// of the occupied cells together, then each occupied cell's candidates twelve at a time, cells visited in the same
+// order and candidates tested in the same order as the reference, so the lists are identical (slot order included).
+template <int KMAX>
+__global__ void __launch_bounds__(TPB) k_knn3(GridView g, int K, float radius_limit2,
+                                               const float4 *__restrict__ smp_loc, const int *__restrict__ smp_ray,
+                                               const int *__restrict__ n_sel, int *__restrict__ smp_pidx,
+                                               int *__restrict__ smp_valid, int *__restrict__ ray_flag,
+                                               unsigned long long *__restrict__ shards, int *__restrict__ pt_flag)
+{
+    constexpr int CB = 12;  // candidates fetched per batch
+    const int S = n_sel[0];
+    for (int64_t s = (int64_t)blockIdx.x * TPB + threadIdx.x; s < S; s += (int64_t)gridDim.x * TPB) {
+        const float4 c = smp_loc[s];
+        int fx, fy, fz;
+        cell_of(g, c.x, c.y, c.z, fx, fy, fz);  // selected samples are inside the grid by construction
+        int kid = 0, far_ind = 0;
+        float far2 = 0.0f;
+        float buf[KMAX];
+        int out[KMAX];
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) {
+            buf[i] = 0.f;
+            out[i] = -1;
+        }
+        unsigned tested = 0;
+        const int nlayers = (g.kernel_size[0] + 1) / 2;  // 1 or 2
+        for (int layer = 0; layer < nlayers; ++layer) {
+            for (int x = -layer; x <= layer; ++x) {
+                const bool in_x = fx + x >= 0 && fx + x < g.dims[0];
+                // ---- level 1: brick records of the slab's cells (slot = 3 (y + 1) + (z + 1)) -----------------------
+                unsigned long long bits[9];
+                unsigned rank[9];
+                unsigned act = 0;
+#pragma unroll
+                for (int sl = 0; sl < 9; ++sl) {
+                    const int y = sl / 3 - 1, z = sl % 3 - 1;
+                    const bool on = in_x && max(abs(z), max(abs(x), abs(y))) == layer && fy + y >= 0 &&
+                                    fy + y < g.dims[1] && fz + z >= 0 && fz + z < g.dims[2];
+                    bits[sl] = 0;
+                    rank[sl] = 0;
+                    if (on) {
+                        int brick, bit;
+                        brick_of(g, fx + x, fy + y, fz + z, brick, bit);
+                        const BrickRec rec = g.rec[brick];
+                        const unsigned long long mbit = 1ull << bit;
+                        if (rec.bits & mbit) {
+                            act |= 1u << sl;
+                            bits[sl] = rec.bits & (mbit - 1ull);
+                            rank[sl] = rec.rank;
+                        }
+                    }
+                }
+                // ---- level 2: list bounds of the occupied cells ----------------------------------------------------
+                int vs[9], ve[9];
+#pragma unroll
+                for (int sl = 0; sl < 9; ++sl) {
+                    vs[sl] = 0;
+                    ve[sl] = 0;
+                    if (act & (1u << sl)) {
+                        const int v = (int)rank[sl] + __popcll(bits[sl]);
+                        vs[sl] = g.vox_start[v];
+                        ve[sl] = g.vox_start[v + 1];
+                    }
+                }
+                // ---- level 3: occupied cells in slot order, candidates CB at a time --------------------------------
+                while (act) {
+                    const int sl = __ffs(act) - 1;
+                    act &= act - 1;
+                    int q0 = 0, q1 = 0;
+#pragma unroll
+                    for (int i = 0; i < 9; ++i)
+                        if (i == sl) {
+                            q0 = vs[i];
+                            q1 = ve[i];
+                        }
+                    for (int base = q0; base < q1; base += CB) {
+                        float4 p[CB];
+#pragma unroll
+                        for (int b = 0; b < CB; ++b) p[b] = g.cand[min(base + b, q1 - 1)];
+#pragma unroll
+                        for (int b = 0; b < CB; ++b) {
+                            if (base + b >= q1) continue;
+                            const float xv = p[b].x - c.x, yv = p[b].y - c.y, zv = p[b].z - c.z;
+                            const float d2 = xv * xv + yv * yv + zv * zv;  // left-to-right, unfused
+                            ++tested;
+                            if (radius_limit2 == 0.0f || d2 <= radius_limit2) {
+                                const int pidx = __float_as_int(p[b].w);
+                                if (kid++ < K) {
+                                    const int slot = kid - 1;
+#pragma unroll
+                                    for (int i = 0; i < KMAX; ++i)
+                                        if (i == slot) {
+                                            out[i] = pidx;
+                                            buf[i] = d2;
+                                        }
+                                    if (d2 > far2) {
+                                        far2 = d2;
+                                        far_ind = slot;
+                                    }
+                                } else if (d2 < far2) {
+#pragma unroll
+                                    for (int i = 0; i < KMAX; ++i)
+                                        if (i == far_ind) {
+                                            out[i] = pidx;
+                                            buf[i] = d2;
+                                        }
+                                    far2 = d2;
+#pragma unroll
+                                    for (int i = 0; i < KMAX; ++i)
+                                        if (i < K && buf[i] > far2) {
+                                            far2 = buf[i];
+                                            far_ind = i;
+                                        }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (kid >= K) break;
+        }
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i)
+            if (i < K) smp_pidx[s * K + i] = out[i];
+        if (pt_flag) {
+#pragma unroll
+            for (int i = 0; i < KMAX; ++i)
+                if (i < K && out[i] >= 0) pt_flag[out[i]] = 1;
+        }
+        const int nn = min(kid, K);
+        smp_valid[s] = nn > 0;
+        if (nn > 0) {
+            ray_flag[smp_ray[s]] = 1;  // every writer stores the same value
+            shard_add(shards, SH_PAIRS, (unsigned long long)nn);
+        }
+        shard_add(shards, SH_CAND, (unsigned long long)tested);
+    }
+}
+
 // vs_list[voff[s]] = s for samples with >= 1 neighbour; publishes S_valid
 __global__ void __launch_bounds__(TPB) k_compact_valid(const int *__restrict__ smp_valid,
                                                         const int *__restrict__ smp_voff, int *__restrict__ n_sel,
@@ -451,7 +594,14 @@ int launch_knn(const GridView &g, int K, float radius_limit, RenderWs &ws, int64
     const float r2 = radius_limit * radius_limit;  // fp32, as cu:410
     // grid-stride over the device-side sample count; enough workgroups to fill the chip
     const unsigned grid = (unsigned)std::min<int64_t>(nblk(cap), 256 * 32);
-    if (K <= 8)
+    const bool batched = g.kernel_size[0] <= 3;
+    if (batched && K <= 8)
+        hipLaunchKernelGGL(k_knn3<8>, dim3(grid), dim3(TPB), 0, stream, g, K, r2, ws.smp_loc, ws.smp_ray, ws.n_sel,
+                           ws.smp_pidx, ws.smp_valid, ws.ray_flag, acc, pt_flag);
+    else if (batched && K <= 16)
+        hipLaunchKernelGGL(k_knn3<16>, dim3(grid), dim3(TPB), 0, stream, g, K, r2, ws.smp_loc, ws.smp_ray, ws.n_sel,
+                           ws.smp_pidx, ws.smp_valid, ws.ray_flag, acc, pt_flag);
+    else if (K <= 8)
         hipLaunchKernelGGL(k_knn<8>, dim3(grid), dim3(TPB), 0, stream, g, K, r2, ws.smp_loc, ws.smp_ray, ws.n_sel,
                            ws.smp_pidx, ws.smp_valid, ws.ray_flag, acc, pt_flag);
     else if (K <= 16)
