@@ -54,7 +54,7 @@ RenderWs carve_render_ws(void *base, int64_t R, int64_t cap, int K, int64_t N, i
         ws.pt_flag = (int *)take((size_t)N * sizeof(int));
         ws.pt_rank = (int *)take((size_t)(N + 1) * sizeof(int));
         ws.pt_list = (int *)take((size_t)ws.u_cap * sizeof(int));
-        ws.pt_table = (float *)take((size_t)ws.u_cap * 256 * sizeof(float));
+        ws.pt_table = (float *)take((size_t)(ws.u_cap + 128) * 256 * sizeof(float));  // + one tile of padding rows
         ws.pt_scan_temp = take(scan_temp_bytes(N + 1));
     }
     ws.total_pt = off;

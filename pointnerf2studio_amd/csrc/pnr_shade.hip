@@ -1215,18 +1215,22 @@ __global__ void __launch_bounds__(TPB, 1) k_point_part(ShadeParams P)
 #pragma unroll
             for (int s = 0; s < 14; ++s) split8(&x0[8 * s], xh[s], xl[s]);
         }
-        float o[128];
+        // Rows leave through the layer's sink, one 16-byte store per four finished values, between the MFMAs of the
+        // following output tile: a burst of 32 scattered stores per lane behind the layer kept the texture-address
+        // unit busy for as long as the layer's MFMAs take, and the next tile's first counted vmcnt waited for them
+        // (vector memory retires in order).  Lanes beyond U write into the table's 128 padding rows (no branch:
+        // a branch inside the layer would split its basic block).
+        float4 *dst = P.pt_table + (int64_t)u * 64 + 4 * h;
+        float q4[3];
+        auto sink = [&](int t, int r, float v) {
+            if ((r & 3) < 3)
+                q4[r & 3] = v;
+            else
+                dst[8 * t + (r >> 2)] = make_float4(q4[0], q4[1], q4[2], v);
+        };
+        (void)ok;
         dense_layer_bf16<14, 8, 14, false>(rsrc, wa, wa, b0, b0, lane, tid, wave_u, lds, ring, xh, xl, nullptr, nullptr,
-                                           StoreOut{o});
-        if (ok) {
-            float4 *dst = P.pt_table + (int64_t)u * 64 + 4 * h;
-#pragma unroll
-            for (int B = 0; B < 8; ++B)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    dst[8 * B + q] = make_float4(o[16 * B + 4 * q], o[16 * B + 4 * q + 1], o[16 * B + 4 * q + 2],
-                                                 o[16 * B + 4 * q + 3]);
-        }
+                                           sink);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
