@@ -29,7 +29,7 @@ import ctypes as C
 from pointnerf2studio_amd import _lib
 lib = _lib.load()
 total = lib.pnr_render_workspace_bytes(dirs.shape[0], cap, 8)
-agg_bytes = cap * 256 * 4
+agg_bytes = (cap + 32) * 256 * 4
 sigma_bytes = (cap * 4 + 255) // 256 * 256
 sigma_off = total - ((agg_bytes + 255) // 256 * 256) - sigma_bytes
 raw = rnd._ws[sigma_off + (cap - 8192) * 4: sigma_off + cap * 4].view(torch.int64).view(-1, 8)[:256].cpu().double()
