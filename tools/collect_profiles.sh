@@ -5,6 +5,7 @@
 set -e -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_final
+rm -rf $O
 mkdir -p $O
 echo "[1/5] bench (default flags)"; python bench.py > $O/bench_default.json 2> $O/bench_default.err
 echo "[2/5] bench fp32"; python bench.py --precision fp32 --cpu-rays-side 0 > $O/bench_fp32.json 2> $O/bench_fp32.err

@@ -16,7 +16,7 @@ def one(pattern):
     hits = glob.glob(os.path.join(src, pattern), recursive=True)
     if not hits:
         raise SystemExit(f"missing {pattern} under {src}")
-    return hits[0]
+    return max(hits, key=os.path.getmtime)  # the newest run if the directory holds several
 
 
 for name, out in (("bench_default.json", "bench_cfg1_n1_bf16x3.json"), ("bench_fp32.json", "bench_cfg1_n1_fp32.json"),
