@@ -188,7 +188,7 @@ def main():
     rnd.render_views(d0, c0, shard.n_pad, cap_samples=cap, out=outs)
 
     lib = _lib.load()
-    n_calls_max = max(args.steps, 1)
+    n_calls_max = max(args.steps, 4)  # the side legs (other mode, early termination) time up to 3 steps
     counters_all = torch.zeros((n_calls_max, _lib.NUM_COUNTERS), dtype=torch.int64, device=dev)
 
     def run_steps(renderer, first, count, counters=None):
@@ -297,6 +297,26 @@ def main():
         alt = {"mode": alt_mode, "value": rays_per_step * 2 / a_el, "unit": "rays/s", "ms_per_step": a_el / 2 * 1e3,
                "roofline": roofline(alt_mode, a_ms, a_cnt, a_n)}
 
+    # opt-in early ray termination (pnr_render_opts_t.early_stop_eps), for the record: NOT part of `value`, which
+    # keeps the reference's sample set (every sample with a neighbour is shaded)
+    early = None
+    if world == 1 and not emulate and not args.no_other_mode:
+        rnd_es = RendererHIP(scene, wh, SR=SR, K=K, D=400, radius_limit=4 * max(VSIZE[0], VSIZE[1]),
+                             vsize_z=VSIZE[2], precision=args.precision, early_stop_eps=1e-5)
+        rnd_es._ws, rnd_es._ws_key, rnd_es.cap_samples = rnd._ws, rnd._ws_key, rnd.cap_samples
+        run_steps(rnd_es, 0, 1)
+        e_rgb = outs["rgb"].clone()
+        run_steps(rnd, 0, 1)
+        e_err = (outs["rgb"] - e_rgb).abs().max().item()
+        e_el, e_ms, e_cnt, e_n = timed(rnd_es, 3, 1)
+        early = {"early_stop_eps": 1e-5, "value": rays_per_step * 3 / e_el, "unit": "rays/s",
+                 "ms_per_step": e_el / 3 * 1e3,
+                 "stages_ms_per_launch": {n: e_ms[i] / e_n for i, n in enumerate(_lib.STAGE_NAMES)},
+                 "samples_valid_per_launch": e_cnt[3] / e_n, "samples_shaded_per_launch": e_cnt[8] / e_n,
+                 "max_abs_rgb_diff_vs_full_render": e_err,
+                 "note": "rays stop being shaded once their transmittance is below eps (chunks of 3, 3, 6, 12, rest "
+                         "samples); the reference shades every sample, so this is reported beside `value`, never as it"}
+
     if rank == 0 or emulate:
         samples = acc_cnt[3]
         result = {
@@ -322,6 +342,8 @@ def main():
         }
         if alt is not None:
             result["other_mode"] = alt
+        if early is not None:
+            result["with_early_ray_termination"] = early
         if world == 1 and not emulate and args.cpu_rays_side > 0:
             cb, ref, dirs, campos, camrot = cpu_baseline(points, weights, cfgd, args.cpu_rays_side, azimuths[0])
             # parity on the very same rays: HIP render vs the oracle that was just timed

@@ -88,6 +88,10 @@ typedef struct {
     float jitter;          /* coarse-sample jitter as a fraction of the step (the reference hard-codes 0.3,
                               studio_utils.py:166); 0 = the mid-points of the table                      */
     uint32_t seed;         /* seed of the counter-based uniforms u(seed, ray, sample) used when jitter > 0 */
+    float early_stop_eps;  /* 0 (default): every selected sample with a neighbour is shaded, as the reference does.
+                              > 0: early ray termination -- samples are shaded front to back in chunks (3, 3, 6, 12,
+                              rest of a ray's samples) and a ray whose transmittance has fallen below eps is not
+                              shaded further; the skipped samples would change the pixel by less than eps.        */
 } pnr_render_opts_t;
 
 /* MLP arithmetic.  FP32: v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fma chain.  BF16X3: every fp32 product is
@@ -106,7 +110,9 @@ enum {
     PNR_CNT_CANDIDATES = 5,     /* candidates distance-tested                                */
     PNR_CNT_OVERFLOW = 6,       /* != 0: cap_samples was too small, output incomplete        */
     PNR_CNT_POINTS_UNIQUE = 7,  /* U   distinct neighbour points (bf16x3 mode; 0 in fp32 mode)      */
-    PNR_NUM_COUNTERS = 8
+    PNR_CNT_SAMPLES_SHADED = 8, /* samples that went through the MLPs (= SAMPLES_VALID unless early_stop_eps > 0) */
+    PNR_CNT_RESERVED = 9,
+    PNR_NUM_COUNTERS = 10
 };
 
 const char *pnr_last_error(void);

@@ -12,9 +12,9 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # PNR_LIB overrides the library path for diagnostic (ablation) builds; never set in normal use
 LIB_PATH = os.environ.get("PNR_LIB") or os.path.join(PKG_DIR, "libpnr_hip.so")
 
-NUM_COUNTERS = 8
+NUM_COUNTERS = 10
 COUNTER_NAMES = ["rays_hit", "rays_kept", "samples_selected", "samples_valid", "pairs_valid", "candidates",
-                 "overflow", "points_unique"]
+                 "overflow", "points_unique", "samples_shaded", "reserved"]
 POINT_ROW_FLOATS = 48
 MAX_K = 32
 MAX_D = 512
@@ -47,7 +47,8 @@ class CameraC(C.Structure):
 
 class RenderOpts(C.Structure):
     _fields_ = [("SR", C.c_int32), ("K", C.c_int32), ("D", C.c_int32), ("radius_limit", C.c_float),
-                ("vsize_z", C.c_float), ("eval_clamp", C.c_int32), ("bg", C.c_float * 3), ("precision", C.c_int32), ("jitter", C.c_float), ("seed", C.c_uint32)]
+                ("vsize_z", C.c_float), ("eval_clamp", C.c_int32), ("bg", C.c_float * 3), ("precision", C.c_int32), ("jitter", C.c_float), ("seed", C.c_uint32),
+                ("early_stop_eps", C.c_float)]
 
 
 PRECISION = {"fp32": 0, "bf16x3": 1}

@@ -213,7 +213,14 @@ struct RenderWs {
     float *smp_sigma;  // [cap] by valid index
     float *agg;        // [cap, 256] by valid index
     float4 *smp_out;   // [cap]
-    int *n_sel;        // device ints: [0]=S_sel (clamped to cap), [1]=S_valid, [2]=R, [3]=U unique neighbour points
+    // early ray termination (opts.early_stop_eps > 0): shade-only buffers behind agg
+    float *smp_sig_s;  // [cap] density by SAMPLE index, 0 for samples not (yet) shaded
+    int *vs_all;       // [cap] samples in shading order: the passes' lists back to back
+    float *ray_T;      // [R] transmittance after the chunks shaded so far
+    float *ray_cm;     // [R] running maximum of the camera-space depth (ray_dist state of the composite)
+    int *ray_alive;    // [R]
+    int *n_sel;        // device ints: [0]=S_sel (clamped to cap), [1]=S_valid, [2]=R, [3]=U unique neighbour points,
+                       // [4],[5] = first / one-past-last position of the current shading pass in vs_all, [6] = 0
     unsigned long long *shards;  // statistics counters, SHARDS x 128-byte lines per counter (see shard_add)
     Camera *cams;                // [PNR_MAX_CAMS] cameras of the call
     void *scan_temp;
@@ -252,9 +259,9 @@ int launch_select_expand(const GridView &g, const CamRef &cr, const float *d_dir
                          hipStream_t stream);
 int launch_knn(const GridView &g, int K, float radius_limit, RenderWs &ws, int64_t cap, int64_t *d_counters,
                hipStream_t stream, int64_t N = 0);
-int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr, const float *d_dirs, int K,
-                 int precision, RenderWs &ws, int64_t cap, hipStream_t stream, hipEvent_t ev_points,
-                 hipEvent_t ev_between);
+int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr, const float *d_dirs,
+                 const pnr_render_opts_t &opts, int64_t R, RenderWs &ws, int64_t cap, int64_t *d_counters,
+                 hipStream_t stream, hipEvent_t ev_points, hipEvent_t ev_between);
 int launch_composite(const CamRef &cr, const pnr_render_opts_t &opts, int64_t R, RenderWs &ws, float *d_rgb,
                      float *d_depth, float *d_acc, int8_t *d_ray_mask, int64_t *d_counters,
                      hipStream_t stream);

@@ -48,6 +48,11 @@ RenderWs carve_render_ws(void *base, int64_t R, int64_t cap, int K, int64_t N, i
     // shade-only buffers last so that the query-only workspace is a prefix
     ws.smp_sigma = (float *)take((size_t)cap * sizeof(float));
     ws.agg = (float *)take((size_t)(cap + 32) * 256 * sizeof(float));  // packed layout: whole 32-sample blocks
+    ws.smp_sig_s = (float *)take((size_t)cap * sizeof(float));
+    ws.vs_all = (int *)take((size_t)cap * sizeof(int));
+    ws.ray_T = (float *)take((size_t)R * sizeof(float));
+    ws.ray_cm = (float *)take((size_t)R * sizeof(float));
+    ws.ray_alive = (int *)take((size_t)R * sizeof(int));
     ws.total = off;
     if (N > 0) {
         ws.u_cap = std::max<int64_t>(1, std::min<int64_t>(n_list, cap * (int64_t)K));

@@ -189,6 +189,8 @@ static int render_views(const pnr_scene_t *scene, const pnr_weights_t *weights, 
     PNR_REQUIRE(opts->K >= 1 && opts->K <= PNR_MAX_K, "%s: K=%d not in [1,%d]", who, opts->K, PNR_MAX_K);
     PNR_REQUIRE(opts->SR >= 1, "%s: SR=%d", who, opts->SR);
     PNR_REQUIRE(opts->jitter >= 0.f && opts->jitter < 1.f, "%s: jitter=%g not in [0,1)", who, opts->jitter);
+    PNR_REQUIRE(opts->early_stop_eps >= 0.f && opts->early_stop_eps <= 0.01f, "%s: early_stop_eps=%g not in [0, 0.01]",
+                who, opts->early_stop_eps);
     PNR_REQUIRE(opts->precision == PNR_PRECISION_FP32 || opts->precision == PNR_PRECISION_BF16X3,
                 "%s: unknown precision %d", who, opts->precision);
     PNR_REQUIRE(cap_samples >= 1 && cap_samples < (int64_t)0x7FFFFFF0 / std::max(opts->K, 1),
@@ -230,7 +232,7 @@ static int render_views(const pnr_scene_t *scene, const pnr_weights_t *weights, 
     if (rc != PNR_OK) return rc;
     if (prof) PNR_HIP_CHECK(hipEventRecord(g_ev[2], stream));
     // events in time order: 0 select 1 knn 2 point-part 6 shade-pairs 3 shade-colour 4 composite 5
-    rc = launch_shade(scene, weights, cr, d_dirs, opts->K, opts->precision, ws, cap_samples, stream,
+    rc = launch_shade(scene, weights, cr, d_dirs, *opts, R, ws, cap_samples, d_counters, stream,
                       prof ? g_ev[6] : nullptr, prof ? g_ev[3] : nullptr);
     if (rc != PNR_OK) return rc;
     if (prof) PNR_HIP_CHECK(hipEventRecord(g_ev[4], stream));

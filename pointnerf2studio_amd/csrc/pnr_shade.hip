@@ -94,6 +94,8 @@ struct ShadeParams {
     int K;
     long long dbg_off;  // PNR_STAMPS builds: float offset into smp_sigma of the stamp area
     // bf16x3 mode: factorised first layer
+    int i_v0, i_v1;        // the kernel works on positions [n_sel[i_v0], n_sel[i_v1]) of vs_list
+    float *smp_sig_s;      // [S_sel] density by sample index (early ray termination), may be null
     size_t w16a_off, w16b_off, w4acc_off, w8acc_off;
     const int *pt_rank;     // [N+1] point index -> row of pt_table
     const int *pt_list;     // [U] rows -> point index
@@ -182,6 +184,7 @@ __device__ __forceinline__ float seg_sum(float v, int K, int lane)
 // rows of a tile: gather + per-row features (shared by both arithmetic modes)
 // ------------------------------------------------------------------------------------------------
 struct RowCtx {
+    int s;        // sample index of this lane's row
     int v_idx;    // valid-sample index of this lane's row
     int slot;     // neighbour slot of the row
     bool row_ok;  // the row maps to a real (sample, slot)
@@ -203,14 +206,15 @@ struct RowFetch {
 };
 
 template <bool K8>
-__device__ __forceinline__ void fetch_a(const ShadeParams &P, int tile, int lane, int wave, int S_valid, RowFetch &f)
+__device__ __forceinline__ void fetch_a(const ShadeParams &P, int tile, int lane, int wave, int V0, int S_valid,
+                                        RowFetch &f)
 {
     const int j = lane & 31;
     const int K = K8 ? 8 : P.K;
     const int SPW = 32 / K;
     const int SPT = SPW * WAVES;
     const int sl = j / K;
-    f.v_idx = tile * SPT + wave * SPW + sl;
+    f.v_idx = V0 + tile * SPT + wave * SPW + sl;
     f.row_ok = (j < SPW * K) && (f.v_idx < S_valid);
     f.slot = j - sl * K;
     // unconditional loads at clamped indices: a branch here would end the basic block, and hipcc then sinks the
@@ -349,6 +353,7 @@ __device__ __forceinline__ void pair_inputs(const ShadeParams &P, const RowFetch
 {
     const int h = lane >> 5;
     const int K = K8 ? 8 : P.K;
+    ctx.s = f.s;
     ctx.v_idx = f.v_idx;
     ctx.row_ok = f.row_ok;
     ctx.slot = f.slot;
@@ -423,11 +428,11 @@ __device__ __forceinline__ void compute_rows(const ShadeParams &P, const RowFetc
 }
 
 template <bool K8, bool FAST_PE>
-__device__ __forceinline__ void load_rows(const ShadeParams &P, int tile, int lane, int wave, int S_valid,
+__device__ __forceinline__ void load_rows(const ShadeParams &P, int tile, int lane, int wave, int V0, int S_valid,
                                           float (&x0)[144], RowCtx &ctx)
 {
     RowFetch f;
-    fetch_a<K8>(P, tile, lane, wave, S_valid, f);
+    fetch_a<K8>(P, tile, lane, wave, V0, S_valid, f);
     fetch_b<K8>(P, f);
     fetch_c(P, lane, f);
     compute_rows<K8, FAST_PE>(P, f, lane, x0, ctx);
@@ -539,7 +544,10 @@ __device__ __forceinline__ void finish_rows(const ShadeParams &P, int lane, cons
     const float alpha = fmaxf(part + b4, 0.f);
     const float sigma = seg_sum<K8>(alpha * ctx.wgt, K, lane);
     const bool writer = ctx.row_ok && ctx.slot == 0;
-    if (writer && h == 0) P.smp_sigma[ctx.v_idx] = sigma;
+    if (writer && h == 0) {
+        P.smp_sigma[ctx.v_idx] = sigma;
+        if (P.smp_sig_s) P.smp_sig_s[ctx.s] = sigma;
+    }
     float *dst = P.agg + (int64_t)ctx.v_idx * 256;
 #pragma unroll
     for (int m = 0; m < 8; ++m)
@@ -680,8 +688,8 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
     const int wave = threadIdx.x >> 6;
     const int K = K8 ? 8 : P.K;
     const int SPT = (32 / K) * WAVES;  // samples per workgroup tile
-    const int S_valid = P.n_sel[1];
-    const int ntiles = (S_valid + SPT - 1) / SPT;
+    const int V0 = P.n_sel[P.i_v0], S_valid = P.n_sel[P.i_v1];
+    const int ntiles = (S_valid - V0 + SPT - 1) / SPT;
     // contiguous tile range per workgroup: neighbouring samples (same / adjacent rays) stay on one XCD's L2
     const int t_begin = (int)(((int64_t)ntiles * blockIdx.x) / gridDim.x);
     const int t_end = (int)(((int64_t)ntiles * (blockIdx.x + 1)) / gridDim.x);
@@ -700,7 +708,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
         asm volatile("" : "+s"(w0), "+s"(w1), "+s"(w2), "+s"(w3));
         float x0[144];
         RowCtx ctx;
-        load_rows<K8, false>(P, tile, lane, wave, S_valid, x0, ctx);
+        load_rows<K8, false>(P, tile, lane, wave, V0, S_valid, x0, ctx);
 
         float hA[128];
         dense_layer<144, 8>(rsrc, w0, b0, lane, x0, hA);
@@ -733,9 +741,9 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_color(ShadeParams P)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
-    const int S_valid = P.n_sel[1];
+    const int V0 = P.n_sel[P.i_v0], S_valid = P.n_sel[P.i_v1];
     constexpr int SPT = 32 * WAVES;
-    const int ntiles = (S_valid + SPT - 1) / SPT;
+    const int ntiles = (S_valid - V0 + SPT - 1) / SPT;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wbuf), 0, (int)P.wbytes, 0x00020000);
     const int w5_ = (int)(P.w_off[5] * 4), w6_ = (int)(P.w_off[6] * 4), w7_ = (int)(P.w_off[7] * 4);
@@ -744,7 +752,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_color(ShadeParams P)
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int w5 = w5_, w6 = w6_, w7 = w7_;
         asm volatile("" : "+s"(w5), "+s"(w6), "+s"(w7));
-        const int v_idx = tile * SPT + wave * 32 + j;
+        const int v_idx = V0 + tile * SPT + wave * 32 + j;  // colour kernels are launched with V0 = 0
         const bool ok = v_idx < S_valid;
         const int s = ok ? P.vs_list[v_idx] : 0;
         const int ray = P.smp_ray[s];
@@ -1245,8 +1253,8 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int K = K8 ? 8 : P.K;
     const int SPT = (32 / K) * WAVES;
-    const int S_valid = P.n_sel[1];
-    const int ntiles = (S_valid + SPT - 1) / SPT;
+    const int V0 = P.n_sel[P.i_v0], S_valid = P.n_sel[P.i_v1];
+    const int ntiles = (S_valid - V0 + SPT - 1) / SPT;
     // XCD-aware tile order.  Workgroup b runs on XCD b % 8 (round-robin dispatch), one workgroup per CU.  In every
     // round of gridDim.x tiles XCD x takes the 32 CONSECUTIVE tiles [x * G/8, (x+1) * G/8) of the round, one per
     // CU: the CUs behind one L2 then work on ~45 neighbouring rays at the same time, and the pt_table / point rows
@@ -1285,7 +1293,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
     ring_start<8>(rsrc, wb_, nullptr, lane, tid, wave_u, lds, ring);
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     RowFetch cur, nxt;
-    fetch_a<K8>(P, t_begin, lane, wave, S_valid, cur);
+    fetch_a<K8>(P, t_begin, lane, wave, V0, S_valid, cur);
     fetch_b<K8>(P, cur);
     fetch_c_pair(P, cur);
     for (int tile = t_begin; tile < t_end; tile += G) {
@@ -1295,7 +1303,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
         const Camera cam = load_cam_wave(P.cr, cur.cid);
         // first level of the next tile's gather chain (a tile past the end loads row 0: harmless); the other two
         // levels follow at the layer boundaries
-        fetch_a<K8>(P, tile + G, lane, wave, S_valid, nxt);
+        fetch_a<K8>(P, tile + G, lane, wave, V0, S_valid, nxt);
         __builtin_amdgcn_sched_barrier(0);
         // Point halves of layer 1 (pt_table rows, accumulator order).  A lane reads 512 B in 32 scattered 16-byte
         // loads; 4 waves x 32 of them keep the CU's texture-address unit busy for ~7k cycles (tools/ub_gather.hip)
@@ -1398,7 +1406,10 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
             const float alpha = fmaxf(part + b4, 0.f);
             const float sigma = seg_sum<true>(alpha * ctx.wgt, 8, lane);
             if (ctx.row_ok) {
-                if (ctx.slot == 0 && lane < 32) P.smp_sigma[ctx.v_idx] = sigma;
+                if (ctx.slot == 0 && lane < 32) {
+                    P.smp_sigma[ctx.v_idx] = sigma;
+                    if (P.smp_sig_s) P.smp_sig_s[ctx.s] = sigma;
+                }
                 float4 *agg4 = reinterpret_cast<float4 *>(P.agg);
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -1445,9 +1456,9 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_color_bf16(ShadeParams P)
     const int wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int j = lane & 31, h = lane >> 5;
-    const int S_valid = P.n_sel[1];
+    const int V0 = P.n_sel[P.i_v0], S_valid = P.n_sel[P.i_v1];
     constexpr int SPT = 32 * WAVES;
-    const int ntiles = (S_valid + SPT - 1) / SPT;
+    const int ntiles = (S_valid - V0 + SPT - 1) / SPT;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wbuf), 0, (int)P.wbytes, 0x00020000);
     const int w5_ = (int)(P.w16_off[5] * 4), w6_ = (int)(P.w16_off[6] * 4), w7_ = (int)(P.w16_off[7] * 4);
@@ -1469,7 +1480,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_color_bf16(ShadeParams P)
     int s_nx, ray_nx;
     float dnx[3];
     {
-        const int v0 = blockIdx.x * SPT + wave * 32 + j;
+        const int v0 = V0 + blockIdx.x * SPT + wave * 32 + j;
         s_nx = P.vs_list[v0 < S_valid ? v0 : 0];
         ray_nx = P.smp_ray[s_nx];
 #pragma unroll
@@ -1478,7 +1489,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_color_bf16(ShadeParams P)
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int w5 = w5_, w6 = w6_, w7 = w7_;
         asm volatile("" : "+s"(w5), "+s"(w6), "+s"(w7));
-        const int v_idx = tile * SPT + wave * 32 + j;
+        const int v_idx = V0 + tile * SPT + wave * 32 + j;  // colour kernels are launched with V0 = 0
         const bool ok = v_idx < S_valid;
         const int s = s_nx;
         const float dir[3] = {dnx[0], dnx[1], dnx[2]};
@@ -1667,10 +1678,127 @@ __global__ void k_copy(const float *__restrict__ src, int n, float *__restrict__
     if (i < n) dst[i] = src[i];
 }
 
-int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr, const float *d_dirs, int K,
-                 int precision, RenderWs &ws, int64_t cap, hipStream_t stream, hipEvent_t ev_points,
-                 hipEvent_t ev_between)
+// ------------------------------------------------------------------------------------------------
+// early ray termination (opts.early_stop_eps > 0): samples are shaded front to back in chunks of a ray's sample
+// index; between the chunks a ray whose transmittance fell below eps leaves.  Everything stays on the device.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TPB) k_pass_init(int64_t R, float *__restrict__ ray_T, int *__restrict__ ray_alive,
+                                                   int *__restrict__ n_sel)
 {
+    const int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (r == 0) {
+        n_sel[4] = 0;
+        n_sel[5] = 0;
+        n_sel[6] = 0;
+    }
+    if (r >= R) return;
+    ray_T[r] = 1.0f;
+    ray_alive[r] = 1;
+}
+
+// flag[v] = valid sample v belongs to a live ray and its index inside the ray is in [lo, hi)
+__global__ void __launch_bounds__(TPB) k_pass_flag(const int *__restrict__ n_sel, const int *__restrict__ vs_list,
+                                                   const int *__restrict__ smp_ray, const int *__restrict__ ray_off,
+                                                   const int *__restrict__ ray_alive, int lo, int hi,
+                                                   int *__restrict__ flag)
+{
+    const int S_valid = n_sel[1];
+    for (int64_t v = (int64_t)blockIdx.x * TPB + threadIdx.x; v < S_valid; v += (int64_t)gridDim.x * TPB) {
+        const int s = vs_list[v];
+        const int r = smp_ray[s];
+        const int i = s - ray_off[r];
+        flag[v] = (ray_alive[r] && i >= lo && i < hi) ? 1 : 0;
+    }
+}
+
+__global__ void __launch_bounds__(TPB) k_pass_scatter(const int *__restrict__ n_sel, const int *__restrict__ vs_list,
+                                                      const int *__restrict__ flag, const int *__restrict__ pos,
+                                                      int *__restrict__ vs_all)
+{
+    const int S_valid = n_sel[1], base = n_sel[5];
+    for (int64_t v = (int64_t)blockIdx.x * TPB + threadIdx.x; v < S_valid; v += (int64_t)gridDim.x * TPB)
+        if (flag[v]) vs_all[base + pos[v]] = vs_list[v];
+}
+
+// the pass just listed occupies positions [n_sel[4], n_sel[5]) of vs_all
+__global__ void k_pass_advance(int *__restrict__ n_sel, const int *__restrict__ pos)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const int count = pos[n_sel[1]];
+        n_sel[4] = n_sel[5];
+        n_sel[5] = n_sel[5] + count;
+    }
+}
+
+// transmittance of the live rays after samples [lo, hi): the composite's own arithmetic (k_composite, same
+// ray_dist quirks), so that "T < eps" means what it means there
+__global__ void __launch_bounds__(TPB) k_pass_update(CamRef cr, pnr_render_opts_t opts, int64_t R,
+                                                     const int *__restrict__ ray_cnt, const int *__restrict__ ray_off,
+                                                     const float4 *__restrict__ smp_loc,
+                                                     const float *__restrict__ smp_sig_s, const int *__restrict__ n_sel,
+                                                     int lo, int hi, float *__restrict__ ray_T,
+                                                     float *__restrict__ ray_cm, int *__restrict__ ray_alive)
+{
+    const int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (r >= R || !ray_alive[r]) return;
+    const int S = n_sel[0];
+    const int off = ray_off[r];
+    int cnt = ray_cnt[r];
+    if ((int64_t)off + cnt > S) cnt = max(0, S - off);
+    if (lo >= cnt) {
+        ray_alive[r] = 0;
+        return;
+    }
+    const Camera cam = load_cam_lanes(cr, cam_id(cr, r));
+    const float vs = opts.vsize_z, two_vs = 2.0f * vs;
+    auto zc = [&](float x, float y, float z) {
+        const float sx = x - cam.o[0], sy = y - cam.o[1], sz = z - cam.o[2];
+        return sx * cam.R[2] + sy * cam.R[5] + sz * cam.R[8];
+    };
+    const float z_unfilled = zc(0.f, 0.f, 0.f);
+    float cm;
+    if (lo == 0) {
+        const float4 p = smp_loc[off];
+        cm = zc(p.x, p.y, p.z);
+    } else {
+        cm = ray_cm[r];
+    }
+    float T = ray_T[r];
+    const int end = min(hi, cnt);
+    for (int i = lo; i < end; ++i) {
+        float delta;
+        if (i == opts.SR - 1) {
+            delta = vs;
+        } else {
+            float z_next = z_unfilled;
+            if (i + 1 < cnt) {
+                const float4 p = smp_loc[off + i + 1];
+                z_next = zc(p.x, p.y, p.z);
+            }
+            const float cm_next = fmaxf(cm, z_next);
+            delta = cm_next - cm;
+            cm = cm_next;
+            if (delta < 1e-8f || delta > two_vs) delta = vs;
+        }
+        const float opacity = 1.0f - expf(-smp_sig_s[off + i] * delta);
+        T = T * (1.0f - opacity + 1e-10f);
+    }
+    ray_T[r] = T;
+    ray_cm[r] = cm;
+    ray_alive[r] = (T > opts.early_stop_eps && hi < cnt) ? 1 : 0;
+}
+
+__global__ void k_publish_shaded(const int *__restrict__ n_sel, int idx, int64_t *__restrict__ counters)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) counters[PNR_CNT_SAMPLES_SHADED] = n_sel[idx];
+}
+
+int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr, const float *d_dirs,
+                 const pnr_render_opts_t &opts, int64_t R, RenderWs &ws, int64_t cap, int64_t *d_counters,
+                 hipStream_t stream, hipEvent_t ev_points, hipEvent_t ev_between)
+{
+    const int K = opts.K, precision = opts.precision;
+    const bool early = opts.early_stop_eps > 0.f;
     ShadeParams P{};
     P.point_rows = reinterpret_cast<const float4 *>(scene->point_rows);
     P.wbuf = w->buf;
@@ -1686,8 +1814,11 @@ int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr,
     P.smp_loc = ws.smp_loc;
     P.smp_ray = ws.smp_ray;
     P.smp_pidx = ws.smp_pidx;
-    P.vs_list = ws.vs_list;
+    P.vs_list = early ? ws.vs_all : ws.vs_list;
     P.n_sel = ws.n_sel;
+    P.i_v0 = early ? 4 : 6;  // n_sel[6] == 0
+    P.i_v1 = early ? 5 : 1;
+    P.smp_sig_s = early ? ws.smp_sig_s : nullptr;
     P.smp_sigma = ws.smp_sigma;
     P.agg = ws.agg;
     P.smp_out = ws.smp_out;
@@ -1704,7 +1835,7 @@ int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr,
     int dev = 0, cus = 256;
     PNR_HIP_CHECK(hipGetDevice(&dev));
     PNR_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    // decoded features of samples without neighbours are zero (studio_model.py:361-362)
+    // decoded features of samples without neighbours (or not shaded) are zero (studio_model.py:361-362)
     PNR_HIP_CHECK(hipMemsetAsync(ws.smp_out, 0, (size_t)cap * sizeof(float4), stream));
     const int spt = (32 / K) * WAVES;
     const int64_t max_tiles = (cap + spt - 1) / spt;
@@ -1720,17 +1851,49 @@ int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr,
                            0, stream, P);
     }
     if (ev_points) PNR_HIP_CHECK(hipEventRecord(ev_points, stream));
-    if (K == 8) {
-        if (bf)
-            hipLaunchKernelGGL(k_shade_pairs_bf16<true>, dim3(grid), dim3(TPB), 0, stream, P);
-        else
-            hipLaunchKernelGGL(k_shade_pairs<true>, dim3(grid), dim3(TPB), 0, stream, P);
+    auto launch_pairs = [&]() {
+        if (K == 8) {
+            if (bf)
+                hipLaunchKernelGGL(k_shade_pairs_bf16<true>, dim3(grid), dim3(TPB), 0, stream, P);
+            else
+                hipLaunchKernelGGL(k_shade_pairs<true>, dim3(grid), dim3(TPB), 0, stream, P);
+        } else {
+            if (bf)
+                hipLaunchKernelGGL(k_shade_pairs_bf16<false>, dim3(grid), dim3(TPB), 0, stream, P);
+            else
+                hipLaunchKernelGGL(k_shade_pairs<false>, dim3(grid), dim3(TPB), 0, stream, P);
+        }
+    };
+    if (!early) {
+        launch_pairs();
     } else {
-        if (bf)
-            hipLaunchKernelGGL(k_shade_pairs_bf16<false>, dim3(grid), dim3(TPB), 0, stream, P);
-        else
-            hipLaunchKernelGGL(k_shade_pairs<false>, dim3(grid), dim3(TPB), 0, stream, P);
+        const unsigned rgrid = (unsigned)((R + TPB - 1) / TPB);
+        const unsigned sgrid = (unsigned)std::min<int64_t>((cap + TPB - 1) / TPB, 256 * 32);
+        PNR_HIP_CHECK(hipMemsetAsync(ws.smp_sig_s, 0, (size_t)cap * sizeof(float), stream));
+        hipLaunchKernelGGL(k_pass_init, dim3(rgrid), dim3(TPB), 0, stream, R, ws.ray_T, ws.ray_alive, ws.n_sel);
+        int *flag = ws.smp_valid, *pos = ws.smp_voff;  // free again once the valid samples are listed
+#ifndef PNR_ES_BOUNDS
+#define PNR_ES_BOUNDS 0, 3, 6, 12, 24
+#endif
+        static const int bounds[] = {PNR_ES_BOUNDS};
+        constexpr int NP = (int)(sizeof(bounds) / sizeof(bounds[0]));
+        for (int p = 0; p < NP; ++p) {
+            const int lo = bounds[p], hi = (p + 1 < NP) ? std::min(bounds[p + 1], opts.SR) : opts.SR;
+            if (lo >= opts.SR) break;
+            hipLaunchKernelGGL(k_pass_flag, dim3(sgrid), dim3(TPB), 0, stream, ws.n_sel, ws.vs_list, ws.smp_ray,
+                               ws.ray_off, ws.ray_alive, lo, hi, flag);
+            int rc = scan_exclusive_i32(flag, pos, cap, ws.n_sel + 1, nullptr, ws.scan_temp, stream);
+            if (rc != PNR_OK) return rc;
+            hipLaunchKernelGGL(k_pass_scatter, dim3(sgrid), dim3(TPB), 0, stream, ws.n_sel, ws.vs_list, flag, pos,
+                               ws.vs_all);
+            hipLaunchKernelGGL(k_pass_advance, dim3(1), dim3(64), 0, stream, ws.n_sel, pos);
+            launch_pairs();
+            hipLaunchKernelGGL(k_pass_update, dim3(rgrid), dim3(TPB), 0, stream, cr, opts, R, ws.ray_cnt, ws.ray_off,
+                               ws.smp_loc, ws.smp_sig_s, ws.n_sel, lo, hi, ws.ray_T, ws.ray_cm, ws.ray_alive);
+        }
+        P.i_v0 = 6;  // the colour MLP runs once over everything that was shaded
     }
+    hipLaunchKernelGGL(k_publish_shaded, dim3(1), dim3(64), 0, stream, ws.n_sel, P.i_v1, d_counters);
     if (ev_between) PNR_HIP_CHECK(hipEventRecord(ev_between, stream));
     const int64_t ctiles = (cap + 32 * WAVES - 1) / (32 * WAVES);
     const unsigned cgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cus, ctiles));

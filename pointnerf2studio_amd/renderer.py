@@ -220,7 +220,8 @@ class RendererHIP:
 
     def __init__(self, scene: SceneHIP, weights: WeightsHIP, SR: int = 80, K: int = 8, D: int = 400,
                  radius_limit: float = 0.016, vsize_z: float = 0.004, eval_clamp: bool = True,
-                 bg=(1.0, 1.0, 1.0), precision: str = "fp32", jitter: float = 0.0, seed: int = 0):
+                 bg=(1.0, 1.0, 1.0), precision: str = "fp32", jitter: float = 0.0, seed: int = 0,
+                 early_stop_eps: float = 0.0):
         self.lib = _lib.load()
         self.scene, self.weights = scene, weights
         self.opts = _lib.RenderOpts()
@@ -234,6 +235,8 @@ class RendererHIP:
         self.opts.precision = _lib.PRECISION[precision]
         self.opts.jitter = float(jitter)
         self.opts.seed = int(seed) & 0xFFFFFFFF
+        # 0: every sample with a neighbour is shaded (the reference's sample set); > 0: early ray termination
+        self.opts.early_stop_eps = float(early_stop_eps)
         self._ws = None
         self._ws_key = None
         self._tmid = {}

@@ -206,6 +206,36 @@ def test_render_edge_cases(oracle, gpu_device, precision):
         _check(ref, out)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_early_ray_termination_option(oracle, gpu_device, precision):
+    """opts.early_stop_eps > 0: rays stop being shaded once their transmittance is below eps.  The image stays within
+    the same 1e-4 of the oracle (which shades everything), fewer samples go through the MLPs on an opaque scene, every
+    sample that WAS shaded decodes to exactly the values of the full render, and eps = 0 is the full render."""
+    pts = small_scene(120000)
+    cfg = oracle_cfg(oracle)
+    w = synthetic.make_weights(0, sigma_scale=300.0, bias_scale=0.1)
+    campos, camrot, dirs = camera_rays(40, 40, az=35.0)
+    ref = oracle.render(pts, w, cfg, campos[None].expand(dirs.shape[0], 3), dirs, 2.0, 6.0, camrot)
+    scene, wh, hyp, info = build_hip(pts, cfg, gpu_device, weights=w)
+    d = dirs.to(gpu_device)
+    full = RendererHIP(scene, wh, precision=precision)
+    of = full.render(d, campos, camrot, 2.0, 6.0)
+    S = int(of["counters"]["samples_selected"])
+    dec_full = full.taps(d.shape[0])["smp_out"][:S].clone()
+    assert of["counters"]["samples_shaded"] == of["counters"]["samples_valid"]
+    es = RendererHIP(scene, wh, precision=precision, early_stop_eps=1e-5)
+    oe = es.render(d, campos, camrot, 2.0, 6.0)
+    _check(ref, oe)
+    assert (oe["rgb"] - of["rgb"]).abs().max().item() <= 2e-5
+    assert 0 < oe["counters"]["samples_shaded"] < 0.95 * oe["counters"]["samples_valid"]
+    dec_es = es.taps(d.shape[0])["smp_out"][:S]
+    shaded = dec_es.abs().sum(1) > 0
+    assert torch.equal(dec_es[shaded], dec_full[shaded])
+    # neighbour lists and counters upstream of the shading do not depend on the option
+    for k in ("rays_hit", "rays_kept", "samples_selected", "samples_valid", "pairs_valid"):
+        assert oe["counters"][k] == of["counters"][k]
+
+
 def test_render_full_size_properties(gpu_device):
     """Size-independent properties at a larger size than the oracle can check quickly (1M points, 400x400):
     determinism (bitwise equal re-render), tiling invariance (rendering the image in two halves gives the

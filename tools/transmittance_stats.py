@@ -37,3 +37,19 @@ T = torch.exp(before)
 for eps in (1e-3, 1e-4, 1e-5, 1e-6):
     print(f"samples with T_before < {eps:g}: {(T < eps).float().mean().item() * 100:.1f} %")
 print("samples", S, "mean sigma", sigma.mean().item(), "alpha>0.5 share", (alpha > 0.5).float().mean().item())
+
+# chunk schedules: a sample in chunk [b_k, b_k+1) is shaded iff its ray is still translucent at the START of the chunk
+idx = torch.arange(S, device=dev) - start              # index inside the ray
+valid = smp[:, 0].abs() + smp[:, 1:].abs().sum(1) > 0   # shaded samples with a neighbour (approx.)
+eps = 1e-5
+for sched in ([0, 3, 6, 12, 24], [0, 2, 4, 6, 8, 12, 16, 24], [0, 2, 4, 8, 16], [0, 4, 8, 16], [0, 1, 2, 3, 4, 6, 8, 12, 16, 24],
+              [0, 4], [0, 3], [0, 2, 5, 12]):
+    b = torch.tensor(sched + [10 ** 6], device=dev)
+    k = torch.bucketize(idx, b, right=True) - 1           # chunk of each sample
+    chunk_start = start + b[k]                            # first sample of that chunk
+    # transmittance before the chunk start = exp(cs[chunk_start - 1] - cs[start - 1])
+    prev = torch.where(chunk_start > start, cs[(chunk_start - 1).clamp(0, S - 1)], torch.where(start > 0, cs[(start - 1).clamp_min(0)], torch.zeros_like(cs)))
+    base = torch.where(start > 0, cs[(start - 1).clamp_min(0)], torch.zeros_like(cs))
+    T_chunk = torch.exp(prev - base)
+    shaded = (T_chunk >= eps)
+    print(f"schedule {sched}: {shaded.float().mean().item() * 100:.1f} % of the samples shaded, {len(sched)} passes")
