@@ -34,7 +34,7 @@ def test_struct_layouts_match_header(lib):
     from pointnerf2studio_amd import _lib
     assert C.sizeof(_lib.GridParams) == 6 * 4 + 3 * 4 + 3 * 4 + 3 * 4 + 3 * 4 + 3 * 4
     assert C.sizeof(_lib.CameraC) == (3 + 9 + 2) * 4
-    assert C.sizeof(_lib.RenderOpts) == 12 * 4
+    assert C.sizeof(_lib.RenderOpts) == 13 * 4
 
 
 def test_argument_validation_fails_loudly(lib):
