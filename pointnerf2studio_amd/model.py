@@ -93,6 +93,7 @@ class PointNerfConfig(ModelConfig):
 
     # additions of this build (not in the reference): arithmetic of the fused HIP MLP, see include/pnr.h
     hip_mlp_mode: str = "bf16x3"   # "bf16x3" (3 bf16 MFMA products per fp32 product) or "fp32" (exact)
+    hip_early_stop_eps: float = 0.0  # eval only: > 0 stops shading a ray once its transmittance is below eps
 
     def __post_init__(self):
         if self.path_point_cloud is not None:
@@ -193,7 +194,8 @@ class PointNerf(Model):
             self._renderer = RendererHIP(scene, self._weights, SR=c.SR, K=c.K, D=c.z_depth_dim,
                                          radius_limit=float(self.neural_points.radius_limit_np),
                                          vsize_z=c.vsize[2], eval_clamp=True, bg=self._background_color.tolist(),
-                                         precision=getattr(c, "hip_mlp_mode", "bf16x3"))
+                                         precision=getattr(c, "hip_mlp_mode", "bf16x3"),
+                                         early_stop_eps=float(getattr(c, "hip_early_stop_eps", 0.0)))
         return self._renderer
 
     def _get_outputs_fused(self, ray_bundle):
