@@ -2,7 +2,7 @@
 //
 // Replaces mask_raypos / host slotting / get_shadingloc / query_neigh_along_ray_layered / host
 // post-filter (query_worldcoords.cu:165-302,381-429).  What is different on MI355X:
-//   * one 64-lane wavefront walks one ray: the D coarse samples are probed 64 at a time against the
+//   * a 64-lane wavefront walks one ray at a time: the D coarse samples are probed 64 at a time against the
 //     L2-resident dilated-occupancy bitmask, `__ballot` + popcount give each hit its slot (the
 //     reference's cumsum over a [R,D] int tensor), and raypos[R,D,3] is never materialised: a sample
 //     position is campos + dir * t_mid[j], evaluated where needed (mul then add, unfused, as torch does);
@@ -67,7 +67,7 @@ RenderWs carve_render_ws(void *base, int64_t R, int64_t cap, int K, int64_t N, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_select: one wavefront per ray.  bits[r][w] = occupancy of coarse samples 64w..64w+63,
+// k_select: bits[r][w] = occupancy of coarse samples 64w..64w+63,
 // cnt[r] = min(SR, hits).  Either explicit positions (d_raypos, the drop-in op) or o + d * t.
 // ------------------------------------------------------------------------------------------------
 // Ray parameter of coarse sample j = 64w + lane.  jitter == 0: the host table.  jitter > 0: the reference's
@@ -99,7 +99,7 @@ __device__ __forceinline__ float sample_t(const CamRef &cr, const float *__restr
     return (e_left + e) / 2.0f;
 }
 
-__device__ __forceinline__ void sample_pos(const float *__restrict__ raypos, const float *__restrict__ dirs,
+__device__ __forceinline__ void sample_pos(const float *__restrict__ raypos, const float (&rd)[3],
                                            const Camera &cam, int64_t r, int D, int j, float t, float &px, float &py,
                                            float &pz)
 {
@@ -109,7 +109,7 @@ __device__ __forceinline__ void sample_pos(const float *__restrict__ raypos, con
         py = p[1];
         pz = p[2];
     } else {
-        float dx = dirs[3 * r], dy = dirs[3 * r + 1], dz = dirs[3 * r + 2];
+        float dx = rd[0], dy = rd[1], dz = rd[2];
         float mx = dx * t, my = dy * t, mz = dz * t;  // unfused: raydir * t, then campos + (.)
         px = cam.o[0] + mx;
         py = cam.o[1] + my;
@@ -117,6 +117,20 @@ __device__ __forceinline__ void sample_pos(const float *__restrict__ raypos, con
     }
 }
 
+// uniform broadcast of lane L's value (L wave-uniform)
+__device__ __forceinline__ float bcast_f(float v, int L)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), L));
+}
+__device__ __forceinline__ int bcast_i(int v, int L) { return __builtin_amdgcn_readlane(v, L); }
+
+// A wavefront owns RPW consecutive rays.  Phase 1, one ray per lane: camera, ray / grid-box clip, word range.  Phase 2:
+// the rays whose range is not empty are probed one after the other by the whole wavefront, 64 coarse samples per
+// step, the occupancy words of all steps of a ray in flight together.  (One wavefront per ray spent its time
+// launching 640 k wavefronts, four out of five of them for a ray that misses the box; 64 rays per wavefront made the
+// chain of dependent loads of its ~15 live rays the bottleneck instead.)
+constexpr int RPW = 16;
+constexpr int MAXW = PNR_MAX_D / 64;  // occupancy words per ray
 __global__ void __launch_bounds__(TPB) k_select(GridView g, CamRef cr, const float *__restrict__ dirs,
                                                  const float *__restrict__ raypos,
                                                  int64_t R, int D, int SR, int *__restrict__ ray_cnt,
@@ -124,86 +138,126 @@ __global__ void __launch_bounds__(TPB) k_select(GridView g, CamRef cr, const flo
                                                  unsigned long long *__restrict__ shards)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
-    if (r >= R) return;
-    int total = 0;
+    const int64_t r0 = ((int64_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6)) * RPW;
+    if (r0 >= R) return;
+    const int64_t rl = r0 + lane;
+    const bool live = lane < RPW && rl < R;
     const int nwords = (D + 63) >> 6;
-    Camera cam{};
-    const float *tmid = nullptr;
-    float near_plane = 0.f;
-    if (!raypos) {  // the ray's camera: wave-uniform
-        const int cid = cam_id(cr, r);
-        cam = load_cam(cr, cid);
-        tmid = cr.tmid + (size_t)cid * 2 * D;
-        near_plane = cr.nears[cid];
-    }
     const bool jittered = !raypos && cr.jitter != 0.0f;
-    // Conservative ray / grid-box clip (generated positions only): a coarse sample outside the voxel grid can
-    // never be occupied (cu:182-187), so whole 64-sample words whose parameter range misses the box -- grown by
-    // two voxels against rounding -- are skipped without probing.  Every probed sample still takes the exact test.
-    float t_in = -3.0e38f, t_out = 3.0e38f;
-    if (!raypos) {
-        const float d[3] = {dirs[3 * r], dirs[3 * r + 1], dirs[3 * r + 2]};
+    // ---- phase 1: this lane's ray ---------------------------------------------------------------------------
+    int cid = 0, w_lo = 1, w_hi = 0;
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (live) {
+        w_lo = 0;
+        w_hi = nwords - 1;
+        if (!raypos) {
+            cid = cam_id(cr, rl);
+            const Camera cam = load_cam(cr, cid);
+            const float *tmid = cr.tmid + (size_t)cid * 2 * D;
+            dx = dirs[3 * rl];
+            dy = dirs[3 * rl + 1];
+            dz = dirs[3 * rl + 2];
+            // Conservative ray / grid-box clip: a coarse sample outside the voxel grid can never be occupied
+            // (cu:182-187), so whole 64-sample words whose parameter range misses the box -- grown by two voxels
+            // against rounding -- are skipped without probing.  Every probed sample still takes the exact test.
+            float t_in = -3.0e38f, t_out = 3.0e38f;
+            const float d[3] = {dx, dy, dz};
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float lo = g.shift[a] - 2.0f * g.vox[a], hi = g.shift[a] + (float)(g.dims[a] + 2) * g.vox[a];
-            if (fabsf(d[a]) > 1e-12f) {
-                const float ta = (lo - cam.o[a]) / d[a], tb = (hi - cam.o[a]) / d[a];
-                t_in = fmaxf(t_in, fminf(ta, tb));
-                t_out = fminf(t_out, fmaxf(ta, tb));
-            } else if (cam.o[a] < lo || cam.o[a] > hi) {
-                t_out = -3.0e38f;  // parallel to the slab and outside it
+            for (int a = 0; a < 3; ++a) {
+                const float lo = g.shift[a] - 2.0f * g.vox[a], hi = g.shift[a] + (float)(g.dims[a] + 2) * g.vox[a];
+                if (fabsf(d[a]) > 1e-12f) {
+                    const float ta = (lo - cam.o[a]) / d[a], tb = (hi - cam.o[a]) / d[a];
+                    t_in = fmaxf(t_in, fminf(ta, tb));
+                    t_out = fminf(t_out, fmaxf(ta, tb));
+                } else if (cam.o[a] < lo || cam.o[a] > hi) {
+                    t_out = -3.0e38f;  // parallel to the slab and outside it
+                }
+            }
+            // word range that can intersect the box.  The table is monotonic and (at jitter 0) linear: the range
+            // comes from its end points with 3 samples of slack, then the first/last kept word is verified against
+            // the table.  Jittered parameters drift from the table: every word is probed.
+            if (!jittered && D > 1) {
+                const float t0 = tmid[0], t1 = tmid[D - 1];
+                const float inv_dt = (float)(D - 1) / (t1 - t0);
+                const float jl = (t_in - t0) * inv_dt - 3.0f, jh = (t_out - t0) * inv_dt + 3.0f;
+                if (!(jh >= 0.f) || !(jl <= (float)(D - 1))) {
+                    w_lo = 1;
+                    w_hi = 0;  // the ray misses the box: nothing to probe
+                } else {
+                    w_lo = (int)fmaxf(jl, 0.f) >> 6;
+                    w_hi = (int)fminf(jh, (float)(D - 1)) >> 6;
+                    while (w_lo > 0 && tmid[w_lo * 64 - 1] >= t_in) --w_lo;
+                    while (w_hi < nwords - 1 && tmid[(w_hi + 1) * 64] <= t_out) ++w_hi;
+                }
             }
         }
+        if (w_lo > w_hi) ray_cnt[rl] = 0;  // (ray_bits of such a ray are never read: k_expand skips it)
     }
-    // word range that can intersect the box.  The table is monotonic and (at jitter 0) linear: the range comes
-    // from its end points with 3 samples of slack, then the first/last kept word is verified against the table.
-    int w_lo = 0, w_hi = nwords - 1;
-    if (!raypos && !jittered && D > 1) {  // jittered parameters drift from the table: probe every word
-        const float t0 = tmid[0], t1 = tmid[D - 1];
-        const float inv_dt = (float)(D - 1) / (t1 - t0);
-        const float jl = (t_in - t0) * inv_dt - 3.0f, jh = (t_out - t0) * inv_dt + 3.0f;
-        if (!(jh >= 0.f) || !(jl <= (float)(D - 1))) {
-            w_lo = 1;
-            w_hi = 0;  // the ray misses the box: nothing to probe
-        } else {
-            w_lo = (int)fmaxf(jl, 0.f) >> 6;
-            w_hi = (int)fminf(jh, (float)(D - 1)) >> 6;
-            // guard against a non-linear (jittered) table: extend while the neighbouring word still overlaps
-            while (w_lo > 0 && tmid[w_lo * 64 - 1] >= t_in) --w_lo;
-            while (w_hi < nwords - 1 && tmid[(w_hi + 1) * 64] <= t_out) ++w_hi;
+    // ---- phase 2: the rays with something to probe, one at a time, 64 samples per step ----------------------------
+    unsigned long long todo = __ballot(live && w_lo <= w_hi);
+    while (todo) {
+        const int L = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int64_t r = r0 + L;
+        const int wl = bcast_i(w_lo, L), wh = bcast_i(w_hi, L);
+        Camera cam{};
+        const float *tmid = nullptr;
+        float near_plane = 0.f;
+        float rd[3] = {0.f, 0.f, 0.f};
+        if (!raypos) {
+            const int c = bcast_i(cid, L);
+            cam = load_cam(cr, c);
+            tmid = cr.tmid + (size_t)c * 2 * D;
+            near_plane = cr.nears[c];
+            rd[0] = bcast_f(dx, L);
+            rd[1] = bcast_f(dy, L);
+            rd[2] = bcast_f(dz, L);
         }
-    }
-    unsigned long long my_word = 0ull;  // lane w keeps word w
-    double carry = 0.0;
-    float e_prev = near_plane;
-    for (int w = w_lo; w <= w_hi; ++w) {
-        int j = w * 64 + lane;
-        bool hit = false;
-        const float t = raypos ? 0.f : sample_t(cr, tmid, near_plane, r, D, w, lane, carry, e_prev);
-        if (j < D) {
-            float px, py, pz;
-            sample_pos(raypos, dirs, cam, r, D, j, t, px, py, pz);
-            int cx, cy, cz;
-            if (cell_of(g, px, py, pz, cx, cy, cz)) {
-                int brick, bit;
-                brick_of(g, cx, cy, cz, brick, bit);
-                hit = (g.occ_dil[brick] >> bit) & 1ull;
+        int total = 0;
+        unsigned long long my_word = 0ull;  // lane w keeps word w
+        double carry = 0.0;
+        float e_prev = near_plane;
+        // all probes of the ray first (one occupancy word per step, loads in flight together), then the ballots
+        unsigned long long occ[MAXW];
+        int bitpos[MAXW];
+#pragma unroll
+        for (int k = 0; k < MAXW; ++k) {
+            occ[k] = 0ull;
+            bitpos[k] = 0;
+            const int w = wl + k;
+            if (w > wh) continue;  // wave-uniform
+            const int j = w * 64 + lane;
+            const float t = raypos ? 0.f : sample_t(cr, tmid, near_plane, r, D, w, lane, carry, e_prev);
+            if (j < D) {
+                float px, py, pz;
+                sample_pos(raypos, rd, cam, r, D, j, t, px, py, pz);
+                int cx, cy, cz;
+                if (cell_of(g, px, py, pz, cx, cy, cz)) {
+                    int brick;
+                    brick_of(g, cx, cy, cz, brick, bitpos[k]);
+                    occ[k] = g.occ_dil[brick];
+                }
             }
         }
-        unsigned long long m = __ballot(hit);
-        if (lane == w) my_word = m;
-        total += __popcll(m);
-    }
-    if (lane < 8) ray_bits[r * 8 + lane] = my_word;  // one 64-byte store per ray
-    if (lane == 0) {
-        ray_cnt[r] = min(total, SR);
-        if (total > 0) shard_add(shards, SH_RAYS_HIT, 1ull);
+#pragma unroll
+        for (int k = 0; k < MAXW; ++k) {
+            const int w = wl + k;
+            if (w > wh) continue;
+            const unsigned long long m = __ballot((occ[k] >> bitpos[k]) & 1ull);
+            if (lane == w) my_word = m;
+            total += __popcll(m);
+        }
+        if (lane < 8) ray_bits[r * 8 + lane] = my_word;  // one 64-byte store per ray
+        if (lane == 0) {
+            ray_cnt[r] = min(total, SR);
+            if (total > 0) shard_add(shards, SH_RAYS_HIT, 1ull);
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_expand: one wavefront per ray; hit j with rank < SR becomes sample off[r] + rank.
+// k_expand: a wavefront per RPW rays; the rays with samples are expanded one at a time by the whole wavefront:
+// hit j with rank < SR becomes sample off[r] + rank.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(TPB) k_expand(CamRef cr, const float *__restrict__ dirs,
                                                  const float *__restrict__ raypos,
@@ -213,44 +267,68 @@ __global__ void __launch_bounds__(TPB) k_expand(CamRef cr, const float *__restri
                                                  int *__restrict__ n_sel, int64_t *__restrict__ counters)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
-    if (r == 0 && lane == 0) {
+    const int64_t r0 = ((int64_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6)) * RPW;
+    if (r0 == 0 && lane == 0) {
         // total selected samples, clamped to the workspace capacity
         int total = ray_off[R];
         n_sel[0] = (int)min((int64_t)total, cap);
         counters[PNR_CNT_SAMPLES_SELECTED] = total;
         if (total > cap) counters[PNR_CNT_OVERFLOW] = 1;
     }
-    if (r >= R) return;
-    Camera cam{};
-    const float *tmid = nullptr;
-    float near_plane = 0.f;
-    if (!raypos) {
-        const int cid = cam_id(cr, r);
-        cam = load_cam(cr, cid);
-        tmid = cr.tmid + (size_t)cid * 2 * D;
-        near_plane = cr.nears[cid];
-    }
-    const int off = ray_off[r];
-    if (ray_off[r + 1] == off) return;  // no selected sample on this ray
-    int base = 0;
-    const int nwords = (D + 63) >> 6;
-    double carry = 0.0;
-    float e_prev = near_plane;
-    for (int w = 0; w < nwords && base < SR; ++w) {
-        unsigned long long m = ray_bits[r * 8 + w];
-        const float t = raypos ? 0.f : sample_t(cr, tmid, near_plane, r, D, w, lane, carry, e_prev);
-        if ((m >> lane) & 1ull) {
-            int rank = base + __popcll(m & ((1ull << lane) - 1ull));
-            int64_t s = (int64_t)off + rank;
-            if (rank < SR && s < cap) {
-                float px, py, pz;
-                sample_pos(raypos, dirs, cam, r, D, w * 64 + lane, t, px, py, pz);
-                smp_loc[s] = make_float4(px, py, pz, t);
-                smp_ray[s] = (int)r;
-            }
+    if (r0 >= R) return;
+    const int64_t rl = r0 + lane;
+    int my_off = 0, my_n = 0, cid = 0;
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (lane < RPW && rl < R) {
+        my_off = ray_off[rl];
+        my_n = ray_off[rl + 1] - my_off;
+        if (my_n > 0 && !raypos) {
+            cid = cam_id(cr, rl);
+            dx = dirs[3 * rl];
+            dy = dirs[3 * rl + 1];
+            dz = dirs[3 * rl + 2];
         }
-        base += __popcll(m);
+    }
+    unsigned long long todo = __ballot(my_n > 0);
+    const int nwords = (D + 63) >> 6;
+    while (todo) {
+        const int L = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int64_t r = r0 + L;
+        const int off = bcast_i(my_off, L);
+        Camera cam{};
+        const float *tmid = nullptr;
+        float near_plane = 0.f;
+        float rd[3] = {0.f, 0.f, 0.f};
+        if (!raypos) {
+            const int c = bcast_i(cid, L);
+            cam = load_cam(cr, c);
+            tmid = cr.tmid + (size_t)c * 2 * D;
+            near_plane = cr.nears[c];
+            rd[0] = bcast_f(dx, L);
+            rd[1] = bcast_f(dy, L);
+            rd[2] = bcast_f(dz, L);
+        }
+        int base = 0;
+        double carry = 0.0;
+        float e_prev = near_plane;
+        // the ray's eight occupancy words: one 64-byte load, word w broadcast from lane w
+        const unsigned long long mine = lane < 8 ? ray_bits[r * 8 + lane] : 0ull;
+        for (int w = 0; w < nwords && base < SR; ++w) {
+            const unsigned long long m = __shfl(mine, w, 64);
+            const float t = raypos ? 0.f : sample_t(cr, tmid, near_plane, r, D, w, lane, carry, e_prev);
+            if ((m >> lane) & 1ull) {
+                const int rank = base + __popcll(m & ((1ull << lane) - 1ull));
+                const int64_t s = (int64_t)off + rank;
+                if (rank < SR && s < cap) {
+                    float px, py, pz;
+                    sample_pos(raypos, rd, cam, r, D, w * 64 + lane, t, px, py, pz);
+                    smp_loc[s] = make_float4(px, py, pz, t);
+                    smp_ray[s] = (int)r;
+                }
+            }
+            base += __popcll(m);
+        }
     }
 }
 
@@ -566,11 +644,11 @@ int launch_select_expand(const GridView &g, const CamRef &cr, const float *d_dir
     PNR_HIP_CHECK(hipMemsetAsync(d_counters, 0, PNR_NUM_COUNTERS * sizeof(int64_t), stream));
     PNR_HIP_CHECK(hipMemsetAsync(ws.ray_flag, 0, (size_t)(R + 1) * sizeof(int), stream));
     unsigned long long *acc = acc_ptr(ws);
-    hipLaunchKernelGGL(k_select, dim3(nblk(R, TPB / 64)), dim3(TPB), 0, stream, g, cr, d_dirs, d_raypos, R, D, SR,
+    hipLaunchKernelGGL(k_select, dim3(nblk((R + RPW - 1) / RPW, TPB / 64)), dim3(TPB), 0, stream, g, cr, d_dirs, d_raypos, R, D, SR,
                        ws.ray_cnt, ws.ray_bits, acc);
     int rc = scan_exclusive_i32(ws.ray_cnt, ws.ray_off, R, nullptr, nullptr, ws.scan_temp, stream);
     if (rc != PNR_OK) return rc;
-    hipLaunchKernelGGL(k_expand, dim3(nblk(R, TPB / 64)), dim3(TPB), 0, stream, cr, d_dirs, d_raypos, R, D, SR,
+    hipLaunchKernelGGL(k_expand, dim3(nblk((R + RPW - 1) / RPW, TPB / 64)), dim3(TPB), 0, stream, cr, d_dirs, d_raypos, R, D, SR,
                        ws.ray_off, ws.ray_bits, cap, ws.smp_loc, ws.smp_ray, ws.n_sel, d_counters);
     PNR_HIP_CHECK(hipGetLastError());
     return PNR_OK;
