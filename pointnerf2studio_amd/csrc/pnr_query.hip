@@ -129,7 +129,10 @@ __device__ __forceinline__ int bcast_i(int v, int L) { return __builtin_amdgcn_r
 // step, the occupancy words of all steps of a ray in flight together.  (One wavefront per ray spent its time
 // launching 640 k wavefronts, four out of five of them for a ray that misses the box; 64 rays per wavefront made the
 // chain of dependent loads of its ~15 live rays the bottleneck instead.)
-constexpr int RPW = 16;
+#ifndef PNR_RPW
+#define PNR_RPW 16
+#endif
+constexpr int RPW = PNR_RPW;
 constexpr int MAXW = PNR_MAX_D / 64;  // occupancy words per ray
 __global__ void __launch_bounds__(TPB) k_select(GridView g, CamRef cr, const float *__restrict__ dirs,
                                                  const float *__restrict__ raypos,
