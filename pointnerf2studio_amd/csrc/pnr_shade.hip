@@ -11,7 +11,8 @@
 //     NO data movement: no LDS round trip for activations, no transposition; activations never leave
 //     the VGPR file.  The k-order this implies is baked into the packed weights (pnr_weights_pack).
 //   * One wavefront owns 32 rows (4 samples x K=8 neighbours) and all 256 features; one wave per SIMD,
-//     four waves per CU, persistent grid over contiguous tile ranges.
+//     four waves per CU, persistent grid of one workgroup per CU (fp32: a contiguous tile range per workgroup;
+//     bf16x3: XCD-aware interleaved tiles, see k_shade_pairs_bf16).
 //   * The gather reads one 192-byte packed row per neighbour; the two lanes that share a row (l, l+32)
 //     split its features, so no positional encoding is computed twice.
 //   * K-aggregation is a segmented butterfly over the 8 lanes of a sample, in registers.
@@ -21,8 +22,12 @@
 //   PNR_PRECISION_BF16X3 v_mfma_f32_32x32x16_bf16 on hi/lo splits: a*b ~ ah*bh + ah*bl + al*bh with fp32
 //                        accumulation (relative error ~2^-16 per product; RGB within 1e-5 of the fp32
 //                        path on the parity scenes).  3 MFMAs of 32 cycles replace 8 of 64: the weights
-//                        are consumed ~5x faster, so the four waves share them through LDS (double-
-//                        buffered 32..36 KiB tiles, one barrier per output tile).
+//                        are consumed ~5x faster, so the four waves share them through LDS (LDS-DMA into a
+//                        4-slot ring of 16..36 KiB tiles, one barrier per tile).  mlp_base layer 0 is
+//                        factorised: k_point_part contracts its 224 point-only inputs once per distinct
+//                        neighbour point of the call, the pair kernel starts from that row (pt_table) and
+//                        multiplies the 60 encoded distances; density head and K-aggregation run inside the
+//                        last layer's MFMA shadow.  DESIGN.md section 4.1 has the measurements.
 #include <algorithm>
 
 #include "pnr_internal.h"
@@ -34,7 +39,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// diagnostic builds only (never shipped): bit0 cheap PE, bit1 no MFMA, bit2 no staging, bit3 no barrier, bit4 no split
+// diagnostic builds only (never shipped; results are wrong by construction): bit0 cheap PE, bit1 no MFMA, bit3 no
+// barrier + no DMA, bit4 no split, bit5 no DMA issue, bit6 no barrier (tools/build_ablate.sh)
 #ifndef PNR_ABLATE
 #define PNR_ABLATE 0
 #endif
