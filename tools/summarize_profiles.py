@@ -41,16 +41,20 @@ json.dump({k: v for k, v in disp.items()}, open(os.path.join(dst, "dispatch_ms_b
 
 # PMC passes
 out = {"command": "rocprofv3 --pmc <COUNTER> --output-format csv -- python bench.py --steps 2 --warmup 1 --cpu-rays-side 0 "
-                  "(one pass per counter)",
+                  "--no-other-mode --precision <MODE> (one pass per counter and mode)",
        "units": "FETCH_SIZE / WRITE_SIZE are reported in KiB; bytes = value * 1024",
        "gfx950_correction": "FETCH_SIZE reads 1/2 of the bytes of a wide 16-B/lane read (MI355X_MICROARCH.md, HBM): "
                             "hbm_read_bytes = 2 * FETCH_SIZE * 1024 for the kernels below marked corrected",
        "kernels": {}}
 for counter, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
     acc = defaultdict(list)
-    for r in csv.DictReader(open(one(f"{d}/**/*counter_collection.csv"))):
-        if r["Counter_Name"] == counter and "pnr::" in r["Kernel_Name"]:
-            acc[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+    for mode in ("bf16x3", "fp32"):
+        for r in csv.DictReader(open(one(f"{d}_{mode}/**/*counter_collection.csv"))):
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            # each mode's run contributes its own MLP kernels; the mode-independent kernels come from the first run
+            mlp = "k_shade" in name or "k_point_part" in name
+            if r["Counter_Name"] == counter and "pnr::" in name and (mlp or mode == "bf16x3"):
+                acc[name].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         e = out["kernels"].setdefault(k, {})
         e[f"{counter}_KiB_avg_per_launch"] = sum(v) / len(v)
