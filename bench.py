@@ -40,7 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from pointnerf2studio_amd import _lib, synthetic  # noqa: E402
-from pointnerf2studio_amd.distributed import gather_views, make_shard  # noqa: E402
+from pointnerf2studio_amd.distributed import ViewGatherPipe, make_shard  # noqa: E402
 from pointnerf2studio_amd.renderer import (RendererHIP, SceneHIP, WeightsHIP, grid_hyperparameters)  # noqa: E402
 
 FLOPS_PER_PAIR = 542_720       # 2 * (284*256 + 256*256 + 263*256 + 256*256 + 256)   SURVEY.md section 8d
@@ -119,11 +119,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path is HIP-only (no CPU fallback)")
+    # PNR_BENCH_REHEARSE=1 (diagnostic): all ranks share cuda:0 and talk over gloo -- a rehearsal of the N > 1 code
+    # path on a one-GPU box (RCCL refuses two ranks on one device); the numbers it prints mean nothing
+    rehearse = os.environ.get("PNR_BENCH_REHEARSE") == "1" and world > 1
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     emulate = args.emulate_world > 1 and world == 1
     if emulate:   # per-rank work of an N-rank run, without the collectives (local copy instead of all_gather)
         world, rank = args.emulate_world, args.emulate_rank
@@ -174,9 +182,9 @@ def main():
         "ray_mask": torch.empty((n_local,), dtype=torch.int8, device=dev),
         "counters_dev": torch.zeros(_lib.NUM_COUNTERS, dtype=torch.int64, device=dev),
     }
-    local4 = torch.empty((n_local, 4), dtype=torch.float32, device=dev)
-    gathered = torch.empty((world, world, shard.n_pad, 4), dtype=torch.float32, device=dev)
-    images = torch.empty((world, H * W, 4), dtype=torch.float32, device=dev)
+    # the step's exchange: ONE all_gather of the rank's RGB+depth tiles of all views, issued asynchronously so that it
+    # overlaps the next step's render (images of step s are complete when step s + 1 is submitted / at drain())
+    pipe = ViewGatherPipe(shard, world, 4, torch.float32, dev, local_copy=emulate)
 
     # capacity: size the workspace once from the heaviest step (untimed)
     cap = 0
@@ -201,13 +209,12 @@ def main():
             if counters is not None:
                 outs["counters_dev"] = counters[call]
             renderer.render_views(dirs_s, cams_s, shard.n_pad, cap_samples=cap, sync_counters=False, out=outs)
+            local4 = pipe.stage()
             local4[:, :3].copy_(outs["rgb"])
             local4[:, 3].copy_(outs["depth"])
-            if emulate:
-                gathered[0].view(-1, 4).copy_(local4)
-            else:
-                gather_views(local4, shard, world, out=images, gathered=gathered)
+            pipe.submit()
             call += 1
+        pipe.drain()   # the last step's images: inside the timed region
         return call
 
     def timed(renderer, steps, first):

@@ -101,3 +101,54 @@ def gather_image(local: torch.Tensor, shard: TileShard, out: Optional[torch.Tens
     src = gathered if shard.slot_index.numel() == gathered.shape[0] else gathered.index_select(0, shard.slot_index)
     out.index_copy_(0, shard.pixel_index, src)
     return out
+
+
+class ViewGatherPipe:
+    """bench.py's exchange step, overlapped with the next step's render.
+
+    Per step a rank fills `stage()` ([n_views * n_pad, C], view-major, each view in shard.pixels order) and calls
+    `submit()`: the all_gather of that step starts on the backend's own stream (async_op) while the caller goes on
+    to render the next step; the images of the PREVIOUS step are assembled (one index_copy) at that point, the last
+    ones by `drain()`.  Two sets of buffers alternate, so a buffer is rewritten only after its collective has been
+    waited for.  `local_copy=True` (single rank, or the one-GPU emulation of an N-rank step) replaces the collective
+    by a copy of the rank's own slice."""
+
+    def __init__(self, shard: TileShard, n_views: int, C: int, dtype, device, local_copy: bool = False):
+        w, n = shard.world, shard.n_pad
+        self.shard, self.n_views, self.C = shard, n_views, C
+        self.use_dist = w > 1 and not local_copy
+        self.local = [torch.empty((n_views * n, C), dtype=dtype, device=device) for _ in range(2)]
+        self.gathered = [torch.empty((w, n_views, n, C), dtype=dtype, device=device) for _ in range(2)]
+        self.images = torch.empty((n_views, shard.H * shard.W, C), dtype=dtype, device=device)
+        self.work = [None, None]
+        self.step = 0
+        self.prev = None
+
+    def stage(self) -> torch.Tensor:
+        return self.local[self.step % 2]
+
+    def submit(self) -> None:
+        b = self.step % 2
+        if self.use_dist:
+            self.work[b] = dist.all_gather_into_tensor(self.gathered[b].view(-1, self.C), self.local[b], async_op=True)
+        else:
+            self.gathered[b][0].view(-1, self.C).copy_(self.local[b])
+        if self.prev is not None:
+            self._assemble(self.prev)
+        self.prev = b
+        self.step += 1
+
+    def drain(self) -> torch.Tensor:
+        if self.prev is not None:
+            self._assemble(self.prev)
+            self.prev = None
+        return self.images
+
+    def _assemble(self, b: int) -> None:
+        if self.work[b] is not None:
+            self.work[b].wait()   # NCCL/RCCL: the current stream waits for the collective; gloo: the host does
+            self.work[b] = None
+        sh, w, n = self.shard, self.shard.world, self.shard.n_pad
+        per_view = self.gathered[b].permute(1, 0, 2, 3).reshape(self.n_views, w * n, self.C)
+        src = per_view if sh.slot_index.numel() == w * n else per_view.index_select(1, sh.slot_index)
+        self.images.index_copy_(1, sh.pixel_index, src)

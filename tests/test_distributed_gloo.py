@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from pointnerf2studio_amd.distributed import gather_image, gather_views, make_shard
+from pointnerf2studio_amd.distributed import ViewGatherPipe, gather_image, gather_views, make_shard
 
 
 def _free_port():
@@ -38,6 +38,18 @@ def _worker(rank, world, port, H, W, q):
         local_v = torch.cat([_fake_render(shard.pixels) + 1000.0 * v for v in range(V)])
         imgs = gather_views(local_v, shard, V)
         ok = ok and all(torch.equal(imgs[v], expect + 1000.0 * v) for v in range(V))
+        # ... and the pipelined form bench.py uses (the collective of step s overlaps step s + 1): every step's
+        # images must equal the synchronous result, including the last ones returned by drain()
+        pipe = ViewGatherPipe(shard, V, 4, torch.float32, torch.device("cpu"))
+        seen = []
+        for step in range(4):
+            pipe.stage().copy_(local_v + 7.0 * step)
+            pipe.submit()
+            if step > 0:
+                seen.append(pipe.images.clone())      # images of step - 1 were assembled by this submit
+        seen.append(pipe.drain().clone())
+        ok = ok and len(seen) == 4 and all(
+            torch.equal(seen[st][v], expect + 1000.0 * v + 7.0 * st) for st in range(4) for v in range(V))
         # bench.py's timing reduction: max over ranks
         t = torch.tensor([1.0 + rank], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
