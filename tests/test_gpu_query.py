@@ -11,9 +11,11 @@ from pointnerf2studio_amd.renderer import query_raypos
 pytestmark = pytest.mark.gpu
 
 
-def _run_case(oracle, device, N, SR, K, P, compat, H=40, W=40, az=35.0, shrink=1.0, seed=1234):
+def _run_case(oracle, device, N, SR, K, P, compat, H=40, W=40, az=35.0, shrink=1.0, seed=1234, ks=3, D=400):
     pts = small_scene(N, seed=seed, shrink=shrink)
-    cfg = oracle_cfg(oracle, SR=SR, K=K, P=P)
+    cfg = oracle_cfg(oracle, SR=SR, K=K, P=P, D=D)
+    cfg.kernel_size = [ks] * 3
+    cfg.query_size = [ks] * 3
     campos, camrot, dirs = camera_rays(H, W, az=az)
     raypos, _ = oracle.ray_generation(campos[None], dirs[None], cfg.z_depth_dim, 2.0, 6.0)
     ranges, svsize, svdim = oracle.get_hyperparameters(cfg, pts["xyz"])
@@ -45,6 +47,19 @@ def _run_case(oracle, device, N, SR, K, P, compat, H=40, W=40, az=35.0, shrink=1
 def test_query_bit_exact(oracle, gpu_device, N, SR, K, P, compat):
     stats = _run_case(oracle, gpu_device, N, SR, K, P, compat)
     assert stats["rays_kept"] > 50 and stats["valid_pairs"] > 1000
+
+
+@pytest.mark.parametrize("N,SR,K,P,ks,D", [
+    (120000, 40, 8, 12, 5, 400),    # 5x5x5 search: three layers, the generic (cell by cell) search kernel
+    (120000, 40, 20, 12, 5, 400),   # ... with K = 20 (> 16: the widest register variant)
+    (60000, 80, 32, 26, 3, 400),    # K = 32 = PNR_MAX_K on the batched kernel's fallback
+    (60000, 80, 8, 12, 1, 400),     # 1x1x1 search: only the sample's own voxel
+    (90000, 16, 3, 5, 3, 130),      # D not a multiple of 64, K = 3
+    (90000, 5, 1, 1, 3, 64),        # one neighbour, one point per voxel, one occupancy word
+])
+def test_query_bit_exact_corner_shapes(oracle, gpu_device, N, SR, K, P, ks, D):
+    stats = _run_case(oracle, gpu_device, N, SR, K, P, True, H=24, W=24, ks=ks, D=D)
+    assert stats["rays_kept"] > 20 and stats["valid_pairs"] > 50
 
 
 def test_query_dense_shrunk_cloud(oracle, gpu_device):
