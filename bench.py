@@ -44,9 +44,9 @@ from pointnerf2studio_amd.distributed import ViewGatherPipe, make_shard  # noqa:
 from pointnerf2studio_amd.renderer import (RendererHIP, SceneHIP, WeightsHIP, grid_hyperparameters)  # noqa: E402
 
 FLOPS_PER_PAIR = 542_720       # 2 * (284*256 + 256*256 + 263*256 + 256*256 + 256)   SURVEY.md section 8d
-# bf16x3 mode: mlp_base layer 0 is factorised; k_shade_pairs_bf16 multiplies the 60 pair inputs only, the 224
-# point-only inputs are contracted once per distinct neighbour point by k_point_part
-FLOPS_PER_PAIR_BF16_KERNEL = 428_032   # 2 * (60*256 + 256*256 + 263*256 + 256*256 + 256)
+# mlp_base layer 0 is factorised (both modes): the pair kernels multiply the 60 pair inputs only, the 224
+# point-only inputs are contracted once per distinct neighbour point by k_point_part(_f32)
+FLOPS_PER_PAIR_BF16_KERNEL = 428_032   # 2 * (60*256 + 256*256 + 263*256 + 256*256 + 256): what the pair kernels do
 FLOPS_PER_POINT_PART = 114_688         # 2 * 224*256
 MFMA_FLOPS_PER_PAIR_BF16 = 1_302_528   # executed: 1272 x v_mfma_f32_32x32x16_bf16 (32768 FLOP) per 32 pairs
 FLOPS_PER_SAMPLE = 137_984     # 2 * (280*128 + 2*128*128 + 128*3)
@@ -249,7 +249,7 @@ def main():
         pairs, samples, upoints = cnt[4], cnt[3], cnt[7]
         t_pairs = acc_ms[2] / 1e3
         bf = mode == "bf16x3"
-        per_pair = FLOPS_PER_PAIR_BF16_KERNEL if bf else FLOPS_PER_PAIR
+        per_pair = FLOPS_PER_PAIR_BF16_KERNEL   # both modes run the factorised first layer
         achieved = pairs * per_pair / t_pairs / 1e12 if t_pairs > 0 else 0.0
         peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
         kernel = "k_shade_pairs_bf16" if bf else "k_shade_pairs"
@@ -259,8 +259,8 @@ def main():
             bytes_note = "pairs*8 + distinct points*1072 + samples*1064"
         else:
             executed = achieved
-            alg_bytes = pairs * 164 + samples * 1028
-            bytes_note = "pairs*164 + samples*1028"
+            alg_bytes = pairs * 8 + upoints * 1072 + samples * 1064
+            bytes_note = "pairs*8 + distinct points*1072 + samples*1064"
         r = {
             "bound": "mfma", "kernel": kernel, "mode": mode,
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
@@ -268,7 +268,8 @@ def main():
                           "factorised: its 224 point-only inputs are contracted once per distinct neighbour point by "
                           "k_point_part, stage point_part) / its launch time; the kernel executes 3 bf16 MFMA products "
                           "per algorithmic product on padded tiles: executed_mfma_frac prices those"
-                          if bf else "dense fp32 MFMA peak"),
+                          if bf else "dense fp32 MFMA peak; achieved = algorithmic fp32 FLOPs of THIS kernel (mlp_base layer 0 "
+                          "factorised as in the bf16x3 mode, point part in k_point_part_f32) / its launch time"),
             "executed_mfma_frac": executed / peak,
             "traffic": pmc_traffic_bytes(kernel),
             "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
@@ -278,7 +279,7 @@ def main():
             "valid_pairs_per_launch": pairs / n_launch,
             "flops_per_pair": per_pair,
         }
-        if bf:
+        if True:
             t_both = (acc_ms[2] + acc_ms[5]) / 1e3
             r["distinct_points_per_launch"] = upoints / n_launch
             r["point_part_ms"] = acc_ms[5] / n_launch

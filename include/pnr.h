@@ -109,7 +109,7 @@ enum {
     PNR_CNT_PAIRS_VALID = 4,    /* M   valid (sample, neighbour) pairs                       */
     PNR_CNT_CANDIDATES = 5,     /* candidates distance-tested                                */
     PNR_CNT_OVERFLOW = 6,       /* != 0: cap_samples was too small, output incomplete        */
-    PNR_CNT_POINTS_UNIQUE = 7,  /* U   distinct neighbour points (bf16x3 mode; 0 in fp32 mode)      */
+    PNR_CNT_POINTS_UNIQUE = 7,  /* U   distinct neighbour points of the call                          */
     PNR_CNT_SAMPLES_SHADED = 8, /* samples that went through the MLPs (= SAMPLES_VALID unless early_stop_eps > 0) */
     PNR_CNT_RESERVED = 9,
     PNR_NUM_COUNTERS = 10
@@ -158,10 +158,11 @@ int pnr_query_raypos(const pnr_scene_t *scene, const float *d_raypos, int64_t R,
                      void *stream);
 
 /* ---- fused render: NeuralPoints.forward + PointNerf.get_outputs for one ray bundle -------------- */
-/* Workspace of a PNR_PRECISION_FP32 render (scene independent), and of a render with the given options on the
- * given (built) scene: PNR_PRECISION_BF16X3 adds the per-call table of the factorised first layer, one 1-KiB row
- * per distinct neighbour point (at most min(points in voxel lists, cap_samples * K) rows), and two int32 per
- * scene point.  pnr_render_workspace_bytes_for returns 0 (and sets the error string) on invalid arguments. */
+/* pnr_render_workspace_bytes: the scene-independent part of the render workspace (what pnr_render_taps addresses).
+ * pnr_render_workspace_bytes_for: the workspace pnr_render / pnr_render_views need on the given (built) scene: the
+ * part above plus the per-call table of the factorised first layer -- one 1-KiB row per distinct neighbour point (at
+ * most min(points in voxel lists, cap_samples * K) rows) -- and two int32 per scene point.  Returns 0 (and sets
+ * the error string) on invalid arguments. */
 size_t pnr_render_workspace_bytes(int64_t R, int64_t cap_samples, int32_t K);
 size_t pnr_render_workspace_bytes_for(const pnr_scene_t *scene, const pnr_render_opts_t *opts, int64_t R,
                                       int64_t cap_samples);
@@ -216,8 +217,8 @@ enum {
     PNR_STAGE_SHADE_PAIRS = 2, /* gather + mlp_base + mlp_head + density + K-aggregation   */
     PNR_STAGE_SHADE_COLOR = 3, /* colour MLP                                               */
     PNR_STAGE_COMPOSITE = 4,   /* ray_dist + alpha composite + background fill             */
-    PNR_STAGE_POINT_PART = 5,  /* bf16x3: first-layer partial products of the distinct neighbour points (runs
-                                  between KNN and SHADE_PAIRS; 0 in fp32 mode)                */
+    PNR_STAGE_POINT_PART = 5,  /* first-layer partial products of the distinct neighbour points (runs between
+                                  KNN and SHADE_PAIRS)                                        */
     PNR_NUM_STAGES = 6
 };
 int pnr_profile_enable(int enable);

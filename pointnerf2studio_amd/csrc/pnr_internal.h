@@ -183,6 +183,7 @@ struct pnr_weights {
     size_t w16a_off = 0;      // mlp_base layer 0, point-only inputs [0:224]: 8 tiles x 14 k-steps
     size_t w16b_off = 0;
     size_t w8acc_off = 0;     // colour head weights in accumulator order (384 floats)
+    size_t w32a_off = 0, w32b_off = 0;  // fp32-packed halves of mlp_base layer 0
     size_t w4acc_off = 0;     // density head weights in accumulator order (256 floats)      // mlp_base layer 0, pair inputs [224:284]: 4 ring tiles x (2 row blocks x 4 k-steps)
     size_t b_off[9] = {0};
     float Rw2c[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};

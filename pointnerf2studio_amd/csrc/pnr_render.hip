@@ -159,7 +159,6 @@ extern "C" size_t pnr_render_workspace_bytes_for(const pnr_scene_t *scene, const
     }
     if (R < 1) R = 1;
     if (cap_samples < 1) cap_samples = 1;
-    if (opts->precision != PNR_PRECISION_BF16X3) return carve_render_ws(nullptr, R, cap_samples, opts->K).total;
     return carve_render_ws(nullptr, R, cap_samples, opts->K, scene->N, scene->info[2]).total_pt;
 }
 
@@ -201,9 +200,8 @@ static int render_views(const pnr_scene_t *scene, const pnr_weights_t *weights, 
                   need);
         return PNR_ERR_WORKSPACE;
     }
-    const bool factored = opts->precision == PNR_PRECISION_BF16X3;
-    RenderWs ws = factored ? carve_render_ws(d_workspace, R, cap_samples, opts->K, scene->N, scene->info[2])
-                           : carve_render_ws(d_workspace, R, cap_samples, opts->K);
+    const bool factored = true;  // both arithmetic modes start mlp_base layer 0 from the per-point table
+    RenderWs ws = carve_render_ws(d_workspace, R, cap_samples, opts->K, scene->N, scene->info[2]);
     CamSet set{};
     for (int c = 0; c < n_cams; ++c) {
         for (int i = 0; i < 3; ++i) set.c[c].o[i] = cams[c].campos[i];

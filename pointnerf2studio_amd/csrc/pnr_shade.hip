@@ -103,6 +103,7 @@ struct ShadeParams {
     int i_v0, i_v1;        // the kernel works on positions [n_sel[i_v0], n_sel[i_v1]) of vs_list
     float *smp_sig_s;      // [S_sel] density by sample index (early ray termination), may be null
     size_t w16a_off, w16b_off, w4acc_off, w8acc_off;
+    size_t w32a_off, w32b_off;   // fp32-packed halves of mlp_base layer 0 (point-only k-steps 0..111, pair 112..143)
     const int *pt_rank;     // [N+1] point index -> row of pt_table
     const int *pt_list;     // [U] rows -> point index
     float4 *pt_table;       // [u_cap, 8 row blocks, 2 lane halves, 4] float4
@@ -645,9 +646,12 @@ __device__ __forceinline__ void color_head_lds(const ShadeParams &P, const u32x4
 // float4) start at byte offset wbase of the weight buffer: buffer loads with the wave-uniform offset in an
 // SGPR, so the ~1000 loads of an unrolled layer share ONE address VGPR (with 64-bit global addresses hipcc
 // hoists a distinct address pair per load out of the tile loop and spills ~2000 VGPRs).
+// `init` (per lane: float4 index 8m + q = accumulator values 4q..4q+3 of output tile m, the pt_table row of the
+// lane's pair) replaces the bias when the layer continues a sum started elsewhere.
 template <int KSP, int MT>
 __device__ __forceinline__ void dense_layer(__amdgpu_buffer_rsrc_t rsrc, int wbase, const float *__restrict__ bias,
-                                            int lane, const float (&in)[KSP], float (&out)[MT * 16])
+                                            int lane, const float (&in)[KSP], float (&out)[MT * 16],
+                                            const float4 *__restrict__ init = nullptr)
 {
     static_assert(KSP % 4 == 0, "k-steps are packed in groups of 4");
     constexpr int KG = KSP / 4;
@@ -659,7 +663,7 @@ __device__ __forceinline__ void dense_layer(__amdgpu_buffer_rsrc_t rsrc, int wba
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 b = *reinterpret_cast<const float4 *>(bias + 32 * m + 8 * q + 4 * h);
+            const float4 b = init ? init[8 * m + q] : *reinterpret_cast<const float4 *>(bias + 32 * m + 8 * q + 4 * h);
             acc[m][4 * q + 0] = b.x;
             acc[m][4 * q + 1] = b.y;
             acc[m][4 * q + 2] = b.z;
@@ -702,7 +706,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
 
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wbuf), 0, (int)P.wbytes, 0x00020000);
-    const int w0_ = (int)(P.w_off[0] * 4), w1_ = (int)(P.w_off[1] * 4), w2_ = (int)(P.w_off[2] * 4),
+    const int w0_ = (int)(P.w32b_off * 4), w1_ = (int)(P.w_off[1] * 4), w2_ = (int)(P.w_off[2] * 4),
               w3_ = (int)(P.w_off[3] * 4);
     const float *b0 = P.wbuf + P.b_off[0], *b1 = P.wbuf + P.b_off[1], *b2 = P.wbuf + P.b_off[2],
                 *b3 = P.wbuf + P.b_off[3];
@@ -712,12 +716,23 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
         // spilled to VGPR lanes
         int w0 = w0_, w1 = w1_, w2 = w2_, w3 = w3_;
         asm volatile("" : "+s"(w0), "+s"(w1), "+s"(w2), "+s"(w3));
-        float x0[144];
+        // mlp_base layer 0 is factorised as in the bf16x3 mode: the 224 point-only inputs were contracted once per
+        // distinct neighbour point by k_point_part_f32 (pt_table row, accumulator order); here the row starts the
+        // accumulators and only the 60 encoded distances (k-steps 112..143 of the lane's inputs) are multiplied
+        float xq[32];
         RowCtx ctx;
-        load_rows<K8, false>(P, tile, lane, wave, V0, S_valid, x0, ctx);
-
+        const float4 *trow;
+        {
+            RowFetch f;
+            fetch_a<K8>(P, tile, lane, wave, V0, S_valid, f);
+            fetch_b<K8>(P, f);
+            fetch_c_pair(P, f);
+            trow = P.pt_table + (int64_t)f.urow * 64 + 4 * (lane >> 5);
+            const Camera cam = load_cam_lanes(P.cr, f.cid);
+            pair_inputs<K8, false>(P, f, cam, lane, xq, ctx);
+        }
         float hA[128];
-        dense_layer<144, 8>(rsrc, w0, b0, lane, x0, hA);
+        dense_layer<32, 8>(rsrc, w0, b0, lane, xq, hA, trow);
 #pragma unroll
         for (int i = 0; i < 128; ++i) hA[i] = leaky(hA[i]);
         float hB[132];
@@ -1166,6 +1181,42 @@ __device__ __forceinline__ void ring_start(__amdgpu_buffer_rsrc_t rsrc, int w_fi
         BiasRegs breg;
         bias_issue(bias0, breg);
         ring.acc0 = bias_finish(breg, lane >> 5);
+    }
+}
+
+// fp32 mode of k_point_part below: the same table with v_mfma_f32_32x32x2_f32 (exact fp32), exact sincosf encodings
+__global__ void __launch_bounds__(TPB, 1) k_point_part_f32(ShadeParams P)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int U = min(P.n_sel[3], P.u_cap);
+    constexpr int PPT = 32 * WAVES;
+    const int ntiles = (U + PPT - 1) / PPT;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wbuf), 0, (int)P.wbytes, 0x00020000);
+    const int wa_ = (int)(P.w32a_off * 4);
+    const float *b0 = P.wbuf + P.b_off[0];
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int wa = wa_;
+        asm volatile("" : "+s"(wa));
+        const int u = tile * PPT + wave * 32 + j;
+        const int pidx = P.pt_list[u < U ? u : 0];
+        const float4 *row = P.point_rows + (int64_t)pidx * 12 + 4 + 4 * h;
+        const float4 e0 = row[0], e1 = row[1], e2 = row[2], e3 = row[3];
+        const float e[16] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w,
+                             e2.x, e2.y, e2.z, e2.w, e3.x, e3.y, e3.z, e3.w};
+        float x0[112];
+        point_inputs<false>(e, x0);
+        float o[128];
+        dense_layer<112, 8>(rsrc, wa, b0, lane, x0, o);
+        float4 *dst = P.pt_table + (int64_t)u * 64 + 4 * h;   // rows beyond U: the table's padding rows
+#pragma unroll
+        for (int B = 0; B < 8; ++B)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                dst[8 * B + q] = make_float4(o[16 * B + 4 * q], o[16 * B + 4 * q + 1], o[16 * B + 4 * q + 2],
+                                             o[16 * B + 4 * q + 3]);
     }
 }
 
@@ -1625,17 +1676,17 @@ __device__ int feat16_of(int kind, int s, int h, int j, int n_in)
     return -1;
 }
 
-__global__ void k_pack_layer(const float *__restrict__ W, int n_out, int n_in, int kind, int ksp,
+__global__ void k_pack_layer(const float *__restrict__ W, int n_out, int n_in, int kind, int ksp, int t0,
                              float *__restrict__ dst)
 {
-    // dst[((m*KG + g)*64 + lane)*4 + q] = W[32m + (lane&31)][feat(4g+q, lane>>5)]
+    // dst[((m*KG + g)*64 + lane)*4 + q] = W[32m + (lane&31)][feat(t0 + 4g+q, lane>>5)]
     const int kg = ksp / 4, mt = n_out / 32;
     const int64_t total = (int64_t)mt * kg * 64 * 4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int q = (int)(i & 3), lane = (int)((i >> 2) & 63);
         const int64_t mg = i >> 8;
         const int g = (int)(mg % kg), m = (int)(mg / kg);
-        const int f = feat_of(kind, 4 * g + q, lane >> 5, n_in);
+        const int f = feat_of(kind, t0 + 4 * g + q, lane >> 5, n_in);
         dst[i] = (f >= 0 && f < n_in) ? W[(int64_t)(32 * m + (lane & 31)) * n_in + f] : 0.f;
     }
 }
@@ -1834,6 +1885,8 @@ int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr,
     P.w16b_off = w->w16b_off;
     P.w4acc_off = w->w4acc_off;
     P.w8acc_off = w->w8acc_off;
+    P.w32a_off = w->w32a_off;
+    P.w32b_off = w->w32b_off;
     P.pt_rank = ws.pt_rank;
     P.pt_list = ws.pt_list;
     P.pt_table = reinterpret_cast<float4 *>(ws.pt_table);
@@ -1847,14 +1900,17 @@ int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr,
     const int64_t max_tiles = (cap + spt - 1) / spt;
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cus, max_tiles));
     const bool bf = precision == PNR_PRECISION_BF16X3;
-    if (bf) {
+    {
         if (!ws.pt_table) {
-            set_error("launch_shade: bf16x3 mode needs the point-part workspace");
+            set_error("launch_shade: the workspace lacks the point-part buffers (pnr_render_workspace_bytes_for)");
             return PNR_ERR_WORKSPACE;
         }
         const int64_t ptiles = (ws.u_cap + 32 * WAVES - 1) / (32 * WAVES);
-        hipLaunchKernelGGL(k_point_part, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(cus, ptiles))), dim3(TPB),
-                           0, stream, P);
+        const dim3 pgrid((unsigned)std::max<int64_t>(1, std::min<int64_t>(cus, ptiles)));
+        if (bf)
+            hipLaunchKernelGGL(k_point_part, pgrid, dim3(TPB), 0, stream, P);
+        else
+            hipLaunchKernelGGL(k_point_part_f32, pgrid, dim3(TPB), 0, stream, P);
     }
     if (ev_points) PNR_HIP_CHECK(hipEventRecord(ev_points, stream));
     auto launch_pairs = [&]() {
@@ -1957,6 +2013,10 @@ extern "C" int pnr_weights_pack(pnr_weights_t *w, const float *const d_w[9], con
     off += pad((size_t)8 * 14 * 512);
     w->w16b_off = off;
     off += pad((size_t)4 * 8 * 512);
+    w->w32a_off = off;
+    off += pad((size_t)8 * (112 / 4) * 256);
+    w->w32b_off = off;
+    off += pad((size_t)8 * (32 / 4) * 256);
     w->w4acc_off = off;
     off += pad(256);
     w->w8acc_off = off;
@@ -1976,7 +2036,7 @@ extern "C" int pnr_weights_pack(pnr_weights_t *w, const float *const d_w[9], con
     for (int i = 0; i < 9; ++i) {
         if (ksp[i]) {
             hipLaunchKernelGGL(k_pack_layer, dim3(256), dim3(256), 0, stream, d_w[i], n_out[i], n_in[i], kind[i],
-                               ksp[i], w->buf + w->w_off[i]);
+                               ksp[i], 0, w->buf + w->w_off[i]);
             hipLaunchKernelGGL(k_pack_layer_bf16, dim3(256), dim3(256), 0, stream, d_w[i], n_out[i], n_in[i], kind[i],
                                ks16[i], ks16[i], 0, reinterpret_cast<unsigned short *>(w->buf + w->w16_off[i]));
         } else {
@@ -1988,6 +2048,10 @@ extern "C" int pnr_weights_pack(pnr_weights_t *w, const float *const d_w[9], con
     }
     hipLaunchKernelGGL(k_pack_layer_bf16, dim3(256), dim3(256), 0, stream, d_w[0], 256, 284, (int)L_BASE0, 14, 14, 0,
                        reinterpret_cast<unsigned short *>(w->buf + w->w16a_off));
+    hipLaunchKernelGGL(k_pack_layer, dim3(256), dim3(256), 0, stream, d_w[0], 256, 284, (int)L_BASE0, 112, 0,
+                       w->buf + w->w32a_off);
+    hipLaunchKernelGGL(k_pack_layer, dim3(256), dim3(256), 0, stream, d_w[0], 256, 284, (int)L_BASE0, 32, 112,
+                       w->buf + w->w32b_off);
     hipLaunchKernelGGL(k_pack_head_acc, dim3(1), dim3(256), 0, stream, d_w[4], w->buf + w->w4acc_off);
     hipLaunchKernelGGL(k_pack_color_head_acc, dim3(2), dim3(256), 0, stream, d_w[8], w->buf + w->w8acc_off);
     hipLaunchKernelGGL(k_pack_layer_bf16, dim3(256), dim3(256), 0, stream, d_w[0], 256, 284, (int)L_BASE0, 8, 4, 14,

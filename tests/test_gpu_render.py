@@ -151,9 +151,9 @@ def test_render_capacity_overflow_regrows(oracle, gpu_device):
 
 
 def test_factorised_first_layer_bookkeeping(oracle, gpu_device):
-    """bf16x3 mode contracts the point-only inputs of mlp_base layer 0 once per DISTINCT neighbour point of the call:
+    """Both modes contract the point-only inputs of mlp_base layer 0 once per DISTINCT neighbour point of the call:
     the published count equals the number of distinct indices in the neighbour lists (integer work: exact), the
-    exact fp32 mode does not use the table (count 0, scene-independent workspace size), and both modes agree."""
+    workspace holds the per-point table on top of the scene-independent part, and the two modes agree."""
     import ctypes as C
     pts = small_scene(60000)
     cfg = oracle_cfg(oracle)
@@ -169,13 +169,10 @@ def test_factorised_first_layer_bookkeeping(oracle, gpu_device):
         S = int(o["counters"]["samples_selected"])
         pidx = t["smp_pidx"][:S]
         distinct = int(torch.unique(pidx[pidx >= 0]).numel())
-        if precision == "bf16x3":
-            assert o["counters"]["points_unique"] == distinct > 0
-        else:
-            assert o["counters"]["points_unique"] == 0
+        assert o["counters"]["points_unique"] == distinct > 0
         n_for = rnd.lib.pnr_render_workspace_bytes_for(scene.handle, C.byref(rnd.opts), d.shape[0], rnd.cap_samples)
         n_base = rnd.lib.pnr_render_workspace_bytes(d.shape[0], rnd.cap_samples, rnd.opts.K)
-        assert (n_for > n_base) if precision == "bf16x3" else (n_for == n_base)
+        assert n_for > n_base
         outs[precision] = (o["rgb"].clone(), o["depth"].clone(), o["ray_mask"].clone())
     assert torch.equal(outs["bf16x3"][2], outs["fp32"][2])
     assert (outs["bf16x3"][0] - outs["fp32"][0]).abs().max().item() <= 2e-5
