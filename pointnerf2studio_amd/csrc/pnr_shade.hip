@@ -17,17 +17,17 @@
 //     split its features, so no positional encoding is computed twice.
 //   * K-aggregation is a segmented butterfly over the 8 lanes of a sample, in registers.
 // Two arithmetic modes (pnr_render_opts_t.precision):
-//   PNR_PRECISION_FP32   v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 fma chain.  Weights stream
-//                        L2 -> VGPR through a buffer descriptor (one 1-KiB load per 4 MFMAs).
+//   PNR_PRECISION_FP32   v_mfma_f32_32x32x2_f32: every product and sum in fp32 (an fp32 fma chain per output).
+//                        Weights stream L2 -> VGPR through a buffer descriptor (one 1-KiB load per 4 MFMAs).
 //   PNR_PRECISION_BF16X3 v_mfma_f32_32x32x16_bf16 on hi/lo splits: a*b ~ ah*bh + ah*bl + al*bh with fp32
 //                        accumulation (relative error ~2^-16 per product; RGB within 1e-5 of the fp32
 //                        path on the parity scenes).  3 MFMAs of 32 cycles replace 8 of 64: the weights
 //                        are consumed ~5x faster, so the four waves share them through LDS (LDS-DMA into a
-//                        4-slot ring of 16..36 KiB tiles, one barrier per tile).  mlp_base layer 0 is
-//                        factorised: k_point_part contracts its 224 point-only inputs once per distinct
-//                        neighbour point of the call, the pair kernel starts from that row (pt_table) and
-//                        multiplies the 60 encoded distances; density head and K-aggregation run inside the
-//                        last layer's MFMA shadow.  DESIGN.md section 4.1 has the measurements.
+//                        4-slot ring of 16..36 KiB tiles, one barrier per tile); density head and
+//                        K-aggregation run inside the last layer's MFMA shadow.
+// In both modes mlp_base layer 0 is factorised: k_point_part(_f32) contracts its 224 point-only inputs once per
+// distinct neighbour point of the call, the pair kernel starts from that row (pt_table) and multiplies the 60 encoded
+// distances.  DESIGN.md section 4.1 has the measurements.
 #include <algorithm>
 
 #include "pnr_internal.h"
