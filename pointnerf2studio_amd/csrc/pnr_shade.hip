@@ -199,16 +199,17 @@ struct RowCtx {
     float ex[4];  // this lane half's share of [color(3), dir - view (3), <dir, view>, 0]
 };
 
-// x0: the lane's 144 layer-1 input values; value i = 8s + j is element j of k-step s in the bf16 path and
-// k-step t = i in the fp32 path.  Lane half h = 0 carries emb[0:16], their encodings and the rotated world
-// distances, h = 1 carries emb[16:32], their encodings and the camera-space distances.
+// The lane's 144 layer-1 input values: value i = 8s + j is element j of k-step s in the bf16 path and k-step t = i in
+// the fp32 path.  Lane half h = 0 carries emb[0:16], their encodings (values 0..111: point_inputs, computed once per
+// distinct point by k_point_part) and the rotated world distances (values 112..143: pair_inputs), h = 1 carries
+// emb[16:32], their encodings and the camera-space distances.
 // Gathered inputs of one lane's (sample, neighbour) row.  The three dependent load levels are separate functions
 // so that the bf16x3 kernel can issue them for the NEXT tile between the layers of the current one (one wave per
 // SIMD cannot hide a vs_list -> smp_pidx -> point-row chain of three HBM/L2 latencies any other way).
 struct RowFetch {
     int v_idx, slot, s, pidx, ray, urow, cid;
     bool row_ok;
-    float4 a0, e0, e1, e2, e3, c0, c1, loc;
+    float4 a0, c0, c1, loc;
     float dirx, diry, dirz;
 };
 
@@ -239,22 +240,6 @@ __device__ __forceinline__ void fetch_b(const ShadeParams &P, RowFetch &f)
     f.pidx = f.row_ok ? pv : -1;
     f.loc = P.smp_loc[f.s];
     f.ray = P.smp_ray[f.s];
-}
-
-__device__ __forceinline__ void fetch_c(const ShadeParams &P, int lane, RowFetch &f)
-{
-    const int h = lane >> 5;
-    const float4 *row = P.point_rows + (int64_t)max(f.pidx, 0) * 12;
-    f.a0 = row[0];
-    f.c0 = row[1];
-    f.c1 = row[2];
-    f.e0 = row[4 + 4 * h];
-    f.e1 = row[5 + 4 * h];
-    f.e2 = row[6 + 4 * h];
-    f.e3 = row[7 + 4 * h];
-    f.dirx = P.dirs[3 * (int64_t)f.ray];
-    f.diry = P.dirs[3 * (int64_t)f.ray + 1];
-    f.dirz = P.dirs[3 * (int64_t)f.ray + 2];
 }
 
 // Camera of a wavefront whose rays all belong to camera cid0, through the scalar cache.  (hipcc emits VECTOR loads
@@ -308,7 +293,7 @@ __device__ __forceinline__ int cam_id_flat(const CamRef &cr, const int *valid_in
     return cr.n_cams <= 1 ? 0 : cid;
 }
 
-// bf16x3 mode: the embedding is not needed per pair (its first-layer contribution comes from pt_table)
+// the embedding is not needed per pair (its first-layer contribution comes from pt_table)
 __device__ __forceinline__ void fetch_c_pair(const ShadeParams &P, RowFetch &f)
 {
     const int p = max(f.pidx, 0);
@@ -421,28 +406,6 @@ __device__ __forceinline__ void pair_inputs(const ShadeParams &P, const RowFetch
     ctx.ex[1] = h ? dv0 : c0.z;
     ctx.ex[2] = h ? dv2 : dv1;
     ctx.ex[3] = h ? 0.f : dot;
-}
-
-template <bool K8, bool FAST_PE>
-__device__ __forceinline__ void compute_rows(const ShadeParams &P, const RowFetch &f, int lane, float (&x0)[144],
-                                             RowCtx &ctx)
-{
-    const float e[16] = {f.e0.x, f.e0.y, f.e0.z, f.e0.w, f.e1.x, f.e1.y, f.e1.z, f.e1.w,
-                         f.e2.x, f.e2.y, f.e2.z, f.e2.w, f.e3.x, f.e3.y, f.e3.z, f.e3.w};
-    point_inputs<FAST_PE>(e, x0);
-    const Camera cam = load_cam_lanes(P.cr, cam_id(P.cr, f.ray));
-    pair_inputs<K8, FAST_PE>(P, f, cam, lane, x0 + 112, ctx);
-}
-
-template <bool K8, bool FAST_PE>
-__device__ __forceinline__ void load_rows(const ShadeParams &P, int tile, int lane, int wave, int V0, int S_valid,
-                                          float (&x0)[144], RowCtx &ctx)
-{
-    RowFetch f;
-    fetch_a<K8>(P, tile, lane, wave, V0, S_valid, f);
-    fetch_b<K8>(P, f);
-    fetch_c(P, lane, f);
-    compute_rows<K8, FAST_PE>(P, f, lane, x0, ctx);
 }
 
 // Bias-initialised accumulator of an output tile.  The tile's 32 biases are wave-uniform: they are fetched through
