@@ -1529,28 +1529,27 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_color_bf16(ShadeParams P)
         {
             float vx, vy, vz;
             rot_rows(P.Rw2c, dir[0], dir[1], dir[2], vx, vy, vz);
-            const float vv[3] = {vx, vy, vz};
-            float p[24];  // [sin(d*4+f) (12) | cos (12)]
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                float sn, cs;
-                fast_sincos(vv[d], sn, cs);
-#pragma unroll
-                for (int f = 0; f < 4; ++f) {
-                    if (f > 0) {
-                        const float s2 = 2.0f * sn * cs, c2 = (cs - sn) * (cs + sn);
-                        sn = s2;
-                        cs = c2;
-                    }
-                    p[d * 4 + f] = sn;
-                    p[12 + d * 4 + f] = cs;
-                }
-            }
+            // encoded view direction, input order [sin(d*4+f) (12) | cos (12)]: k-step 16 = values 0..7 (h = 0) /
+            // 8..15 (h = 1), k-step 17 = values 16..23 (h = 0) / zero.  Selected value by value between scalars: a
+            // select between two elements of one array becomes an indexed read of the array through SCRATCH, whose
+            // s_waitcnt vmcnt(0) also drains the weight DMA in flight
+            float sn0, cs0, sn1, cs1, sn2, cs2;
+            fast_sincos(vx, sn0, cs0);
+            fast_sincos(vy, sn1, cs1);
+            fast_sincos(vz, sn2, cs2);
             float v16[8], v17[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                v16[q] = h ? p[8 + q] : p[q];
-                v17[q] = h ? 0.f : p[16 + q];
+            for (int f = 0; f < 4; ++f) {
+                if (f > 0) {
+                    const float a0 = 2.0f * sn0 * cs0, b0 = (cs0 - sn0) * (cs0 + sn0);
+                    const float a1 = 2.0f * sn1 * cs1, b1 = (cs1 - sn1) * (cs1 + sn1);
+                    const float a2 = 2.0f * sn2 * cs2, b2 = (cs2 - sn2) * (cs2 + sn2);
+                    sn0 = a0, cs0 = b0, sn1 = a1, cs1 = b1, sn2 = a2, cs2 = b2;
+                }
+                v16[f] = h ? sn2 : sn0;        // values 8 + f (sin of component 2) / f (sin of component 0)
+                v16[4 + f] = h ? cs0 : sn1;    // values 12 + f (cos of component 0) / 4 + f (sin of component 1)
+                v17[f] = h ? 0.f : cs1;        // values 16 + f (cos of component 1)
+                v17[4 + f] = h ? 0.f : cs2;    // values 20 + f (cos of component 2)
             }
             split8(v16, xh[16], xl[16]);
             split8(v17, xh[17], xl[17]);
