@@ -566,11 +566,10 @@ __device__ __forceinline__ void color_head(const ShadeParams &P, int lane, const
 // the same with the weights from the LDS table w8tab[((c * 4 + t) * 2 + h) * 16 + r] (accumulator order).  Inline asm
 // reads (hipcc would guard plain ones with s_waitcnt vmcnt(0) while the next tile's weight DMA is in flight), all
 // twelve per colour in flight at once.
-__device__ __forceinline__ void color_head_lds(const ShadeParams &P, const u32x4 *w8tab, int lane, const float (&hA)[64],
-                                               float (&rgb)[3])
+__device__ __forceinline__ void color_head_lds(const float (&b8)[3], const u32x4 *w8tab, int lane,
+                                               const float (&hA)[64], float (&rgb)[3])
 {
     const int h = lane >> 5;
-    const float *b8 = P.wbuf + P.b_off[8];
     const unsigned base = (unsigned)(uintptr_t)w8tab + 64u * h;
     float part[3];
 #pragma unroll
@@ -1496,6 +1495,9 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_color_bf16(ShadeParams P)
     Ring ring;
     ring_start<18>(rsrc, w5_, b5, lane, tid, wave_u, lds, ring);
     const float4 *agg4 = reinterpret_cast<const float4 *>(P.agg);
+    // loads behind the last MFMA of a tile would each cost a full vmcnt(0) round trip: head biases once, the sample's
+    // density with the tile's other loads
+    const float b8[3] = {P.wbuf[P.b_off[8]], P.wbuf[P.b_off[8] + 1], P.wbuf[P.b_off[8] + 2]};
     // sample -> ray -> direction of the first tile; the chain of the next tile is issued while this one computes
     int s_nx, ray_nx;
     float dnx[3];
@@ -1512,6 +1514,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_color_bf16(ShadeParams P)
         const int v_idx = V0 + tile * SPT + wave * 32 + j;  // colour kernels are launched with V0 = 0
         const bool ok = v_idx < S_valid;
         const int s = s_nx;
+        const float sigma = P.smp_sigma[ok ? v_idx : 0];
         const float dir[3] = {dnx[0], dnx[1], dnx[2]};
         const int v_nx = v_idx + (int)gridDim.x * SPT;
         s_nx = P.vs_list[v_nx < S_valid ? v_nx : 0];
@@ -1563,8 +1566,8 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_color_bf16(ShadeParams P)
         dense_layer_bf16<8, 4, 18, false, true, true>(rsrc, w7, w5, b7, b5, lane, tid, wave_u, lds, ring, xh, xl, nullptr,
                                                       nullptr, StoreOut{o});
         float rgb[3];
-        color_head_lds(P, w8tab, lane, o, rgb);
-        if (ok && h == 0) P.smp_out[s] = make_float4(P.smp_sigma[v_idx], rgb[0], rgb[1], rgb[2]);
+        color_head_lds(b8, w8tab, lane, o, rgb);
+        if (ok && h == 0) P.smp_out[s] = make_float4(sigma, rgb[0], rgb[1], rgb[2]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
