@@ -662,9 +662,12 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
     const int SPT = (32 / K) * WAVES;  // samples per workgroup tile
     const int V0 = P.n_sel[P.i_v0], S_valid = P.n_sel[P.i_v1];
     const int ntiles = (S_valid - V0 + SPT - 1) / SPT;
-    // contiguous tile range per workgroup: neighbouring samples (same / adjacent rays) stay on one XCD's L2
-    const int t_begin = (int)(((int64_t)ntiles * blockIdx.x) / gridDim.x);
-    const int t_end = (int)(((int64_t)ntiles * (blockIdx.x + 1)) / gridDim.x);
+    // XCD-aware tile order (see k_shade_pairs_bf16): 32 consecutive tiles per XCD and round, so that the pt_table rows
+    // neighbouring rays share are fetched into that XCD's L2 once (12.7 GB beyond L2 per launch with one contiguous
+    // tile range per workgroup)
+    const int G = gridDim.x;
+    const int t_begin = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    const int t_end = ntiles;
 
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wbuf), 0, (int)P.wbytes, 0x00020000);
@@ -673,7 +676,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
     const float *b0 = P.wbuf + P.b_off[0], *b1 = P.wbuf + P.b_off[1], *b2 = P.wbuf + P.b_off[2],
                 *b3 = P.wbuf + P.b_off[3];
 
-    for (int tile = t_begin; tile < t_end; ++tile) {
+    for (int tile = t_begin; tile < t_end; tile += G) {
         // opaque per iteration: otherwise the ~1000 scalar load offsets are hoisted out of this loop and
         // spilled to VGPR lanes
         int w0 = w0_, w1 = w1_, w2 = w2_, w3 = w3_;
