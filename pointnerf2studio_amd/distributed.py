@@ -121,6 +121,7 @@ class ViewGatherPipe:
         self.gathered = [torch.empty((w, n_views, n, C), dtype=dtype, device=device) for _ in range(2)]
         self.images = torch.empty((n_views, shard.H * shard.W, C), dtype=dtype, device=device)
         self.work = [None, None]
+        self.use_async = True
         self.step = 0
         self.prev = None
 
@@ -130,7 +131,14 @@ class ViewGatherPipe:
     def submit(self) -> None:
         b = self.step % 2
         if self.use_dist:
-            self.work[b] = dist.all_gather_into_tensor(self.gathered[b].view(-1, self.C), self.local[b], async_op=True)
+            out, inp = self.gathered[b].view(-1, self.C), self.local[b]
+            if self.use_async:
+                try:
+                    self.work[b] = dist.all_gather_into_tensor(out, inp, async_op=True)
+                except (RuntimeError, NotImplementedError):
+                    self.use_async = False   # a backend without asynchronous all_gather: exchange synchronously
+            if not self.use_async:
+                dist.all_gather_into_tensor(out, inp)
         else:
             self.gathered[b][0].view(-1, self.C).copy_(self.local[b])
         if self.prev is not None:
