@@ -90,7 +90,7 @@ def pmc_traffic_bytes(kernel):
     path = os.path.join(ROOT, "profiles", "r01", "pmc_hbm_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f)["kernels"][f"pnr::{kernel}<true>"]["hbm_bytes_per_launch_corrected"]
+            return json.load(f)["kernels"][f"pnr::{kernel}<8>"]["hbm_bytes_per_launch_corrected"]
     except (OSError, KeyError, ValueError):
         return None
 

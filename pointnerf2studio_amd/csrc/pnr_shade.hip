@@ -160,23 +160,35 @@ __device__ __forceinline__ void fast_sincos(float x, float &sn, float &cs)
     cs = ((q + 1) & 2) ? -cc : cc;
 }
 
-// v + (v of the lane DPP control CTRL selects): 0xB1 / 0x4E = quad_perm xor 1 / xor 2, 0x141 = row_half_mirror
+// v + (v of the lane DPP control CTRL selects): 0xB1 / 0x4E = quad_perm xor 1 / xor 2, 0x141 = row_half_mirror,
+// 0x140 = row_mirror
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v)
 {
     return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 
-// sum over the K lanes of one sample (lanes [g*K, g*K+K) inside each 32-lane half)
-template <bool POW2_8>
+// Lane segment of one sample inside each 32-lane half.  SEG = 8 (K <= 8) / 16 (K <= 16): the sample's K rows sit in
+// the first K lanes of an 8- / 16-lane segment aligned to the DPP rows (the other lanes of the segment idle: pidx -1,
+// weight 0), so that sums over a sample are DPP steps.  SEG = 0 (K > 16): segments of exactly K lanes, summed with
+// K cross-lane reads.
+template <int SEG>
+__device__ __forceinline__ int seg_len(int K)
+{
+    return SEG ? SEG : K;
+}
+
+// sum over the lanes of one sample's segment (idle lanes must hold 0)
+template <int SEG>
 __device__ __forceinline__ float seg_sum(float v, int K, int lane)
 {
-    if (POW2_8) {
-        // 8 consecutive lanes, all on the VALU (DPP): xor-1 and xor-2 inside each quad, then the mirrored quad
-        // of the 8-lane half row (lane i <- lane 7 - i) -- no LDS crossbar (ds_bpermute) involved
-        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
-        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
-        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    if (SEG == 8 || SEG == 16) {
+        // all on the VALU (DPP): xor-1 and xor-2 inside each quad, the mirrored quad of the 8-lane half row (lane i <-
+        // lane 7 - i), and for 16 lanes the mirrored half row -- no LDS crossbar (ds_bpermute) involved
+        v = dpp_add<0xB1>(v);
+        v = dpp_add<0x4E>(v);
+        v = dpp_add<0x141>(v);
+        if (SEG == 16) v = dpp_add<0x140>(v);
         return v;
     } else {
         const int j = lane & 31;
@@ -195,6 +207,7 @@ struct RowCtx {
     int v_idx;    // valid-sample index of this lane's row
     int slot;     // neighbour slot of the row
     bool row_ok;  // the row maps to a real (sample, slot)
+    bool smp_ok;  // the lane's segment maps to a real sample (the lane may still be an idle slot >= K)
     float wgt;    // normalised inverse-distance weight (0 for unfilled slots)
     float ex[4];  // this lane half's share of [color(3), dir - view (3), <dir, view>, 0]
 };
@@ -208,35 +221,36 @@ struct RowCtx {
 // SIMD cannot hide a vs_list -> smp_pidx -> point-row chain of three HBM/L2 latencies any other way).
 struct RowFetch {
     int v_idx, slot, s, pidx, ray, urow, cid;
-    bool row_ok;
+    bool row_ok, smp_ok;
     float4 a0, c0, c1, loc;
     float dirx, diry, dirz;
 };
 
-template <bool K8>
+template <int SEG>
 __device__ __forceinline__ void fetch_a(const ShadeParams &P, int tile, int lane, int wave, int V0, int S_valid,
                                         RowFetch &f)
 {
     const int j = lane & 31;
-    const int K = K8 ? 8 : P.K;
-    const int SPW = 32 / K;
+    const int L = seg_len<SEG>(P.K);
+    const int SPW = 32 / L;
     const int SPT = SPW * WAVES;
-    const int sl = j / K;
+    const int sl = j / L;
     f.v_idx = V0 + tile * SPT + wave * SPW + sl;
-    f.row_ok = (j < SPW * K) && (f.v_idx < S_valid);
-    f.slot = j - sl * K;
+    f.slot = j - sl * L;
+    f.smp_ok = (j < SPW * L) && (f.v_idx < S_valid);
+    f.row_ok = f.smp_ok && f.slot < P.K;
     // unconditional loads at clamped indices: a branch here would end the basic block, and hipcc then sinks the
     // hi/lo split of the previous layer out of the MFMA shadows into the block behind the branch
     // (the select on row_ok happens in fetch_b: here it would put a wait for this load right behind its issue)
     f.s = P.vs_list[f.row_ok ? f.v_idx : 0];
 }
 
-template <bool K8>
+template <int SEG>
 __device__ __forceinline__ void fetch_b(const ShadeParams &P, RowFetch &f)
 {
-    const int K = K8 ? 8 : P.K;
+    const int K = P.K;
     f.s = f.row_ok ? f.s : 0;
-    const int pv = P.smp_pidx[(int64_t)f.s * K + f.slot];
+    const int pv = P.smp_pidx[(int64_t)f.s * K + (f.row_ok ? f.slot : 0)];
     f.pidx = f.row_ok ? pv : -1;
     f.loc = P.smp_loc[f.s];
     f.ray = P.smp_ray[f.s];
@@ -339,15 +353,16 @@ __device__ __forceinline__ void point_inputs(const float (&e)[16], float *x0)
 }
 
 // the lane's pair inputs: weight, encoded distances (xq[0:32] = x0[112:144]) and the extra head inputs
-template <bool K8, bool FAST_PE>
+template <int SEG, bool FAST_PE>
 __device__ __forceinline__ void pair_inputs(const ShadeParams &P, const RowFetch &f, const Camera &cam, int lane,
                                             float *xq, RowCtx &ctx)
 {
     const int h = lane >> 5;
-    const int K = K8 ? 8 : P.K;
+    const int K = P.K;
     ctx.s = f.s;
     ctx.v_idx = f.v_idx;
     ctx.row_ok = f.row_ok;
+    ctx.smp_ok = f.smp_ok;
     ctx.slot = f.slot;
     const bool valid = f.pidx >= 0;
     const float4 a0 = f.a0, c0 = f.c0, c1 = f.c1, loc = f.loc;
@@ -357,7 +372,7 @@ __device__ __forceinline__ void pair_inputs(const ShadeParams &P, const RowFetch
     const float dwx = a0.x - loc.x, dwy = a0.y - loc.y, dwz = a0.z - loc.z;
     const float nrm = sqrtf(dwx * dwx + dwy * dwy + dwz * dwz);
     float wgt = valid ? 1.0f / fmaxf(nrm, 1e-6f) : 0.f;
-    const float wsum = seg_sum<K8>(wgt, K, lane);
+    const float wsum = seg_sum<SEG>(wgt, K, lane);
     ctx.wgt = wgt / fmaxf(wsum, 1e-8f);
 
     float dd[3];
@@ -481,12 +496,12 @@ __device__ __forceinline__ int64_t agg_idx4(int v, int k, int hp, int h)
 }
 
 // density head + weighted K-aggregation + stores (studio_model.py:337-353)
-template <bool K8, bool PACKED>
+template <int SEG, bool PACKED>
 __device__ __forceinline__ void finish_rows(const ShadeParams &P, int lane, const float (&hC)[128],
                                             const RowCtx &ctx)
 {
     const int h = lane >> 5;
-    const int K = K8 ? 8 : P.K;
+    const int K = P.K;
     const float *w4 = P.wbuf + P.w_off[4];
     const float b4 = P.wbuf[P.b_off[4]];
     // The 256 head weights are wave-uniform: 32 at a time through the scalar cache (hipcc turned the per-lane
@@ -512,7 +527,7 @@ __device__ __forceinline__ void finish_rows(const ShadeParams &P, int lane, cons
     float part = h ? part_hi : part_lo;
     part += __shfl_xor(part, 32, 64);
     const float alpha = fmaxf(part + b4, 0.f);
-    const float sigma = seg_sum<K8>(alpha * ctx.wgt, K, lane);
+    const float sigma = seg_sum<SEG>(alpha * ctx.wgt, K, lane);
     const bool writer = ctx.row_ok && ctx.slot == 0;
     if (writer && h == 0) {
         P.smp_sigma[ctx.v_idx] = sigma;
@@ -524,10 +539,10 @@ __device__ __forceinline__ void finish_rows(const ShadeParams &P, int lane, cons
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float4 o;
-            o.x = seg_sum<K8>(hC[m * 16 + 4 * q + 0] * ctx.wgt, K, lane);
-            o.y = seg_sum<K8>(hC[m * 16 + 4 * q + 1] * ctx.wgt, K, lane);
-            o.z = seg_sum<K8>(hC[m * 16 + 4 * q + 2] * ctx.wgt, K, lane);
-            o.w = seg_sum<K8>(hC[m * 16 + 4 * q + 3] * ctx.wgt, K, lane);
+            o.x = seg_sum<SEG>(hC[m * 16 + 4 * q + 0] * ctx.wgt, K, lane);
+            o.y = seg_sum<SEG>(hC[m * 16 + 4 * q + 1] * ctx.wgt, K, lane);
+            o.z = seg_sum<SEG>(hC[m * 16 + 4 * q + 2] * ctx.wgt, K, lane);
+            o.w = seg_sum<SEG>(hC[m * 16 + 4 * q + 3] * ctx.wgt, K, lane);
             if (writer) {
                 if (PACKED)
                     reinterpret_cast<float4 *>(P.agg)[agg_idx4(ctx.v_idx, 2 * m + (q >> 1), h, q & 1)] = o;
@@ -653,13 +668,12 @@ __device__ __forceinline__ void dense_layer(__amdgpu_buffer_rsrc_t rsrc, int wba
         for (int r = 0; r < 16; ++r) out[m * 16 + r] = acc[m][r];
 }
 
-template <bool K8>
+template <int SEG>
 __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
 {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int K = K8 ? 8 : P.K;
-    const int SPT = (32 / K) * WAVES;  // samples per workgroup tile
+    const int SPT = (32 / seg_len<SEG>(P.K)) * WAVES;  // samples per workgroup tile
     const int V0 = P.n_sel[P.i_v0], S_valid = P.n_sel[P.i_v1];
     const int ntiles = (S_valid - V0 + SPT - 1) / SPT;
     // XCD-aware tile order (see k_shade_pairs_bf16): 32 consecutive tiles per XCD and round, so that the pt_table rows
@@ -689,12 +703,12 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
         const float4 *trow;
         {
             RowFetch f;
-            fetch_a<K8>(P, tile, lane, wave, V0, S_valid, f);
-            fetch_b<K8>(P, f);
+            fetch_a<SEG>(P, tile, lane, wave, V0, S_valid, f);
+            fetch_b<SEG>(P, f);
             fetch_c_pair(P, f);
             trow = P.pt_table + (int64_t)f.urow * 64 + 4 * (lane >> 5);
             const Camera cam = load_cam_lanes(P.cr, f.cid);
-            pair_inputs<K8, false>(P, f, cam, lane, xq, ctx);
+            pair_inputs<SEG, false>(P, f, cam, lane, xq, ctx);
         }
         float hA[128];
         dense_layer<32, 8>(rsrc, w0, b0, lane, xq, hA, trow);
@@ -716,7 +730,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
         dense_layer<128, 8>(rsrc, w3, b3, lane, hA, hC);
 #pragma unroll
         for (int i = 0; i < 128; ++i) hC[i] = leaky(hC[i]);
-        finish_rows<K8, false>(P, lane, hC, ctx);
+        finish_rows<SEG, false>(P, lane, hC, ctx);
     }
 }
 
@@ -1265,7 +1279,7 @@ __global__ void __launch_bounds__(TPB, 1) k_point_part(ShadeParams P)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <bool K8>
+template <int SEG>
 __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
 {
     __shared__ u32x4 lds[LDS_U4 + 64];
@@ -1273,8 +1287,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int K = K8 ? 8 : P.K;
-    const int SPT = (32 / K) * WAVES;
+    const int SPT = (32 / seg_len<SEG>(P.K)) * WAVES;
     const int V0 = P.n_sel[P.i_v0], S_valid = P.n_sel[P.i_v1];
     const int ntiles = (S_valid - V0 + SPT - 1) / SPT;
     // XCD-aware tile order.  Workgroup b runs on XCD b % 8 (round-robin dispatch), one workgroup per CU.  In every
@@ -1315,8 +1328,8 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
     ring_start<8>(rsrc, wb_, nullptr, lane, tid, wave_u, lds, ring);
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     RowFetch cur, nxt;
-    fetch_a<K8>(P, t_begin, lane, wave, V0, S_valid, cur);
-    fetch_b<K8>(P, cur);
+    fetch_a<SEG>(P, t_begin, lane, wave, V0, S_valid, cur);
+    fetch_b<SEG>(P, cur);
     fetch_c_pair(P, cur);
     for (int tile = t_begin; tile < t_end; tile += G) {
         int wb = wb_, w1 = w1_, w2 = w2_, w3 = w3_;
@@ -1325,7 +1338,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
         const Camera cam = load_cam_wave(P.cr, cur.cid);
         // first level of the next tile's gather chain (a tile past the end loads row 0: harmless); the other two
         // levels follow at the layer boundaries
-        fetch_a<K8>(P, tile + G, lane, wave, V0, S_valid, nxt);
+        fetch_a<SEG>(P, tile + G, lane, wave, V0, S_valid, nxt);
         __builtin_amdgcn_sched_barrier(0);
         // Point halves of layer 1 (pt_table rows, accumulator order).  A lane reads 512 B in 32 scattered 16-byte
         // loads; 4 waves x 32 of them keep the CU's texture-address unit busy for ~7k cycles (tools/ub_gather.hip)
@@ -1352,7 +1365,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
         bf16x8 xqh[4], xql[4];
         {
             float xq[32];
-            pair_inputs<K8, true>(P, cur, cam, lane, xq, ctx);
+            pair_inputs<SEG, true>(P, cur, cam, lane, xq, ctx);
 #pragma unroll
             for (int s = 0; s < 4; ++s) split8(&xq[8 * s], xqh[s], xql[s]);
         }
@@ -1360,7 +1373,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
         bf16x8 xh[17], xl[17], yh[17], yl[17];
         dense_layer1b_bf16<16>(rsrc, wb, w1, b1, lane, tid, wave_u, lds, ring, xqh, xql, pin, yh, yl);
         const unsigned long long ts2 = stamp();
-        fetch_b<K8>(P, nxt);
+        fetch_b<SEG>(P, nxt);
         // layer 2's output (+ the 7 extra head inputs as k-step 16) goes to xh/xl
         dense_layer_bf16<16, 8, 17, true>(rsrc, w1, w2, b1, b2, lane, tid, wave_u, lds, ring, yh, yl, xh, xl, StoreOut{nullptr});
         const unsigned long long ts3 = stamp();
@@ -1373,12 +1386,13 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
         const unsigned long long ts4 = stamp();
         // Last layer.  The chain wraps around: the next pair tile starts again with the pair half of layer 0, whose
         // accumulators come from pt_table (no bias prefetch).
-        if (K8) {
-            // K = 8: density head and K-aggregation (studio_model.py:337-353) run inside the layer, one finished
+        if (SEG != 0) {
+            // K <= 16: density head and K-aggregation (studio_model.py:337-353) run inside the layer, one finished
             // value per k-step in the MFMA shadow.  Value r of output tile t (feature 32t + 8(r>>2) + 4h + (r&3)) is
             // multiplied with its head weight (w4tab: accumulator order, 16 per lane half and tile, fetched four at a
-            // time three k-steps ahead), weighted, summed over the sample's 8 lanes, and kept by the lane whose
-            // neighbour slot equals t: afterwards every lane stores one 32-feature tile of its sample's 256.
+            // time three k-steps ahead), weighted, summed over the lanes of the sample's segment, and kept by the lane
+            // whose slot equals t: afterwards lanes 0..7 of a segment store one 32-feature tile each of the sample's 256.
+            constexpr int NS = SEG == 16 ? 4 : 3;   // DPP steps of the segment sum
             float part = 0.f;
             float mine[16];
             f32x4 wv[4];
@@ -1395,10 +1409,11 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
             // The three DPP steps of the 8-lane sum form a pipeline over consecutive values (p1..p3): a DPP operand
             // written by the instruction just before it costs two wait states (s_nop), here every DPP reads a
             // register written one k-step earlier.
-            float p1 = 0.f, p2 = 0.f, p3 = 0.f;
+            float p1 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f;
             auto stage = [&](int L) {  // value L leaves the pipeline
-                const float a = dpp_add<0x141>(p3);
+                const float a = SEG == 16 ? dpp_add<0x140>(p4) : dpp_add<0x141>(p3);
                 if (L >= 0) mine[L & 15] = (ctx.slot == (L >> 4)) ? a : ((L >> 4) == 0 ? 0.f : mine[L & 15]);
+                if (SEG == 16) p4 = dpp_add<0x141>(p3);
                 p3 = dpp_add<0x4E>(p2);
                 p2 = dpp_add<0xB1>(p1);
             };
@@ -1406,18 +1421,19 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
                 const f32x4 w = wv[r >> 2];
                 const float wr = (r & 3) == 0 ? w.x : (r & 3) == 1 ? w.y : (r & 3) == 2 ? w.z : w.w;
                 part += v * wr;
-                stage(16 * t + r - 3);
+                stage(16 * t + r - NS);
                 p1 = v * ctx.wgt;
                 // (an opaque use: hipcc otherwise sinks the whole chain into the block of the stores behind the layer)
-                asm volatile("" : "+v"(p1), "+v"(p2), "+v"(p3), "+v"(part));
-                if (16 * t + r >= 3) asm volatile("" : "+v"(mine[(16 * t + r - 3) & 15]));
+                asm volatile("" : "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(part));
+                if (16 * t + r >= NS) asm volatile("" : "+v"(mine[(16 * t + r - NS) & 15]));
             };
             dense_layer_bf16<16, 8, 8, false, false, true>(rsrc, w3, wb, b3, nullptr, lane, tid, wave_u, lds, ring, yh,
                                                            yl, nullptr, nullptr, sink, hook);
-            stage(125);
-            p1 = 0.f;
-            stage(126);
-            stage(127);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                stage(128 - NS + i);
+                p1 = 0.f;
+            }
             const unsigned long long ts5 = stamp();
             ph[4] += ts5 - ts4;
             // Retire the next tile's prefetched loads HERE, ahead of the stores (vector memory returns in order and
@@ -1426,12 +1442,12 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
             asm volatile("" ::"v"(nxt.dirz), "v"(nxt.urow));
             part += __shfl_xor(part, 32, 64);
             const float alpha = fmaxf(part + b4, 0.f);
-            const float sigma = seg_sum<true>(alpha * ctx.wgt, 8, lane);
-            if (ctx.row_ok) {
-                if (ctx.slot == 0 && lane < 32) {
-                    P.smp_sigma[ctx.v_idx] = sigma;
-                    if (P.smp_sig_s) P.smp_sig_s[ctx.s] = sigma;
-                }
+            const float sigma = seg_sum<SEG>(alpha * ctx.wgt, P.K, lane);
+            if (ctx.row_ok && ctx.slot == 0 && lane < 32) {
+                P.smp_sigma[ctx.v_idx] = sigma;
+                if (P.smp_sig_s) P.smp_sig_s[ctx.s] = sigma;
+            }
+            if (ctx.smp_ok && ctx.slot < 8) {   // (idle lanes of the segment store too: K < 8 leaves slots K..7 idle)
                 float4 *agg4 = reinterpret_cast<float4 *>(P.agg);
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -1446,7 +1462,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
             const unsigned long long ts5 = stamp();
             ph[4] += ts5 - ts4;
             asm volatile("" ::"v"(nxt.dirz), "v"(nxt.urow));
-            finish_rows<K8, true>(P, lane, o, ctx);  // o: LeakyReLU already applied inside the layer
+            finish_rows<SEG, true>(P, lane, o, ctx);  // o: LeakyReLU already applied inside the layer
             ph[5] += stamp() - ts5;
         }
         ph[0] += ts1 - ts0;
@@ -1864,7 +1880,8 @@ int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr,
     PNR_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     // decoded features of samples without neighbours (or not shaded) are zero (studio_model.py:361-362)
     PNR_HIP_CHECK(hipMemsetAsync(ws.smp_out, 0, (size_t)cap * sizeof(float4), stream));
-    const int spt = (32 / K) * WAVES;
+    const int seg = K <= 8 ? 8 : (K <= 16 ? 16 : 0);   // lanes per sample segment (0: exactly K)
+    const int spt = (32 / (seg ? seg : K)) * WAVES;
     const int64_t max_tiles = (cap + spt - 1) / spt;
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cus, max_tiles));
     const bool bf = precision == PNR_PRECISION_BF16X3;
@@ -1882,16 +1899,21 @@ int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr,
     }
     if (ev_points) PNR_HIP_CHECK(hipEventRecord(ev_points, stream));
     auto launch_pairs = [&]() {
-        if (K == 8) {
+        if (seg == 8) {
             if (bf)
-                hipLaunchKernelGGL(k_shade_pairs_bf16<true>, dim3(grid), dim3(TPB), 0, stream, P);
+                hipLaunchKernelGGL(k_shade_pairs_bf16<8>, dim3(grid), dim3(TPB), 0, stream, P);
             else
-                hipLaunchKernelGGL(k_shade_pairs<true>, dim3(grid), dim3(TPB), 0, stream, P);
+                hipLaunchKernelGGL(k_shade_pairs<8>, dim3(grid), dim3(TPB), 0, stream, P);
+        } else if (seg == 16) {
+            if (bf)
+                hipLaunchKernelGGL(k_shade_pairs_bf16<16>, dim3(grid), dim3(TPB), 0, stream, P);
+            else
+                hipLaunchKernelGGL(k_shade_pairs<16>, dim3(grid), dim3(TPB), 0, stream, P);
         } else {
             if (bf)
-                hipLaunchKernelGGL(k_shade_pairs_bf16<false>, dim3(grid), dim3(TPB), 0, stream, P);
+                hipLaunchKernelGGL(k_shade_pairs_bf16<0>, dim3(grid), dim3(TPB), 0, stream, P);
             else
-                hipLaunchKernelGGL(k_shade_pairs<false>, dim3(grid), dim3(TPB), 0, stream, P);
+                hipLaunchKernelGGL(k_shade_pairs<0>, dim3(grid), dim3(TPB), 0, stream, P);
         }
     };
     if (!early) {
