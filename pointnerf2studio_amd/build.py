@@ -20,7 +20,8 @@ LIB_NAME = "libpnr_hip.so"
 LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
 OBJ_DIR = os.path.join(PKG_DIR, "csrc", "_obj")
 
-SOURCES = ["pnr_scan.hip", "pnr_scene.hip", "pnr_query.hip", "pnr_shade.hip", "pnr_render.hip"]
+SOURCES = ["pnr_scan.hip", "pnr_scene.hip", "pnr_query.hip", "pnr_shade.hip", "pnr_shade_fp32.hip", "pnr_shade_bf16.hip",
+           "pnr_render.hip"]
 
 # -ffp-contract=off: the voxel coordinate, the sample position (o + d*t) and the neighbour distance
 # must be evaluated exactly as the reference / oracle do (no FMA contraction); the MLP runs on fp32
@@ -45,7 +46,8 @@ def _stale(target: str, deps) -> bool:
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
-    headers = [os.path.join(CSRC, "pnr_internal.h"), os.path.join(INCLUDE, "pnr.h"), os.path.abspath(__file__)]
+    headers = [os.path.join(CSRC, "pnr_internal.h"), os.path.join(CSRC, "pnr_shade_common.h"),
+               os.path.join(INCLUDE, "pnr.h"), os.path.abspath(__file__)]
     cc = hipcc()
     jobs = []
     for src in SOURCES:

@@ -7,7 +7,7 @@ mkdir -p pointnerf2studio_amd/_abl
 C=pointnerf2studio_amd/csrc
 for a in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -shared \
-    -DPNR_ABLATE=$a -Iinclude -I$C $C/pnr_scan.hip $C/pnr_scene.hip $C/pnr_query.hip $C/pnr_shade.hip $C/pnr_render.hip \
+    -DPNR_ABLATE=$a -Iinclude -I$C $C/pnr_scan.hip $C/pnr_scene.hip $C/pnr_query.hip $C/pnr_shade.hip $C/pnr_shade_fp32.hip $C/pnr_shade_bf16.hip $C/pnr_render.hip \
     -o pointnerf2studio_amd/_abl/libpnr_abl$a.so &
 done
 wait
