@@ -259,16 +259,17 @@ def test_render_full_size_properties(gpu_device):
     assert float(b["acc"].min()) >= 0.0 and float(b["acc"].max()) <= 1.0 + 1e-5
 
 
-def test_render_views_equals_per_camera_renders(oracle, gpu_device):
+@pytest.mark.parametrize("K", [8, 12, 5])
+def test_render_views_equals_per_camera_renders(oracle, gpu_device, K):
     """pnr_render_views (several cameras in one call; the reference allows one per bundle, studio_utils.py:152):
     pixels are bitwise identical to per-camera pnr_render calls, with contiguous bundles and with an explicit
-    per-ray camera index in shuffled order."""
+    per-ray camera index in shuffled order.  K = 12 / 5: the 16-lane and the partly idle 8-lane sample segments."""
     pts = small_scene(80000)
-    cfg = oracle_cfg(oracle)
+    cfg = oracle_cfg(oracle, K=K)
     w = synthetic.make_weights(0, sigma_scale=300.0, bias_scale=0.1)
     scene, wh, hyp, info = build_hip(pts, cfg, gpu_device, weights=w)
     for precision in ("fp32", "bf16x3"):
-        rnd = RendererHIP(scene, wh, precision=precision)
+        rnd = RendererHIP(scene, wh, K=K, precision=precision)
         cams, dirs, singles = [], [], []
         for az in (15.0, 140.0, 260.0):
             campos, camrot, d = camera_rays(24, 24, az=az)
