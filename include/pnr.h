@@ -94,9 +94,10 @@ typedef struct {
                               shaded further; the skipped samples would change the pixel by less than eps.        */
 } pnr_render_opts_t;
 
-/* MLP arithmetic.  FP32: v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fma chain.  BF16X3: every fp32 product is
+/* MLP arithmetic.  FP32: v_mfma_f32_32x32x2_f32, every product and sum in fp32.  BF16X3: every fp32 product is
  * evaluated as ah*bh + ah*bl + al*bh on bf16 hi/lo splits with fp32 accumulation (relative error ~2^-16 per
- * product; RGB stays within 1e-5 of the fp32 mode on the parity scenes, inside the 1e-4 budget). */
+ * product; RGB stays within 2e-5 of the fp32 mode, inside the 1e-4 budget; 2.6x the fp32 mode's speed).  In both
+ * modes mlp_base layer 0 is summed in two parts (per-point table + per-pair distances). */
 #define PNR_PRECISION_FP32 0
 #define PNR_PRECISION_BF16X3 1
 
@@ -109,8 +110,9 @@ enum {
     PNR_CNT_PAIRS_VALID = 4,    /* M   valid (sample, neighbour) pairs                       */
     PNR_CNT_CANDIDATES = 5,     /* candidates distance-tested                                */
     PNR_CNT_OVERFLOW = 6,       /* != 0: cap_samples was too small, output incomplete        */
-    PNR_CNT_POINTS_UNIQUE = 7,  /* U   distinct neighbour points of the call                          */
-    PNR_CNT_SAMPLES_SHADED = 8, /* samples that went through the MLPs (= SAMPLES_VALID unless early_stop_eps > 0) */
+    PNR_CNT_POINTS_UNIQUE = 7,  /* U   distinct neighbour points of the call                 */
+    PNR_CNT_SAMPLES_SHADED = 8, /* samples sent through the MLPs (= SAMPLES_VALID unless
+                                   early_stop_eps > 0)                                       */
     PNR_CNT_RESERVED = 9,
     PNR_NUM_COUNTERS = 10
 };
@@ -169,8 +171,8 @@ size_t pnr_render_workspace_bytes_for(const pnr_scene_t *scene, const pnr_render
 /* d_dirs [R,3] ray directions, d_tmid [2,D]: row 0 = coarse-sample mid-point ray parameters at jitter 0, row 1 =
  * segment lengths tvals[j+1] - tvals[j] (diff_ray_marching.py:307-323 evaluated on the host).  With
  * opts->jitter > 0 every ray draws u_j = pnr_jitter_uniform(seed, ray, j) and follows the reference's arithmetic:
- * seg_j * (1 + jitter * (u_j - 0.5)), running sum, + near, mid-points (diff_ray_marching.py:312-323).  Outputs: d_rgb [R,3] (coarse_raycolor, background-filled), d_depth [R],
- * d_acc [R], d_ray_mask [R] int8, d_counters [PNR_NUM_COUNTERS] int64.  cap_samples bounds the number
+ * seg_j * (1 + jitter * (u_j - 0.5)), running sum, + near, mid-points (diff_ray_marching.py:312-323).
+ * Outputs: d_rgb [R,3] (coarse_raycolor, background-filled), d_depth [R], d_acc [R], d_ray_mask [R] int8, d_counters [PNR_NUM_COUNTERS] int64.  cap_samples bounds the number
  * of selected shading samples held in the workspace; if exceeded PNR_CNT_OVERFLOW is set. */
 int pnr_render(const pnr_scene_t *scene, const pnr_weights_t *weights, const float *d_dirs, int64_t R,
                const pnr_camera_t *cam, const float *d_tmid, const pnr_render_opts_t *opts,
