@@ -1,5 +1,7 @@
 // Shade stage, default mode (PNR_PRECISION_BF16X3): v_mfma_f32_32x32x16_bf16 on hi/lo splits, weights shared by the
 // four waves through an LDS ring filled by LDS-DMA.  See pnr_shade_common.h for the design overview.
+#include <type_traits>
+
 #include "pnr_shade_common.h"
 
 namespace pnr {
@@ -82,6 +84,12 @@ struct StoreOut {
     float *out;
     __device__ __forceinline__ void operator()(int tile, int r, float v) const { out[tile * 16 + r] = v; }
 };
+
+// A sink callable as sink(tile, s, const f32x16 &prev) is a STEP sink: instead of single values it is handed the whole
+// finished accumulator of output tile `tile` at every k-step s >= 2 of the following tile and decides itself what to
+// do at which step (k_point_part: a 4x4 transpose across the lanes of a quad spread over the k-steps).
+template <typename Sink>
+constexpr bool kStepSink = std::is_invocable_v<Sink &, int, int, const f32x16 &>;
 
 // `hook(m, s)` runs at the end of k-step s of tile m, inside that k-step's scheduling region: the place for loads
 // that must be issued a few at a time between MFMAs (a burst of scattered loads blocks the wave at issue).
@@ -166,7 +174,10 @@ __device__ __forceinline__ void dense_layer_bf16(__amdgpu_buffer_rsrc_t rsrc, in
                 yl[kk][j0] = (__bf16)r0;
                 yl[kk][j0 + 1] = (__bf16)r1;
             }
-            if (!SPLIT_OUT && m > 0) {
+            if constexpr (!SPLIT_OUT && kStepSink<Sink>) {
+                // a step sink sees the whole previous tile and schedules its own work over the k-steps (from 2 on)
+                if (m > 0 && s >= 2) sink(m - 1, s, prev);
+            } else if (!SPLIT_OUT && m > 0) {
                 // the previous tile's last MFMA was issued >= 96 cycles ago: its accumulators have retired
 #pragma unroll
                 for (int r = (s * 16) / KS; r < ((s + 1) * 16) / KS; ++r)
@@ -209,7 +220,10 @@ __device__ __forceinline__ void dense_layer_bf16(__amdgpu_buffer_rsrc_t rsrc, in
         prev = acc;
         ring.cur = nxs;
     }
-    if (!SPLIT_OUT) {
+    if constexpr (!SPLIT_OUT && kStepSink<Sink>) {
+#pragma unroll
+        for (int s = 2; s < KS; ++s) sink(MT - 1, s, prev);
+    } else if (!SPLIT_OUT) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) sink(MT - 1, r, OUT_LEAKY ? leaky(prev[r]) : prev[r]);
     }
@@ -430,18 +444,52 @@ __global__ void __launch_bounds__(TPB, 1) k_point_part(ShadeParams P)
 #pragma unroll
             for (int s = 0; s < 14; ++s) split8(&x0[8 * s], xh[s], xl[s]);
         }
-        // Rows leave through the layer's sink, one 16-byte store per four finished values, between the MFMAs of the
-        // following output tile: a burst of 32 scattered stores per lane behind the layer kept the texture-address
-        // unit busy for as long as the layer's MFMAs take, and the next tile's first counted vmcnt waited for them
-        // (vector memory retires in order).  Lanes beyond U write into the table's 128 padding rows (no branch:
-        // a branch inside the layer would split its basic block).
-        float4 *dst = P.pt_table + (int64_t)u * 64 + 4 * h;
-        float q4[3];
-        auto sink = [&](int t, int r, float v) {
-            if ((r & 3) < 3)
-                q4[r & 3] = v;
-            else
-                dst[8 * t + (r >> 2)] = make_float4(q4[0], q4[1], q4[2], v);
+        // Rows leave through the layer's step sink, between the MFMAs of the following output tile, as QUAD-COALESCED
+        // stores.  In accumulator order lane (j, h) owns chunks q = 0..3 (16 B each) of row block t of ITS row, so a
+        // plain store instruction would touch 64 different rows; scattered 16-byte accesses keep the texture-address
+        // unit busy for ~100 cycles per instruction (tools/ub_gather.hip), 4 waves x 32 stores x 8 row blocks made
+        // this kernel TA-bound at 2.5x its MFMA time.  A 4x4 transpose across the four lanes of a quad (rows 4a..4a+3,
+        // same h) turns "my four chunks" into "chunk p of the quad's four rows": store i then writes 64 contiguous
+        // bytes of row 4a+i per quad.  Two DPP stages (quad_perm xor 1, xor 2), one exchange unit per k-step.
+        // Lanes beyond U write into the table's 128 padding rows (no branch: it would split the layer's basic block).
+        const int pq = lane & 3;
+        float4 *dst = P.pt_table + (int64_t)(u - pq) * 64 + 4 * h + pq;
+        const bool odd = lane & 1, up = lane & 2;
+        float t1[16];
+        auto sink = [&](int t, int s, const f32x16 &pv) {
+            // value r = 4q + c of the row block: chunk q, component c.  Stage 1 pairs chunks (0,1) and (2,3):
+            // t1[4q + c], unit n = 0..7 = (pair n >> 2, component n & 3) at k-steps 2..9
+            if (s >= 2 && s < 10) {
+                const int n = s - 2, q0 = 2 * (n >> 2), c = n & 3;
+                const float a = pv[4 * q0 + c], b = pv[4 * (q0 + 1) + c];
+                const float ax = dpp_mov<0xB1>(a), bx = dpp_mov<0xB1>(b);
+                t1[4 * q0 + c] = odd ? bx : a;
+                t1[4 * (q0 + 1) + c] = odd ? b : ax;
+            }
+            // stage 2 pairs chunks (0,2) and (1,3): two components per k-step, the two finished rows leave at once
+            if (s >= 10 && s < 14) {
+                const int i = (s - 10) >> 1;
+                if (((s - 10) & 1) == 0) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const float a = t1[4 * i + c], b = t1[4 * (i + 2) + c];
+                        const float ax = dpp_mov<0x4E>(a), bx = dpp_mov<0x4E>(b);
+                        t1[4 * i + c] = up ? bx : a;
+                        t1[4 * (i + 2) + c] = up ? b : ax;
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 2; c < 4; ++c) {
+                        const float a = t1[4 * i + c], b = t1[4 * (i + 2) + c];
+                        const float ax = dpp_mov<0x4E>(a), bx = dpp_mov<0x4E>(b);
+                        t1[4 * i + c] = up ? bx : a;
+                        t1[4 * (i + 2) + c] = up ? b : ax;
+                    }
+                    dst[(int64_t)i * 64 + 8 * t] = make_float4(t1[4 * i], t1[4 * i + 1], t1[4 * i + 2], t1[4 * i + 3]);
+                    dst[(int64_t)(i + 2) * 64 + 8 * t] =
+                        make_float4(t1[4 * (i + 2)], t1[4 * (i + 2) + 1], t1[4 * (i + 2) + 2], t1[4 * (i + 2) + 3]);
+                }
+            }
         };
         (void)ok;
         dense_layer_bf16<14, 8, 14, false>(rsrc, wa, wa, b0, b0, lane, tid, wave_u, lds, ring, xh, xl, nullptr, nullptr,

@@ -175,6 +175,13 @@ __device__ __forceinline__ float dpp_add(float v)
     return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 
+// v of the lane DPP control CTRL selects (every lane has a source for the quad_perm controls)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
 // Lane segment of one sample inside each 32-lane half.  SEG = 8 (K <= 8) / 16 (K <= 16): the sample's K rows sit in
 // the first K lanes of an 8- / 16-lane segment aligned to the DPP rows (the other lanes of the segment idle: pidx -1,
 // weight 0), so that sums over a sample are DPP steps.  SEG = 0 (K > 16): segments of exactly K lanes, summed with
