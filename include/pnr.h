@@ -207,6 +207,38 @@ typedef struct {
 int pnr_render_taps(void *d_workspace, size_t workspace_bytes, int64_t R, int64_t cap_samples, int32_t K,
                     pnr_render_taps_t *taps);
 
+/* ---- training step: gradients of a render ----------------------------------------------------------
+ * Replaces what torch autograd derives when `ns-train pointnerf-original` back-propagates
+ * get_loss_dict (studio_model.py:415-431) through get_outputs (studio_model.py:263-399) and
+ * NeuralPoints.forward's index_select gathers (studio_utils.py:199-207): d loss / d {points_embeding,
+ * points_color, points_dir, the nine Linear weights and biases}.  points_xyz and points_Rw2c are frozen in the
+ * reference (studio_utils.py:84-90) and points_conf does not enter the render (studio_model.py:285-292: it feeds
+ * the loss directly), so none of them gets a gradient here.
+ * Every pointer may be null (that gradient is skipped); gradients are ACCUMULATED (+=) as torch does with .grad:
+ * zero the buffers first for plain gradients.  Shapes are those of pnr_points_pack / pnr_weights_pack inputs. */
+typedef struct {
+    float *d_embedding; /* [N,32] */
+    float *d_color;     /* [N,3]  */
+    float *d_dir;       /* [N,3]  */
+    float *d_w[9];      /* nn.Linear weights, [out,in] row-major, order of pnr_weights_pack */
+    float *d_b[9];      /* [out] */
+} pnr_grads_t;
+
+size_t pnr_backward_workspace_bytes(int64_t cap_samples, int32_t K);
+/* Call after pnr_render / pnr_render_views with the SAME scene, rays, cameras, options, cap_samples and render
+ * workspace (its sample lists and neighbour indices are reused; nothing else may have used that workspace in
+ * between).  The MLP forward is recomputed in fp32 whatever opts->precision the render used.  d_w / d_b are the
+ * raw weights (as given to pnr_weights_pack; `weights` only supplies Rw2c), d_grad_rgb [R,3] is d loss / d rgb.
+ * opts->early_stop_eps must be 0.  d_rgb_recomputed (may be null) receives the fp32 rgb [R,3] of the recomputed
+ * forward.  No host synchronisation; everything is queued on `stream`. */
+int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t *weights, const float *const d_w[9],
+                        const float *const d_b[9], const float *d_dirs, int64_t R, const pnr_camera_t *cams,
+                        int32_t n_cams, const int32_t *d_ray_cam, int64_t rays_per_cam,
+                        const pnr_render_opts_t *opts, const float *d_grad_rgb, void *d_render_workspace,
+                        size_t render_workspace_bytes, int64_t cap_samples, void *d_train_workspace,
+                        size_t train_workspace_bytes, const pnr_grads_t *grads, float *d_rgb_recomputed,
+                        void *stream);
+
 /* ---- per-stage device timing (bench / roofline) ------------------------------------------------- */
 /* When enabled, pnr_render records hipEvents on `stream` between its stages into a ring of
  * PNR_PROFILE_SLOTS slots, one slot per call (no host sync is added to the render).  pnr_profile_calls() is

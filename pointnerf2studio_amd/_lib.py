@@ -28,6 +28,7 @@ EXPORTED_SYMBOLS = [
     "pnr_query_workspace_bytes", "pnr_query_raypos",
     "pnr_render_workspace_bytes", "pnr_render_workspace_bytes_for", "pnr_render", "pnr_render_views",
     "pnr_render_taps",
+    "pnr_backward_workspace_bytes", "pnr_render_backward",
     "pnr_profile_enable", "pnr_profile_calls", "pnr_profile_read",
 ]
 NUM_STAGES = 6
@@ -57,6 +58,11 @@ PRECISION = {"fp32": 0, "bf16x3": 1}
 class RenderTaps(C.Structure):
     _fields_ = [("smp_loc", C.c_void_p), ("smp_ray", C.c_void_p), ("smp_pidx", C.c_void_p),
                 ("smp_out", C.c_void_p), ("ray_cnt", C.c_void_p), ("ray_off", C.c_void_p)]
+
+
+class GradsC(C.Structure):
+    _fields_ = [("d_embedding", C.c_void_p), ("d_color", C.c_void_p), ("d_dir", C.c_void_p),
+                ("d_w", C.c_void_p * 9), ("d_b", C.c_void_p * 9)]
 
 
 _lib: Optional[C.CDLL] = None
@@ -98,6 +104,11 @@ def load() -> C.CDLL:
     lib.pnr_render_views.argtypes = [vp, vp, vp, i64, C.POINTER(CameraC), i32, vp, i64, vp, C.POINTER(RenderOpts), vp, vp,
                                      vp, vp, vp, vp, sz, i64, vp]
     lib.pnr_render_taps.argtypes = [vp, sz, i64, i64, i32, C.POINTER(RenderTaps)]
+    lib.pnr_backward_workspace_bytes.restype = sz
+    lib.pnr_backward_workspace_bytes.argtypes = [i64, i32]
+    lib.pnr_render_backward.argtypes = [vp, vp, C.POINTER(vp * 9), C.POINTER(vp * 9), vp, i64, C.POINTER(CameraC), i32,
+                                        vp, i64, C.POINTER(RenderOpts), vp, vp, sz, i64, vp, sz, C.POINTER(GradsC), vp,
+                                        vp]
     lib.pnr_profile_enable.argtypes = [C.c_int]
     lib.pnr_profile_calls.restype = C.c_int64
     lib.pnr_profile_calls.argtypes = []
@@ -105,7 +116,8 @@ def load() -> C.CDLL:
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("pnr_last_error", "pnr_query_workspace_bytes", "pnr_render_workspace_bytes",
-                        "pnr_render_workspace_bytes_for", "pnr_profile_calls", "pnr_jitter_uniform"):
+                        "pnr_render_workspace_bytes_for", "pnr_profile_calls", "pnr_jitter_uniform",
+                        "pnr_backward_workspace_bytes"):
             fn.restype = C.c_int
     _lib = lib
     return lib

@@ -1,0 +1,903 @@
+// Training step: gradients of a render with respect to the trainable point tensors and the MLP weights
+// (SURVEY.md section 8f rank 1).  Replaces what torch autograd derives for studio_model.py:263-399 when
+// `ns-train pointnerf-original` back-propagates the loss of studio_model.py:415-431 through get_outputs:
+// index_select backward (dense [N,32] scatter), nine F.linear backward pairs, the boolean-compaction scatters,
+// the K-aggregation and the cumprod composite.
+//
+// First HIP version of this row: correct and matrix-core bound, not yet fused.  The query products of the
+// preceding pnr_render call (sample lists, neighbour indices) are taken from its workspace; the MLP forward is
+// recomputed in fp32 with every activation kept ROW-MAJOR in HBM (the "tape"), then walked backwards:
+//   * every Linear is one of three shapes of ONE hand-written fp32 MFMA GEMM (k_gemm: 128x128 tiles,
+//     v_mfma_f32_32x32x2_f32, LDS double buffer): forward X.W^T (+bias, LeakyReLU), data gradient dZ.W (times
+//     LeakyReLU' from the taped activation, written IN PLACE over that activation), weight gradient dZ^T.X
+//     (split over the rows, fp32 atomics into a padded buffer);
+//   * small row-parallel kernels for what is not a GEMM: inputs / encodings, density head + K-aggregation,
+//     colour head, composite (reverse scan per ray), and the scatter of point gradients with float atomics.
+// Frozen tensors (xyz, Rw2c) and the sample positions get no gradient, as in the reference
+// (studio_utils.py:84-103: only embedding / conf / dir / color are Parameters with requires_grad; conf does not
+// enter the render, studio_model.py:285-292).
+#include <algorithm>
+
+#include "pnr_shade_common.h"
+
+namespace pnr {
+
+// ------------------------------------------------------------------------------------------------
+// fp32 MFMA GEMM   C[M,N] = op(A) . op(B)      (all matrices row-major, leading dimensions multiples of 4)
+//   TA = false: A is [M, K] (tile rows m, contiguous k)     TA = true: A is [K, M] (A'[m][k] = A[k][m])
+//   TB = false: B is [K, N]                                 TB = true: B is [N, K] (B'[k][n] = B[n][k])
+// The row count that comes from the device (pairs / samples of the call) is read from *dev_rows: it is M when
+// TA = false and the reduction length K when TA = true (weight gradients, split over gridDim.z).
+// ------------------------------------------------------------------------------------------------
+enum { EPI_STORE = 0, EPI_BIAS_LEAKY = 1, EPI_MASK = 2, EPI_ATOMIC = 3 };
+
+struct GemmArgs {
+    const float *A;
+    const float *B;
+    float *C;
+    int lda, ldb, ldc;
+    int M, N, K;            // static extents (M or K replaced by *dev_rows, see above)
+    const int *dev_rows;
+    const float *bias;      // EPI_BIAS_LEAKY
+    const float *mask;      // EPI_MASK: taped post-activation, same leading dimension as C
+    int mask_cols;          // columns >= mask_cols pass unmasked
+};
+
+constexpr int TM = 128, TN = 128, TK = 16, LDT = TM + 4;
+
+template <bool TA, bool TB, int EPI>
+__global__ void __launch_bounds__(256, 2) k_gemm(GemmArgs g)
+{
+    __shared__ float As[2][TK][LDT];
+    __shared__ float Bs[2][TK][LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int rows = *g.dev_rows;
+    const int M = TA ? g.M : rows;
+    const int N = g.N;
+    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
+    if (m0 >= M || n0 >= N) return;
+    int k_begin = 0, k_end = TA ? rows : g.K;
+    if (TA) {
+        // split of the reduction over gridDim.z, in multiples of TK
+        const int nz = gridDim.z;
+        const int chunk = ((rows + nz - 1) / nz + TK - 1) / TK * TK;
+        k_begin = min(rows, (int)blockIdx.z * chunk);
+        k_end = min(rows, k_begin + chunk);
+        if (k_begin >= k_end) return;
+    }
+    const int wm = wave & 1, wn = wave >> 1;
+
+    float4 ra[2], rb[2];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (TA) {  // natural: 16 rows (k) x 128 contiguous m
+                const int kr = (tid >> 5) + 8 * i, c4 = (tid & 31) * 4;
+                const int k = k0 + kr, m = m0 + c4;
+                ra[i] = (k < k_end && m < M) ? *reinterpret_cast<const float4 *>(g.A + (int64_t)k * g.lda + m)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {  // transposing: 128 rows (m) x 16 contiguous k
+                const int mr = (tid >> 2) + 64 * i, kq = (tid & 3) * 4;
+                const int m = m0 + mr, k = k0 + kq;
+                ra[i] = (m < M && k < k_end) ? *reinterpret_cast<const float4 *>(g.A + (int64_t)m * g.lda + k)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (!TB) {
+                const int kr = (tid >> 5) + 8 * i, c4 = (tid & 31) * 4;
+                const int k = k0 + kr, n = n0 + c4;
+                rb[i] = (k < k_end && n < N) ? *reinterpret_cast<const float4 *>(g.B + (int64_t)k * g.ldb + n)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                const int nr = (tid >> 2) + 64 * i, kq = (tid & 3) * 4;
+                const int n = n0 + nr, k = k0 + kq;
+                rb[i] = (n < N && k < k_end) ? *reinterpret_cast<const float4 *>(g.B + (int64_t)n * g.ldb + k)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (TA) {
+                const int kr = (tid >> 5) + 8 * i, c4 = (tid & 31) * 4;
+                *reinterpret_cast<float4 *>(&As[buf][kr][c4]) = ra[i];
+            } else {
+                const int mr = (tid >> 2) + 64 * i, kq = (tid & 3) * 4;
+                As[buf][kq + 0][mr] = ra[i].x;
+                As[buf][kq + 1][mr] = ra[i].y;
+                As[buf][kq + 2][mr] = ra[i].z;
+                As[buf][kq + 3][mr] = ra[i].w;
+            }
+            if (!TB) {
+                const int kr = (tid >> 5) + 8 * i, c4 = (tid & 31) * 4;
+                *reinterpret_cast<float4 *>(&Bs[buf][kr][c4]) = rb[i];
+            } else {
+                const int nr = (tid >> 2) + 64 * i, kq = (tid & 3) * 4;
+                Bs[buf][kq + 0][nr] = rb[i].x;
+                Bs[buf][kq + 1][nr] = rb[i].y;
+                Bs[buf][kq + 2][nr] = rb[i].z;
+                Bs[buf][kq + 3][nr] = rb[i].w;
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nchunks = (k_end - k_begin + TK - 1) / TK;
+    load_tiles(k_begin);
+    store_tiles(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) load_tiles(k_begin + (c + 1) * TK);
+#pragma unroll
+        for (int kk = 0; kk < TK; kk += 2) {
+            const float a0 = As[buf][kk + h][wm * 64 + j], a1 = As[buf][kk + h][wm * 64 + 32 + j];
+            const float b0 = Bs[buf][kk + h][wn * 64 + j], b1 = Bs[buf][kk + h][wn * 64 + 32 + j];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (c + 1 < nchunks) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // accumulator register r of lane (j, h): row (r & 3) + 8 (r >> 2) + 4 h, column j of the 32x32 block
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = n0 + wn * 64 + b * 32 + j;
+            if (col >= N) continue;
+            const float bias = (EPI == EPI_BIAS_LEAKY) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row >= M) continue;
+                float v = acc[a][b][r];
+                float *dst = g.C + (int64_t)row * g.ldc + col;
+                if (EPI == EPI_BIAS_LEAKY) {
+                    v += bias;
+                    v = v > 0.f ? v : 0.1f * v;
+                } else if (EPI == EPI_MASK) {
+                    if (col < g.mask_cols) v *= (g.mask[(int64_t)row * g.ldc + col] > 0.f) ? 1.0f : 0.1f;
+                }
+                if (EPI == EPI_ATOMIC)
+                    unsafeAtomicAdd(dst, v);
+                else
+                    *dst = v;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace of a backward call
+// ------------------------------------------------------------------------------------------------
+constexpr int LD_X0 = 288, LD_H = 256, LD_H2 = 264, LD_XC = 288, LD_C = 128;
+// padded weights / weight gradients: [out, ld] with the reference's [out, in] in the leading columns
+static const int W_OUT[9] = {256, 256, 256, 256, 1, 128, 128, 128, 3};
+static const int W_IN[9] = {284, 256, 263, 256, 256, 280, 128, 128, 128};
+static const int W_LD[9] = {288, 256, 264, 256, 256, 288, 128, 128, 128};
+
+struct TrainWs {
+    int *cnt;        // [0] rows = S * K, [1] S valid samples
+    int *s2v;        // [cap] sample index -> valid index or -1
+    int *row_pidx;   // [cap * K]
+    float *row_w;    // [cap * K] normalised inverse-distance weight
+    float *row_z;    // [cap * K] density head before the ReLU
+    float *sig;      // [cap] density per valid sample
+    float4 *sg;      // [cap] sigmoid outputs of the colour head
+    float4 *d_out;   // [cap] (d sigma, d rgb) per valid sample
+    float *tmpT;     // [cap] transmittance in front of the sample
+    float *tmpD;     // [cap] segment length
+    float *X0, *H1, *H2, *G1, *G2;  // [cap * K, ld]
+    float *XC, *C1, *C2, *C3;       // [cap, ld]
+    float *Wp[9], *dWp[9], *dbp[9];
+    float *dw_begin;                // dWp / dbp are contiguous: [dw_begin, dw_begin + dw_floats)
+    size_t dw_floats;
+    size_t total;
+};
+
+static TrainWs carve_train_ws(void *base, int64_t cap, int K)
+{
+    TrainWs w{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        void *p = base ? (void *)((char *)base + off) : nullptr;
+        off += (bytes + 255) & ~(size_t)255;
+        return p;
+    };
+    const size_t rows = (size_t)cap * K + TM;  // a tile of slack behind the last row
+    const size_t smp = (size_t)cap + TM;
+    w.cnt = (int *)take(64);
+    w.s2v = (int *)take(smp * 4);
+    w.row_pidx = (int *)take(rows * 4);
+    w.row_w = (float *)take(rows * 4);
+    w.row_z = (float *)take(rows * 4);
+    w.sig = (float *)take(smp * 4);
+    w.sg = (float4 *)take(smp * 16);
+    w.d_out = (float4 *)take(smp * 16);
+    w.tmpT = (float *)take(smp * 4);
+    w.tmpD = (float *)take(smp * 4);
+    w.X0 = (float *)take(rows * LD_X0 * 4);
+    w.H1 = (float *)take(rows * LD_H * 4);
+    w.H2 = (float *)take(rows * LD_H2 * 4);
+    w.G1 = (float *)take(rows * LD_H * 4);
+    w.G2 = (float *)take(rows * LD_H * 4);
+    w.XC = (float *)take(smp * LD_XC * 4);
+    w.C1 = (float *)take(smp * LD_C * 4);
+    w.C2 = (float *)take(smp * LD_C * 4);
+    w.C3 = (float *)take(smp * LD_C * 4);
+    for (int i = 0; i < 9; ++i) w.Wp[i] = (float *)take((size_t)W_OUT[i] * W_LD[i] * 4);
+    const size_t dw0 = off;
+    for (int i = 0; i < 9; ++i) w.dWp[i] = (float *)take((size_t)W_OUT[i] * W_LD[i] * 4);
+    for (int i = 0; i < 9; ++i) w.dbp[i] = (float *)take((size_t)W_OUT[i] * 4);
+    w.dw_begin = base ? (float *)((char *)base + dw0) : nullptr;
+    w.dw_floats = (off - dw0) / 4;
+    w.total = off;
+    return w;
+}
+
+// ------------------------------------------------------------------------------------------------
+// small kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void k_train_set_cams(CamSet set, int n, Camera *__restrict__ dst)
+{
+    const int i = threadIdx.x;
+    if (i < n) dst[i] = set.c[i];
+}
+
+__global__ void k_train_counts(const int *__restrict__ n_sel, int cap, int K, int *__restrict__ cnt)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const int S = min(n_sel[1], cap);
+        cnt[0] = S * K;
+        cnt[1] = S;
+    }
+}
+
+__global__ void k_train_s2v(const int *__restrict__ vs_list, const int *__restrict__ cnt, int *__restrict__ s2v)
+{
+    const int S = cnt[1];
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < S; v += gridDim.x * blockDim.x) s2v[vs_list[v]] = v;
+}
+
+// dst[out, ld] = src[out, in] zero-padded
+__global__ void k_pad_weights(const float *__restrict__ src, int n_out, int n_in, int ld, float *__restrict__ dst)
+{
+    const int n = n_out * ld;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int o = i / ld, c = i - o * ld;
+        dst[i] = c < n_in ? src[(int64_t)o * n_in + c] : 0.f;
+    }
+}
+
+// dst[out, in] += src[out, ld]
+__global__ void k_unpad_add(const float *__restrict__ src, int n_out, int n_in, int ld, float *__restrict__ dst)
+{
+    const int n = n_out * n_in;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int o = i / n_in, c = i - o * n_in;
+        dst[i] += src[(int64_t)o * ld + c];
+    }
+}
+
+struct TrainParams {
+    const float4 *point_rows;
+    float Rw2c[9];
+    CamRef cr;
+    const float *dirs;
+    const float4 *smp_loc;
+    const int *smp_ray;
+    const int *smp_pidx;
+    const int *vs_list;
+    const int *n_sel;
+    int K;
+};
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// One wavefront per (sample, neighbour slot) row: the 284 inputs of mlp_base layer 0
+// [emb(32) | (sin, cos)(emb * 2^f), f < 3 (192) | (sin, cos)(dist * 2^f), f < 5 (60)]  (studio_model.py:309-317,
+// studio_utils.py:58-68), the 7 extra inputs of mlp_head layer 0 and the row's aggregation weight
+// (studio_model.py:270-286).  Unfilled slots (pidx < 0) get zero inputs and weight 0: their gradient vanishes.
+__global__ void __launch_bounds__(256) k_train_rows(TrainParams P, TrainWs w)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwv = (gridDim.x * blockDim.x) >> 6;
+    const int rows = w.cnt[0], K = P.K;
+    for (int row = wv; row < rows; row += nwv) {
+        const int v = row / K, k = row - v * K;
+        const int s = P.vs_list[v];
+        const float4 loc = P.smp_loc[s];
+        const int ray = P.smp_ray[s];
+        // normalised weights: every lane < K looks at one slot of the sample
+        float wl = 0.f;
+        if (lane < K) {
+            const int pk = P.smp_pidx[(int64_t)s * K + lane];
+            if (pk >= 0) {
+                const float4 a = P.point_rows[(int64_t)pk * 12];
+                const float dx = a.x - loc.x, dy = a.y - loc.y, dz = a.z - loc.z;
+                wl = 1.0f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-6f);
+            }
+        }
+        const float wsum = wave_sum(wl);
+        const float wk = __shfl(wl, k, 64) / fmaxf(wsum, 1e-8f);
+        const int pidx = P.smp_pidx[(int64_t)s * K + k];
+        const bool valid = pidx >= 0;
+        const float4 *prow = P.point_rows + (int64_t)max(pidx, 0) * 12;
+        const float4 a0 = prow[0], c0 = prow[1], c1 = prow[2];
+        const float *emb = reinterpret_cast<const float *>(prow + 4);
+        const Camera cam = load_cam(P.cr, cam_id(P.cr, ray));
+        const float dwx = a0.x - loc.x, dwy = a0.y - loc.y, dwz = a0.z - loc.z;
+        float dd[6];
+        rot_rows(P.Rw2c, dwx, dwy, dwz, dd[0], dd[1], dd[2]);
+        {
+            float pcx, pcy, pcz, scx, scy, scz;
+            to_cam(cam, a0.x, a0.y, a0.z, pcx, pcy, pcz);
+            to_cam(cam, loc.x, loc.y, loc.z, scx, scy, scz);
+            const float ppx = pcx / pcz, ppy = pcy / pcz, spx = scx / scz, spy = scy / scz;
+            dd[3] = ppx * pcz - spx * scz;
+            dd[4] = ppy * pcz - spy * scz;
+            dd[5] = pcz - scz;
+        }
+        float *x0 = w.X0 + (int64_t)row * LD_X0;
+        for (int c = lane; c < LD_X0; c += 64) {
+            float val = 0.f;
+            if (valid) {
+                if (c < 32) {
+                    val = emb[c];
+                } else if (c < 224) {
+                    const int q = c - 32, d = q / 6, f = (q - 6 * d) >> 1;
+                    float sn, cs;
+                    sincosf(emb[d] * (float)(1 << f), &sn, &cs);
+                    val = (q & 1) ? cs : sn;
+                } else if (c < 284) {
+                    const int q = c - 224, d = q / 10, f = (q - 10 * d) >> 1;
+                    float dv = dd[0];
+                    dv = d == 1 ? dd[1] : dv;
+                    dv = d == 2 ? dd[2] : dv;
+                    dv = d == 3 ? dd[3] : dv;
+                    dv = d == 4 ? dd[4] : dv;
+                    dv = d == 5 ? dd[5] : dv;
+                    float sn, cs;
+                    sincosf(dv * (float)(1 << f), &sn, &cs);
+                    val = (q & 1) ? cs : sn;
+                }
+            }
+            x0[c] = val;
+        }
+        if (lane < 8) {
+            float sdx, sdy, sdz, vx, vy, vz;
+            rot_rows(P.Rw2c, c0.w, c1.x, c1.y, sdx, sdy, sdz);
+            rot_rows(P.Rw2c, P.dirs[3 * (int64_t)ray], P.dirs[3 * (int64_t)ray + 1], P.dirs[3 * (int64_t)ray + 2], vx, vy,
+                     vz);
+            float e = 0.f;
+            e = lane == 0 ? c0.x : e;
+            e = lane == 1 ? c0.y : e;
+            e = lane == 2 ? c0.z : e;
+            e = lane == 3 ? sdx - vx : e;
+            e = lane == 4 ? sdy - vy : e;
+            e = lane == 5 ? sdz - vz : e;
+            e = lane == 6 ? sdx * vx + sdy * vy + sdz * vz : e;
+            w.H2[(int64_t)row * LD_H2 + 256 + lane] = valid ? e : 0.f;
+        }
+        if (lane == 0) {
+            w.row_pidx[row] = pidx;
+            w.row_w[row] = valid ? wk : 0.f;
+        }
+    }
+}
+
+// One wavefront per valid sample: density head, weighted K-aggregation (studio_model.py:337-353) and the colour
+// MLP's input row [agg(256) | sin(view * 2^f) (12) | cos(...) (12)] (studio_model.py:304-308,355).
+__global__ void __launch_bounds__(256) k_train_head_agg(TrainParams P, TrainWs w, const float *__restrict__ w4,
+                                                        const float *__restrict__ b4)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwv = (gridDim.x * blockDim.x) >> 6;
+    const int S = w.cnt[1], K = P.K;
+    const float4 wq = *reinterpret_cast<const float4 *>(w4 + 4 * lane);
+    const float bias = b4[0];
+    for (int v = wv; v < S; v += nwv) {
+        float4 agg = make_float4(0.f, 0.f, 0.f, 0.f);
+        float sigma = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const int row = v * K + k;
+            const float4 gq = *reinterpret_cast<const float4 *>(w.G2 + (int64_t)row * LD_H + 4 * lane);
+            const float z = wave_sum(gq.x * wq.x + gq.y * wq.y + gq.z * wq.z + gq.w * wq.w) + bias;
+            const float wk = w.row_w[row];
+            if (lane == 0) w.row_z[row] = z;
+            sigma += wk * fmaxf(z, 0.f);
+            agg.x += wk * gq.x;
+            agg.y += wk * gq.y;
+            agg.z += wk * gq.z;
+            agg.w += wk * gq.w;
+        }
+        float *xc = w.XC + (int64_t)v * LD_XC;
+        *reinterpret_cast<float4 *>(xc + 4 * lane) = agg;
+        if (lane < 32) {
+            const int ray = P.smp_ray[P.vs_list[v]];
+            float vv[3];
+            rot_rows(P.Rw2c, P.dirs[3 * (int64_t)ray], P.dirs[3 * (int64_t)ray + 1], P.dirs[3 * (int64_t)ray + 2], vv[0],
+                     vv[1], vv[2]);
+            float val = 0.f;
+            if (lane < 24) {
+                const int q = lane % 12, d = q >> 2, f = q & 3;
+                const float dv = d == 0 ? vv[0] : (d == 1 ? vv[1] : vv[2]);
+                float sn, cs;
+                sincosf(dv * (float)(1 << f), &sn, &cs);
+                val = lane < 12 ? sn : cs;
+            }
+            xc[256 + lane] = val;
+        }
+        if (lane == 0) w.sig[v] = sigma;
+    }
+}
+
+// colour head: Linear 128 -> 3, sigmoid (the widening happens where the value is used) (studio_model.py:357-359)
+__global__ void __launch_bounds__(256) k_train_color_head(TrainWs w, const float *__restrict__ w8,
+                                                          const float *__restrict__ b8)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwv = (gridDim.x * blockDim.x) >> 6;
+    const int S = w.cnt[1];
+    for (int v = wv; v < S; v += nwv) {
+        const float c0 = w.C3[(int64_t)v * LD_C + lane], c1 = w.C3[(int64_t)v * LD_C + 64 + lane];
+        float sg[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float z = wave_sum(c0 * w8[c * 128 + lane] + c1 * w8[c * 128 + 64 + lane]) + b8[c];
+            sg[c] = 1.0f / (1.0f + expf(-z));
+        }
+        if (lane == 0) w.sg[v] = make_float4(sg[0], sg[1], sg[2], 0.f);
+    }
+}
+
+// One thread per ray: the composite of k_composite (studio_model.py:368-390) forwards, then its reverse scan.
+//   w_i = o_i T_i,  T_{i+1} = T_i (1 - o_i + 1e-10),  o_i = 1 - exp(-sigma_i delta_i),  out = sum w c + bg (1 - sum w)
+__global__ void __launch_bounds__(256) k_train_composite_bwd(CamRef cr, pnr_render_opts_t opts, int64_t R,
+                                                             const int *__restrict__ ray_cnt,
+                                                             const int *__restrict__ ray_off,
+                                                             const int *__restrict__ ray_flag,
+                                                             const float4 *__restrict__ smp_loc,
+                                                             const int *__restrict__ n_sel, TrainWs w,
+                                                             const float *__restrict__ g_rgb,
+                                                             float *__restrict__ rgb_out)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const int S = n_sel[0];
+    const int off = ray_off[r];
+    int cnt = ray_cnt[r];
+    if ((int64_t)off + cnt > S) cnt = max(0, S - off);
+    const bool keep = ray_flag[r] != 0 && cnt > 0;
+    float o0 = opts.bg[0], o1 = opts.bg[1], o2 = opts.bg[2];
+    if (keep) {
+        const Camera cam = load_cam(cr, cam_id(cr, r));
+        const float vs = opts.vsize_z, two_vs = 2.0f * vs;
+        auto zc = [&](float x, float y, float z) {
+            const float sx = x - cam.o[0], sy = y - cam.o[1], sz = z - cam.o[2];
+            return sx * cam.R[2] + sy * cam.R[5] + sz * cam.R[8];
+        };
+        const float z_unfilled = zc(0.f, 0.f, 0.f);
+        float4 p = smp_loc[off];
+        float cm = zc(p.x, p.y, p.z);
+        float T = 1.0f, cr_ = 0.f, cg = 0.f, cb = 0.f, acc = 0.f;
+        for (int i = 0; i < cnt; ++i) {
+            float delta;
+            if (i == opts.SR - 1) {
+                delta = vs;
+            } else {
+                float z_next;
+                if (i + 1 < cnt) {
+                    p = smp_loc[off + i + 1];
+                    z_next = zc(p.x, p.y, p.z);
+                } else {
+                    z_next = z_unfilled;
+                }
+                const float cm_next = fmaxf(cm, z_next);
+                delta = cm_next - cm;
+                cm = cm_next;
+                if (delta < 1e-8f || delta > two_vs) delta = vs;
+            }
+            const int v = w.s2v[off + i];
+            const float sigma = v >= 0 ? w.sig[v] : 0.f;
+            const float opacity = 1.0f - expf(-sigma * delta);
+            const float wi = opacity * T;
+            w.tmpT[off + i] = T;
+            w.tmpD[off + i] = delta;
+            T = T * (1.0f - opacity + 1e-10f);
+            if (v >= 0) {
+                const float4 sg = w.sg[v];
+                cr_ += wi * (sg.x * 1.002f - 0.001f);
+                cg += wi * (sg.y * 1.002f - 0.001f);
+                cb += wi * (sg.z * 1.002f - 0.001f);
+            }
+            acc += wi;
+        }
+        o0 = cr_ + opts.bg[0] * (1.0f - acc);
+        o1 = cg + opts.bg[1] * (1.0f - acc);
+        o2 = cb + opts.bg[2] * (1.0f - acc);
+        float g0 = g_rgb[3 * r], g1 = g_rgb[3 * r + 1], g2 = g_rgb[3 * r + 2];
+        if (opts.eval_clamp) {  // torch.clamp passes the gradient inside [min, max]
+            g0 = (o0 < 0.f || o0 > 1.f) ? 0.f : g0;
+            g1 = (o1 < 0.f || o1 > 1.f) ? 0.f : g1;
+            g2 = (o2 < 0.f || o2 > 1.f) ? 0.f : g2;
+            o0 = fminf(fmaxf(o0, 0.f), 1.f);
+            o1 = fminf(fmaxf(o1, 0.f), 1.f);
+            o2 = fminf(fmaxf(o2, 0.f), 1.f);
+        }
+        float GT = 0.f;  // gradient with respect to the transmittance behind sample i
+        for (int i = cnt - 1; i >= 0; --i) {
+            const int v = w.s2v[off + i];
+            const float Ti = w.tmpT[off + i], delta = w.tmpD[off + i];
+            const float sigma = v >= 0 ? w.sig[v] : 0.f;
+            const float ex = expf(-sigma * delta);
+            const float opacity = 1.0f - ex;
+            float c_r = 0.f, c_g = 0.f, c_b = 0.f;
+            if (v >= 0) {
+                const float4 sg = w.sg[v];
+                c_r = sg.x * 1.002f - 0.001f;
+                c_g = sg.y * 1.002f - 0.001f;
+                c_b = sg.z * 1.002f - 0.001f;
+            }
+            const float gw = g0 * (c_r - opts.bg[0]) + g1 * (c_g - opts.bg[1]) + g2 * (c_b - opts.bg[2]);
+            const float go = gw * Ti - GT * Ti;
+            GT = gw * opacity + GT * (1.0f - opacity + 1e-10f);
+            if (v >= 0) {
+                const float wi = opacity * Ti;
+                w.d_out[v] = make_float4(go * delta * ex, wi * g0, wi * g1, wi * g2);
+            }
+        }
+    }
+    if (rgb_out) {
+        rgb_out[3 * r] = o0;
+        rgb_out[3 * r + 1] = o1;
+        rgb_out[3 * r + 2] = o2;
+    }
+}
+
+// colour head backwards: dz8 = d rgb * 1.002 * sg (1 - sg); dW8 += dz8 (x) C3; db8 += dz8;
+// C3 <- (dz8 . W8) * LeakyReLU'(C3)   (the gradient at the colour MLP's last pre-activation, in place)
+__global__ void __launch_bounds__(256) k_train_color_head_bwd(TrainWs w, const float *__restrict__ w8)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwv = (gridDim.x * blockDim.x) >> 6;
+    const int S = w.cnt[1];
+    float dw[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}, db[3] = {0.f, 0.f, 0.f};
+    float wr[3][2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        wr[c][0] = w8[c * 128 + lane];
+        wr[c][1] = w8[c * 128 + 64 + lane];
+    }
+    for (int v = wv; v < S; v += nwv) {
+        const float4 sg = w.sg[v], go = w.d_out[v];
+        const float dz[3] = {go.y * 1.002f * sg.x * (1.0f - sg.x), go.z * 1.002f * sg.y * (1.0f - sg.y),
+                             go.w * 1.002f * sg.z * (1.0f - sg.z)};
+        float *c3 = w.C3 + (int64_t)v * LD_C;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float a = c3[64 * q + lane];
+            float g = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                dw[c][q] += dz[c] * a;
+                g += dz[c] * wr[c][q];
+            }
+            c3[64 * q + lane] = g * (a > 0.f ? 1.0f : 0.1f);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) db[c] += dz[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        unsafeAtomicAdd(w.dWp[8] + c * 128 + lane, dw[c][0]);
+        unsafeAtomicAdd(w.dWp[8] + c * 128 + 64 + lane, dw[c][1]);
+        if (lane == 0) unsafeAtomicAdd(w.dbp[8] + c, db[c]);
+    }
+}
+
+// density head + K-aggregation backwards (dAGG arrives in XC[:, 0:256], d sigma in d_out.x):
+//   dG2 = w (dAGG + d sigma * [z > 0] * w4);  G2 <- dG2 * LeakyReLU'(G2) (in place);  dw4, db4 accumulated
+__global__ void __launch_bounds__(256) k_train_head_agg_bwd(TrainWs w, int K, const float *__restrict__ w4)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwv = (gridDim.x * blockDim.x) >> 6;
+    const int S = w.cnt[1];
+    const float4 wq = *reinterpret_cast<const float4 *>(w4 + 4 * lane);
+    float4 dw = make_float4(0.f, 0.f, 0.f, 0.f);
+    float db = 0.f;
+    for (int v = wv; v < S; v += nwv) {
+        const float4 da = *reinterpret_cast<const float4 *>(w.XC + (int64_t)v * LD_XC + 4 * lane);
+        const float dsig = w.d_out[v].x;
+        for (int k = 0; k < K; ++k) {
+            const int row = v * K + k;
+            float4 *gp = reinterpret_cast<float4 *>(w.G2 + (int64_t)row * LD_H + 4 * lane);
+            const float4 gq = *gp;
+            const float wk = w.row_w[row];
+            const float coef = w.row_z[row] > 0.f ? wk * dsig : 0.f;
+            dw.x += coef * gq.x;
+            dw.y += coef * gq.y;
+            dw.z += coef * gq.z;
+            dw.w += coef * gq.w;
+            db += coef;
+            float4 o;
+            o.x = (wk * da.x + coef * wq.x) * (gq.x > 0.f ? 1.0f : 0.1f);
+            o.y = (wk * da.y + coef * wq.y) * (gq.y > 0.f ? 1.0f : 0.1f);
+            o.z = (wk * da.z + coef * wq.z) * (gq.z > 0.f ? 1.0f : 0.1f);
+            o.w = (wk * da.w + coef * wq.w) * (gq.w > 0.f ? 1.0f : 0.1f);
+            *gp = o;
+        }
+    }
+    unsafeAtomicAdd(w.dWp[4] + 4 * lane + 0, dw.x);
+    unsafeAtomicAdd(w.dWp[4] + 4 * lane + 1, dw.y);
+    unsafeAtomicAdd(w.dWp[4] + 4 * lane + 2, dw.z);
+    unsafeAtomicAdd(w.dWp[4] + 4 * lane + 3, dw.w);
+    if (lane == 0) unsafeAtomicAdd(w.dbp[4], db);
+}
+
+// column sums of a [rows, ld] matrix (bias gradients): out[c] += sum_r A[r][c]
+__global__ void __launch_bounds__(256) k_colsum(const float *__restrict__ A, int ld, int ncols,
+                                                const int *__restrict__ dev_rows, float *__restrict__ out)
+{
+    const int rows = *dev_rows;
+    const int c = threadIdx.x;  // ncols <= 256
+    if (c >= ncols) return;
+    float s = 0.f;
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) s += A[(int64_t)r * ld + c];
+    unsafeAtomicAdd(out + c, s);
+}
+
+// One wavefront per row: gradients of the point tensors, scattered with float atomics (index_select backward).
+//   dX0 [row, 0:224] is in G2, the taped encodings in X0, d[color | sdir - view | <sdir, view>] in H2[:, 256:263]
+__global__ void __launch_bounds__(256) k_train_scatter(TrainParams P, TrainWs w, float *__restrict__ d_emb,
+                                                       float *__restrict__ d_color, float *__restrict__ d_dir)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwv = (gridDim.x * blockDim.x) >> 6;
+    const int rows = w.cnt[0], K = P.K;
+    for (int row = wv; row < rows; row += nwv) {
+        const int pidx = w.row_pidx[row];
+        if (pidx < 0) continue;
+        const float *dx = w.G2 + (int64_t)row * LD_H;
+        const float *x0 = w.X0 + (int64_t)row * LD_X0;
+        const float *dh = w.H2 + (int64_t)row * LD_H2 + 256;
+        if (lane < 32) {
+            // d/de [e, sin(e 2^f), cos(e 2^f)] = [1, 2^f cos, -2^f sin]
+            float g = dx[lane];
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+                const int i = 32 + 2 * (3 * lane + f);
+                g += (float)(1 << f) * (x0[i + 1] * dx[i] - x0[i] * dx[i + 1]);
+            }
+            if (d_emb) unsafeAtomicAdd(d_emb + (int64_t)pidx * 32 + lane, g);
+        } else if (lane < 35) {
+            if (d_color) unsafeAtomicAdd(d_color + (int64_t)pidx * 3 + (lane - 32), dh[lane - 32]);
+        } else if (lane < 38 && d_dir) {
+            const int jd = lane - 35;
+            const int ray = P.smp_ray[P.vs_list[row / K]];
+            float vx, vy, vz;
+            rot_rows(P.Rw2c, P.dirs[3 * (int64_t)ray], P.dirs[3 * (int64_t)ray + 1], P.dirs[3 * (int64_t)ray + 2], vx, vy,
+                     vz);
+            // sdir = dir @ Rw2c^T; the head sees sdir - view and <sdir, view>
+            const float gd = dh[6];
+            const float gs0 = dh[3] + gd * vx, gs1 = dh[4] + gd * vy, gs2 = dh[5] + gd * vz;
+            // sdir[i] = sum_j dir[j] M[i][j]  =>  d dir[j] = sum_i d sdir[i] M[i][j]
+            const float gj = gs0 * P.Rw2c[jd] + gs1 * P.Rw2c[3 + jd] + gs2 * P.Rw2c[6 + jd];
+            unsafeAtomicAdd(d_dir + (int64_t)pidx * 3 + jd, gj);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+template <bool TA, bool TB, int EPI>
+static void gemm(hipStream_t st, const GemmArgs &g, int m_max, int nsplit = 1)
+{
+    const dim3 grid((unsigned)((m_max + TM - 1) / TM), (unsigned)((g.N + TN - 1) / TN), (unsigned)nsplit);
+    hipLaunchKernelGGL((k_gemm<TA, TB, EPI>), grid, dim3(256), 0, st, g);
+}
+
+// C[rows, N] = leaky(A[rows, K] . W[N, K]^T + b)
+static void gemm_forward(hipStream_t st, const float *A, int lda, const float *W, int ldw, const float *b, float *C,
+                         int ldc, int N, int K, const int *dev_rows, int64_t rows_max)
+{
+    GemmArgs g{};
+    g.A = A; g.B = W; g.C = C; g.lda = lda; g.ldb = ldw; g.ldc = ldc; g.M = 0; g.N = N; g.K = K;
+    g.dev_rows = dev_rows; g.bias = b;
+    gemm<false, true, EPI_BIAS_LEAKY>(st, g, (int)rows_max);
+}
+
+// C[rows, N] = (dZ[rows, K] . W[K, N]) * leaky'(C) for columns < mask_cols (in place over the taped activation)
+static void gemm_data(hipStream_t st, const float *dZ, int lda, const float *W, int ldw, float *C, int ldc, int N,
+                      int K, int mask_cols, const int *dev_rows, int64_t rows_max)
+{
+    GemmArgs g{};
+    g.A = dZ; g.B = W; g.C = C; g.lda = lda; g.ldb = ldw; g.ldc = ldc; g.M = 0; g.N = N; g.K = K;
+    g.dev_rows = dev_rows; g.mask = C; g.mask_cols = mask_cols;
+    if (mask_cols > 0)
+        gemm<false, false, EPI_MASK>(st, g, (int)rows_max);
+    else
+        gemm<false, false, EPI_STORE>(st, g, (int)rows_max);
+}
+
+// dW[M, N] += dZ[rows, M]^T . X[rows, N]
+static void gemm_weight(hipStream_t st, const float *dZ, int lda, const float *X, int ldx, float *dW, int ldw, int M,
+                        int N, const int *dev_rows, int64_t rows_max)
+{
+    GemmArgs g{};
+    g.A = dZ; g.B = X; g.C = dW; g.lda = lda; g.ldb = ldx; g.ldc = ldw; g.M = M; g.N = N; g.K = 0;
+    g.dev_rows = dev_rows;
+    const int tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
+    int nsplit = (int)std::min<int64_t>(std::max<int64_t>(1, 768 / tiles), (rows_max + 4 * TK - 1) / (4 * TK));
+    nsplit = std::max(nsplit, 1);
+    gemm<true, false, EPI_ATOMIC>(st, g, M, nsplit);
+}
+
+}  // namespace pnr
+
+using namespace pnr;
+
+extern "C" size_t pnr_backward_workspace_bytes(int64_t cap_samples, int32_t K)
+{
+    if (cap_samples < 1) cap_samples = 1;
+    if (K < 1) K = 1;
+    return carve_train_ws(nullptr, cap_samples, K).total;
+}
+
+extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t *weights, const float *const d_w[9],
+                                   const float *const d_b[9], const float *d_dirs, int64_t R, const pnr_camera_t *cams,
+                                   int32_t n_cams, const int32_t *d_ray_cam, int64_t rays_per_cam,
+                                   const pnr_render_opts_t *opts, const float *d_grad_rgb, void *d_render_workspace,
+                                   size_t render_workspace_bytes, int64_t cap_samples, void *d_train_workspace,
+                                   size_t train_workspace_bytes, const pnr_grads_t *grads, float *d_rgb_recomputed,
+                                   void *stream_)
+{
+    const char *who = "pnr_render_backward";
+    hipStream_t st = (hipStream_t)stream_;
+    PNR_REQUIRE(scene && weights && d_w && d_b && d_dirs && cams && opts && d_grad_rgb && d_render_workspace &&
+                    d_train_workspace && grads,
+                "%s: null argument", who);
+    for (int i = 0; i < 9; ++i) PNR_REQUIRE(d_w[i] && d_b[i], "%s: null weight pointer %d", who, i);
+    if (!scene->built || !scene->packed) {
+        set_error("%s: scene not built / points not packed", who);
+        return PNR_ERR_STATE;
+    }
+    PNR_REQUIRE(R >= 1 && R < (int64_t)0x7FFFFFF0, "%s: R=%lld out of range", who, (long long)R);
+    PNR_REQUIRE(n_cams >= 1 && n_cams <= PNR_MAX_CAMS, "%s: n_cams=%d not in [1,%d]", who, n_cams, PNR_MAX_CAMS);
+    PNR_REQUIRE(d_ray_cam != nullptr || (rays_per_cam >= 1 && rays_per_cam * n_cams >= R),
+                "%s: rays_per_cam=%lld does not cover R=%lld rays with %d cameras", who, (long long)rays_per_cam,
+                (long long)R, n_cams);
+    PNR_REQUIRE(opts->K >= 1 && opts->K <= PNR_MAX_K, "%s: K=%d not in [1,%d]", who, opts->K, PNR_MAX_K);
+    PNR_REQUIRE(opts->early_stop_eps == 0.f, "%s: early ray termination skips samples; train with early_stop_eps = 0",
+                who);
+    PNR_REQUIRE(cap_samples >= 1 && cap_samples * (int64_t)opts->K < (int64_t)0x7FFFFF00 / 8,
+                "%s: cap_samples=%lld out of range", who, (long long)cap_samples);
+    const size_t need_r = pnr_render_workspace_bytes_for(scene, opts, R, cap_samples);
+    if (render_workspace_bytes < need_r) {
+        set_error("%s: render workspace of %zu bytes < %zu: pass the workspace of the preceding pnr_render call", who,
+                  render_workspace_bytes, need_r);
+        return PNR_ERR_WORKSPACE;
+    }
+    const size_t need_t = pnr_backward_workspace_bytes(cap_samples, opts->K);
+    if (train_workspace_bytes < need_t) {
+        set_error("%s: training workspace of %zu bytes < %zu required (pnr_backward_workspace_bytes)", who,
+                  train_workspace_bytes, need_t);
+        return PNR_ERR_WORKSPACE;
+    }
+    const int K = opts->K;
+    RenderWs ws = carve_render_ws(d_render_workspace, R, cap_samples, K, scene->N, scene->info[2]);
+    TrainWs tw = carve_train_ws(d_train_workspace, cap_samples, K);
+
+    CamRef cr{};
+    cr.cams = ws.cams;
+    cr.ray_cam = d_ray_cam;
+    cr.rays_per_cam = d_ray_cam ? 1 : rays_per_cam;
+    cr.tmid = nullptr;
+    cr.D = opts->D;
+    cr.n_cams = n_cams;
+    cr.jitter = opts->jitter;
+    cr.seed = opts->seed;
+    {
+        CamSet set{};
+        for (int c = 0; c < n_cams; ++c) {
+            for (int i = 0; i < 3; ++i) set.c[c].o[i] = cams[c].campos[i];
+            for (int i = 0; i < 9; ++i) set.c[c].R[i] = cams[c].camrotc2w[i];
+        }
+        hipLaunchKernelGGL(k_train_set_cams, dim3(1), dim3(64), 0, st, set, n_cams, ws.cams);
+    }
+
+    TrainParams P{};
+    P.point_rows = reinterpret_cast<const float4 *>(scene->point_rows);
+    for (int i = 0; i < 9; ++i) P.Rw2c[i] = weights->Rw2c[i];
+    P.cr = cr;
+    P.dirs = d_dirs;
+    P.smp_loc = ws.smp_loc;
+    P.smp_ray = ws.smp_ray;
+    P.smp_pidx = ws.smp_pidx;
+    P.vs_list = ws.vs_list;
+    P.n_sel = ws.n_sel;
+    P.K = K;
+
+    const int64_t rows_max = cap_samples * K, smp_max = cap_samples;
+    const int *n_rows = tw.cnt, *n_smp = tw.cnt + 1;
+    const dim3 eg(2048), eb(256);
+
+    hipLaunchKernelGGL(k_train_counts, dim3(1), dim3(64), 0, st, ws.n_sel, (int)cap_samples, K, tw.cnt);
+    PNR_HIP_CHECK(hipMemsetAsync(tw.s2v, 0xFF, (size_t)cap_samples * 4, st));
+    PNR_HIP_CHECK(hipMemsetAsync(tw.dw_begin, 0, tw.dw_floats * 4, st));
+    PNR_HIP_CHECK(hipMemsetAsync(tw.d_out, 0, (size_t)cap_samples * 16, st));
+    hipLaunchKernelGGL(k_train_s2v, dim3(256), eb, 0, st, ws.vs_list, tw.cnt, tw.s2v);
+    for (int i = 0; i < 9; ++i)
+        hipLaunchKernelGGL(k_pad_weights, dim3(64), eb, 0, st, d_w[i], W_OUT[i], W_IN[i], W_LD[i], tw.Wp[i]);
+
+    // ---- forward with tape -----------------------------------------------------------------------
+    hipLaunchKernelGGL(k_train_rows, eg, eb, 0, st, P, tw);
+    gemm_forward(st, tw.X0, LD_X0, tw.Wp[0], 288, d_b[0], tw.H1, LD_H, 256, 288, n_rows, rows_max);
+    gemm_forward(st, tw.H1, LD_H, tw.Wp[1], 256, d_b[1], tw.H2, LD_H2, 256, 256, n_rows, rows_max);
+    gemm_forward(st, tw.H2, LD_H2, tw.Wp[2], 264, d_b[2], tw.G1, LD_H, 256, 264, n_rows, rows_max);
+    gemm_forward(st, tw.G1, LD_H, tw.Wp[3], 256, d_b[3], tw.G2, LD_H, 256, 256, n_rows, rows_max);
+    hipLaunchKernelGGL(k_train_head_agg, eg, eb, 0, st, P, tw, d_w[4], d_b[4]);
+    gemm_forward(st, tw.XC, LD_XC, tw.Wp[5], 288, d_b[5], tw.C1, LD_C, 128, 288, n_smp, smp_max);
+    gemm_forward(st, tw.C1, LD_C, tw.Wp[6], 128, d_b[6], tw.C2, LD_C, 128, 128, n_smp, smp_max);
+    gemm_forward(st, tw.C2, LD_C, tw.Wp[7], 128, d_b[7], tw.C3, LD_C, 128, 128, n_smp, smp_max);
+    hipLaunchKernelGGL(k_train_color_head, eg, eb, 0, st, tw, d_w[8], d_b[8]);
+
+    // ---- backward --------------------------------------------------------------------------------
+    hipLaunchKernelGGL(k_train_composite_bwd, dim3((unsigned)((R + 255) / 256)), eb, 0, st, cr, *opts, R, ws.ray_cnt,
+                       ws.ray_off, ws.ray_flag, ws.smp_loc, ws.n_sel, tw, d_grad_rgb, d_rgb_recomputed);
+    // colour MLP
+    hipLaunchKernelGGL(k_train_color_head_bwd, dim3(256), eb, 0, st, tw, d_w[8]);  // C3 <- dZ7
+    gemm_weight(st, tw.C3, LD_C, tw.C2, LD_C, tw.dWp[7], 128, 128, 128, n_smp, smp_max);
+    hipLaunchKernelGGL(k_colsum, dim3(512), eb, 0, st, tw.C3, LD_C, 128, n_smp, tw.dbp[7]);
+    gemm_data(st, tw.C3, LD_C, tw.Wp[7], 128, tw.C2, LD_C, 128, 128, 128, n_smp, smp_max);  // C2 <- dZ6
+    gemm_weight(st, tw.C2, LD_C, tw.C1, LD_C, tw.dWp[6], 128, 128, 128, n_smp, smp_max);
+    hipLaunchKernelGGL(k_colsum, dim3(512), eb, 0, st, tw.C2, LD_C, 128, n_smp, tw.dbp[6]);
+    gemm_data(st, tw.C2, LD_C, tw.Wp[6], 128, tw.C1, LD_C, 128, 128, 128, n_smp, smp_max);  // C1 <- dZ5
+    gemm_weight(st, tw.C1, LD_C, tw.XC, LD_XC, tw.dWp[5], 288, 128, 288, n_smp, smp_max);
+    hipLaunchKernelGGL(k_colsum, dim3(512), eb, 0, st, tw.C1, LD_C, 128, n_smp, tw.dbp[5]);
+    gemm_data(st, tw.C1, LD_C, tw.Wp[5], 288, tw.XC, LD_XC, 256, 128, 0, n_smp, smp_max);   // XC[:, :256] <- dAGG
+    // density head + aggregation
+    hipLaunchKernelGGL(k_train_head_agg_bwd, dim3(512), eb, 0, st, tw, K, d_w[4]);          // G2 <- dZ4
+    // mlp_head
+    gemm_weight(st, tw.G2, LD_H, tw.G1, LD_H, tw.dWp[3], 256, 256, 256, n_rows, rows_max);
+    hipLaunchKernelGGL(k_colsum, dim3(1024), eb, 0, st, tw.G2, LD_H, 256, n_rows, tw.dbp[3]);
+    gemm_data(st, tw.G2, LD_H, tw.Wp[3], 256, tw.G1, LD_H, 256, 256, 256, n_rows, rows_max);   // G1 <- dZ3
+    gemm_weight(st, tw.G1, LD_H, tw.H2, LD_H2, tw.dWp[2], 264, 256, 264, n_rows, rows_max);
+    hipLaunchKernelGGL(k_colsum, dim3(1024), eb, 0, st, tw.G1, LD_H, 256, n_rows, tw.dbp[2]);
+    gemm_data(st, tw.G1, LD_H, tw.Wp[2], 264, tw.H2, LD_H2, 264, 256, 256, n_rows, rows_max);  // H2 <- [dZ2 | d extras]
+    // mlp_base
+    gemm_weight(st, tw.H2, LD_H2, tw.H1, LD_H, tw.dWp[1], 256, 256, 256, n_rows, rows_max);
+    hipLaunchKernelGGL(k_colsum, dim3(1024), eb, 0, st, tw.H2, LD_H2, 256, n_rows, tw.dbp[1]);
+    gemm_data(st, tw.H2, LD_H2, tw.Wp[1], 256, tw.H1, LD_H, 256, 256, 256, n_rows, rows_max);  // H1 <- dZ1
+    gemm_weight(st, tw.H1, LD_H, tw.X0, LD_X0, tw.dWp[0], 288, 256, 288, n_rows, rows_max);
+    hipLaunchKernelGGL(k_colsum, dim3(1024), eb, 0, st, tw.H1, LD_H, 256, n_rows, tw.dbp[0]);
+    gemm_data(st, tw.H1, LD_H, tw.Wp[0], 288, tw.G2, LD_H, 224, 256, 0, n_rows, rows_max);     // G2 <- dX0[:, :224]
+    // point tensors
+    hipLaunchKernelGGL(k_train_scatter, eg, eb, 0, st, P, tw, grads->d_embedding, grads->d_color, grads->d_dir);
+    // weight gradients out of the padded buffers
+    for (int i = 0; i < 9; ++i) {
+        if (grads->d_w[i])
+            hipLaunchKernelGGL(k_unpad_add, dim3(64), eb, 0, st, tw.dWp[i], W_OUT[i], W_IN[i], W_LD[i], grads->d_w[i]);
+        if (grads->d_b[i])
+            hipLaunchKernelGGL(k_unpad_add, dim3(1), eb, 0, st, tw.dbp[i], 1, W_OUT[i], W_OUT[i], grads->d_b[i]);
+    }
+    PNR_HIP_CHECK(hipGetLastError());
+    return PNR_OK;
+}

@@ -309,6 +309,7 @@ class RendererHIP:
             }
         while True:
             ws = self._workspace(R, cap, dev)
+            self._last = (d, R, arr, n, rc, int(rays_per_cam), cap)
             with torch.cuda.device(dev):
                 _lib.check(self.lib.pnr_render_views(
                     self.scene.handle, self.weights.handle, _ptr(d), R, arr, n, _ptr(rc), int(rays_per_cam), _ptr(tm),
@@ -322,6 +323,50 @@ class RendererHIP:
                 return out
             # overflow: grow to what the frame actually needs (+12 %) and render again
             cap = int(cnt[2] * 1.125) + 1024
+
+    def backward(self, grad_rgb: torch.Tensor, state: Dict[str, torch.Tensor], num_points: int,
+                 point_grads: bool = True, weight_grads: bool = True) -> Dict[str, torch.Tensor]:
+        """Gradients of the LAST render / render_views call (pnr_render_backward): d loss / d {embedding [N,32],
+        color [N,3], dir [N,3], '<module>.weight', '<module>.bias'} for grad_rgb = d loss / d rgb [R,3].  `state` holds
+        the raw MLP tensors the weights were packed from.  What torch autograd derives for studio_model.py:263-399;
+        the MLP forward is recomputed in fp32 ('rgb' in the result is that recomputed image)."""
+        if getattr(self, "_last", None) is None:
+            raise RuntimeError("RendererHIP.backward: no render call to differentiate")
+        d, R, arr, n, rc, rays_per_cam, cap = self._last
+        dev = d.device
+        g = _f32c(grad_rgb.reshape(R, 3), dev)
+        ws_t, bs_t = [], []
+        for name, shape in zip(MLP_TENSOR_ORDER, MLP_SHAPES):
+            ws_t.append(_f32c(state[name + ".weight"], dev))
+            bs_t.append(_f32c(state[name + ".bias"], dev))
+        wp = (C.c_void_p * 9)(*[w.data_ptr() for w in ws_t])
+        bp = (C.c_void_p * 9)(*[b.data_ptr() for b in bs_t])
+        out: Dict[str, torch.Tensor] = {"rgb": torch.empty((R, 3), dtype=torch.float32, device=dev)}
+        grads = _lib.GradsC()
+        if point_grads:
+            out["embedding"] = torch.zeros((num_points, 32), dtype=torch.float32, device=dev)
+            out["color"] = torch.zeros((num_points, 3), dtype=torch.float32, device=dev)
+            out["dir"] = torch.zeros((num_points, 3), dtype=torch.float32, device=dev)
+            grads.d_embedding, grads.d_color, grads.d_dir = (out["embedding"].data_ptr(), out["color"].data_ptr(),
+                                                             out["dir"].data_ptr())
+        if weight_grads:
+            for i, (name, shape) in enumerate(zip(MLP_TENSOR_ORDER, MLP_SHAPES)):
+                out[name + ".weight"] = torch.zeros(shape, dtype=torch.float32, device=dev)
+                out[name + ".bias"] = torch.zeros((shape[0],), dtype=torch.float32, device=dev)
+                grads.d_w[i] = out[name + ".weight"].data_ptr()
+                grads.d_b[i] = out[name + ".bias"].data_ptr()
+        nbytes = self.lib.pnr_backward_workspace_bytes(cap, self.opts.K)
+        if getattr(self, "_tws", None) is None or self._tws.numel() < nbytes:
+            self._tws = None
+            self._tws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ws = self._ws
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.pnr_render_backward(
+                self.scene.handle, self.weights.handle, C.byref(wp), C.byref(bp), _ptr(d), R, arr, n, _ptr(rc),
+                rays_per_cam, C.byref(self.opts), _ptr(g), _ptr(ws), ws.numel(), cap, _ptr(self._tws),
+                self._tws.numel(), C.byref(grads), _ptr(out["rgb"]), _stream_ptr(dev)), "pnr_render_backward")
+            torch.cuda.current_stream(dev).synchronize()  # the converted inputs above may be temporaries
+        return out
 
     def taps(self, R: int):
         """Views into the last frame's workspace (tests): per selected sample loc+t, ray, pidx, decoded."""

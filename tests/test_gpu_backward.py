@@ -1,0 +1,113 @@
+"""GPU parity of pnr_render_backward (the gradients of a render) against torch
+autograd through the CPU oracle of NeuralPoints.forward + PointNerf.get_outputs (studio_model.py:263-399,
+studio_utils.py:190-209) -- the very computation `ns-train pointnerf-original` differentiates.
+
+Tolerance: every gradient tensor within 2e-3 of its own largest magnitude (fp32 MFMA products summed in a
+different order than torch's CPU GEMMs, float atomics), the recomputed image within 1e-4 abs."""
+import pytest
+import torch
+
+from helpers import build_hip, camera_rays, oracle_cfg, small_scene
+from pointnerf2studio_amd import synthetic
+from pointnerf2studio_amd.renderer import MLP_TENSOR_ORDER, RendererHIP
+
+pytestmark = pytest.mark.gpu
+
+GRAD_REL_TOL = 2e-3
+
+
+def _oracle_grads(oracle, pts, w, cfg, campos, camrot, dirs, G, training, jitter=0.0, u=None):
+    pts_g = dict(pts)
+    for k in ("embedding", "color", "dir"):
+        pts_g[k] = pts[k].clone().requires_grad_(True)
+    w_g = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    ref = oracle.render(pts_g, w_g, cfg, campos[None].expand(dirs.shape[0], 3), dirs, 2.0, 6.0, camrot,
+                        jitter=jitter, u=u, training=training)
+    loss = (ref["coarse_raycolor"] * G).sum()
+    loss.backward()
+    grads = {k: pts_g[k].grad.reshape(pts_g[k].shape[-2], -1) for k in ("embedding", "color", "dir")}
+    for k, v in w_g.items():
+        grads[k] = v.grad if v.grad is not None else torch.zeros_like(v)
+    return ref, grads
+
+
+def _compare(name, got, want):
+    scale = want.abs().max().item()
+    err = (got - want).abs().max().item()
+    assert scale > 0, f"{name}: the oracle gradient is identically zero (test scene too empty)"
+    assert err <= GRAD_REL_TOL * scale, f"{name}: max abs err {err:.3e} vs scale {scale:.3e} ({err / scale:.2e} rel)"
+    return err / scale
+
+
+@pytest.mark.parametrize("N,SR,K,P,H,W,az,training", [
+    (60000, 80, 8, 12, 24, 24, 35.0, True),      # training composite (no clamp)
+    (50000, 32, 8, 12, 32, 32, 200.0, False),    # eval clamp: gradient passes only inside [0, 1]
+    (200000, 24, 12, 26, 20, 20, 300.0, True),   # K = 12
+])
+def test_backward_matches_oracle_autograd(oracle, gpu_device, N, SR, K, P, H, W, az, training):
+    pts = small_scene(N)
+    cfg = oracle_cfg(oracle, SR=SR, K=K, P=P)
+    w = synthetic.make_weights(0, sigma_scale=300.0, bias_scale=0.1)
+    campos, camrot, dirs = camera_rays(H, W, az=az)
+    torch.manual_seed(5)
+    G = torch.randn(dirs.shape[0], 3)
+    ref, want = _oracle_grads(oracle, pts, w, cfg, campos, camrot, dirs, G, training)
+    assert ref["acc"].max().item() > 0.5
+
+    scene, wh, hyp, info = build_hip(pts, cfg, gpu_device, weights=w)
+    rnd = RendererHIP(scene, wh, SR=SR, K=K, D=cfg.z_depth_dim, radius_limit=float(oracle.radius_limit(cfg)),
+                      vsize_z=cfg.vsize[2], precision="fp32", eval_clamp=not training)
+    out = rnd.render(dirs.to(gpu_device), campos, camrot, 2.0, 6.0)
+    assert out["counters"]["overflow"] == 0
+    got = rnd.backward(G.to(gpu_device), w, pts["xyz"].shape[0])
+
+    err = (got["rgb"].cpu() - ref["coarse_raycolor"]).abs().max().item()
+    assert err <= 1e-4, f"recomputed image differs from the oracle by {err:.3e}"
+    err2 = (got["rgb"] - out["rgb"]).abs().max().item()
+    assert err2 <= 1e-4, f"recomputed image differs from pnr_render by {err2:.3e}"
+    rel = {}
+    for k in ("embedding", "color", "dir"):
+        rel[k] = _compare(k, got[k].cpu(), want[k])
+    for name in MLP_TENSOR_ORDER:
+        for suf in (".weight", ".bias"):
+            rel[name + suf] = _compare(name + suf, got[name + suf].cpu(), want[name + suf])
+    print("relative gradient errors:", {k: f"{v:.1e}" for k, v in rel.items()})
+
+
+def test_backward_after_bf16x3_render_and_accumulation(oracle, gpu_device):
+    """The render may run in the default bf16x3 mode (the backward recomputes in fp32 from its sample lists), and a
+    second backward call with other cotangents returns the gradients of THAT call (buffers are fresh zeros)."""
+    N, SR, K, P = 60000, 80, 8, 12
+    pts = small_scene(N)
+    cfg = oracle_cfg(oracle, SR=SR, K=K, P=P)
+    w = synthetic.make_weights(0, sigma_scale=300.0, bias_scale=0.1)
+    campos, camrot, dirs = camera_rays(24, 24, az=35.0)
+    torch.manual_seed(6)
+    G = torch.randn(dirs.shape[0], 3)
+    ref, want = _oracle_grads(oracle, pts, w, cfg, campos, camrot, dirs, G, True)
+    scene, wh, hyp, info = build_hip(pts, cfg, gpu_device, weights=w)
+    rnd = RendererHIP(scene, wh, SR=SR, K=K, D=cfg.z_depth_dim, radius_limit=float(oracle.radius_limit(cfg)),
+                      vsize_z=cfg.vsize[2], precision="bf16x3", eval_clamp=False)
+    rnd.render(dirs.to(gpu_device), campos, camrot, 2.0, 6.0)
+    first = rnd.backward(torch.ones_like(G).to(gpu_device), w, N)
+    got = rnd.backward(G.to(gpu_device), w, N)
+    assert (first["embedding"] - got["embedding"]).abs().max().item() > 0
+    for k in ("embedding", "color", "dir"):
+        _compare(k, got[k].cpu(), want[k])
+    for name in MLP_TENSOR_ORDER:
+        _compare(name + ".weight", got[name + ".weight"].cpu(), want[name + ".weight"])
+
+
+def test_backward_rejects_bad_arguments(oracle, gpu_device):
+    pts = small_scene(20000)
+    cfg = oracle_cfg(oracle, SR=16, K=8, P=12)
+    w = synthetic.make_weights(0, sigma_scale=300.0, bias_scale=0.1)
+    campos, camrot, dirs = camera_rays(8, 8)
+    scene, wh, hyp, info = build_hip(pts, cfg, gpu_device, weights=w)
+    rnd = RendererHIP(scene, wh, SR=16, K=8, D=cfg.z_depth_dim, radius_limit=float(oracle.radius_limit(cfg)),
+                      vsize_z=cfg.vsize[2], early_stop_eps=1e-4)
+    with pytest.raises(RuntimeError, match="no render call"):
+        rnd.backward(torch.zeros(64, 3, device=gpu_device), w, 20000)
+    rnd.render(dirs.to(gpu_device), campos, camrot, 2.0, 6.0)
+    with pytest.raises(RuntimeError, match="early_stop_eps"):
+        rnd.backward(torch.zeros(64, 3, device=gpu_device), w, 20000)
