@@ -94,11 +94,42 @@ class PointNerfConfig(ModelConfig):
     # additions of this build (not in the reference): arithmetic of the fused HIP MLP, see include/pnr.h
     hip_mlp_mode: str = "bf16x3"   # "bf16x3" (3 bf16 MFMA products per fp32 product) or "fp32" (exact)
     hip_early_stop_eps: float = 0.0  # eval only: > 0 stops shading a ray once its transmittance is below eps
+    hip_fused_training: bool = True  # training: fused HIP render + pnr_render_backward instead of torch autograd
 
     def __post_init__(self):
         if self.path_point_cloud is not None:
             if not Path(self.path_point_cloud).exists():
                 raise RuntimeError(f"PointCloud path {self.path_point_cloud} does not exist")
+
+
+class _FusedRenderFn(torch.autograd.Function):
+    """pnr_render forwards, pnr_render_backward backwards (include/pnr.h).  Inputs after `far`: points_embeding,
+    points_color, points_dir and the nine (weight, bias) pairs in MLP_TENSOR_ORDER."""
+
+    @staticmethod
+    def forward(ctx, rnd, dirs, pos, rot, near, far, emb, color, pdir, *mlp):
+        out = rnd.render(dirs, pos, rot, near, far)
+        rnd.last_counters = out["counters"]
+        ctx.rnd = rnd
+        ctx.shapes = (emb.shape, color.shape, pdir.shape)
+        ctx.state = {name + suf: mlp[2 * i + j] for i, name in enumerate(MLP_TENSOR_ORDER)
+                     for j, suf in enumerate((".weight", ".bias"))}
+        ctx.call = rnd.calls
+        ctx.mark_non_differentiable(out["ray_mask"])
+        return out["rgb"], out["ray_mask"]
+
+    @staticmethod
+    def backward(ctx, g_rgb, _g_mask):
+        rnd = ctx.rnd
+        if rnd.calls != ctx.call:
+            raise RuntimeError("fused training: the renderer ran another render before backward(); its workspace "
+                               "no longer holds this step's sample lists")
+        es, cs, ds = ctx.shapes
+        g = rnd.backward(g_rgb, ctx.state, es[-2])
+        grads = [g["embedding"].view(es), g["color"].view(cs), g["dir"].view(ds)]
+        for name in MLP_TENSOR_ORDER:
+            grads += [g[name + ".weight"], g[name + ".bias"]]
+        return (None, None, None, None, None, None, *grads)
 
 
 class PointNerf(Model):
@@ -113,6 +144,7 @@ class PointNerf(Model):
         self.cameras = cameras
         self._device = "cuda"
         self._renderer: Optional[RendererHIP] = None
+        self._renderer_train: Optional[RendererHIP] = None
         self._weights: Optional[WeightsHIP] = None
         self._weights_key = None
         self._render_calls = 0
@@ -180,7 +212,7 @@ class PointNerf(Model):
             sd[name + ".weight"], sd[name + ".bias"] = mod.weight, mod.bias
         return sd
 
-    def _fused_renderer(self) -> RendererHIP:
+    def _fused_renderer(self, train: bool = False) -> RendererHIP:
         scene = self.neural_points.fused_scene()
         sd = self._mlp_state()
         key = tuple((t.data_ptr(), t._version) for t in sd.values()) + (self.neural_points.points_Rw2c._version,)
@@ -189,8 +221,18 @@ class PointNerf(Model):
                 self._weights = WeightsHIP()
             self._weights.pack(sd, self.neural_points.points_Rw2c.detach(), self.neural_points.points_xyz.device)
             self._weights_key = key
+        c = self.config
+        if train:
+            # the training renderer has its own workspace and never clamps (nerfstudio's RGBRenderer in training)
+            if self._renderer_train is None or self._renderer_train.scene is not scene:
+                self._renderer_train = RendererHIP(scene, self._weights, SR=c.SR, K=c.K, D=c.z_depth_dim,
+                                                   radius_limit=float(self.neural_points.radius_limit_np),
+                                                   vsize_z=c.vsize[2], eval_clamp=False,
+                                                   bg=self._background_color.tolist(),
+                                                   precision=getattr(c, "hip_mlp_mode", "bf16x3"))
+            self._renderer_train.mlp_state = sd
+            return self._renderer_train
         if self._renderer is None or self._renderer.scene is not scene:
-            c = self.config
             self._renderer = RendererHIP(scene, self._weights, SR=c.SR, K=c.K, D=c.z_depth_dim,
                                          radius_limit=float(self.neural_points.radius_limit_np),
                                          vsize_z=c.vsize[2], eval_clamp=True, bg=self._background_color.tolist(),
@@ -212,11 +254,45 @@ class PointNerf(Model):
         return {"coarse_raycolor": out["rgb"], "ray_mask": out["ray_mask"], "depth": out["depth"],
                 "accumulation": out["acc"]}
 
+    def _get_outputs_fused_train(self, ray_bundle):
+        """Training step on the fused path: pnr_render forwards (no clamp, the reference's 0.3 jitter with a fresh
+        seed per call), pnr_render_backward behind a torch.autograd.Function for d loss / d {points_embeding,
+        points_color, points_dir, MLP weights} -- what autograd derives for studio_model.py:263-399.
+        `conf_coefficient` (studio_model.py:288-292) is gathered here with torch ops so that its loss term reaches
+        points_conf: the reference's tensor is [1,R'',SR,K] with unfilled slots reading point 0
+        (studio_utils.py:193-199, clamp(pidx, 0)); the same multiset of values is returned flat, which is all the
+        loss (a mean) looks at."""
+        rot, pos = self.neural_points._camera(ray_bundle)
+        rnd = self._fused_renderer(train=True)
+        rnd.opts.jitter = float(self.neural_points.jitter)
+        rnd.opts.seed = self._render_calls & 0xFFFFFFFF
+        self._render_calls += 1
+        npts = self.neural_points
+        mlp = []
+        for name in MLP_TENSOR_ORDER:
+            mod = self.get_submodule(name)
+            mlp += [mod.weight, mod.bias]
+        rgb, ray_mask = _FusedRenderFn.apply(rnd, ray_bundle.directions.to(self._device), pos[0], rot[0],
+                                             ray_bundle.nears[0].item(), ray_bundle.fars[0].item(),
+                                             npts.points_embeding, npts.points_color, npts.points_dir, *mlp)
+        cnt = rnd.last_counters
+        R = ray_bundle.directions.reshape(-1, 3).shape[0]
+        pidx = rnd.taps(R)["smp_pidx"][:cnt["samples_selected"]].reshape(-1).long()
+        conf = npts.points_conf[0, :, 0]
+        cv = conf[pidx[pidx >= 0]]
+        n_slots = cnt["rays_kept"] * self.config.SR * self.config.K
+        conf_all = torch.cat([cv, conf[0:1].expand(max(n_slots - cv.numel(), 0))])
+        conf_coefficient = conf_all - (conf_all - torch.clamp(conf_all, min=0.0001, max=1)).detach()
+        return {"coarse_raycolor": rgb, "ray_mask": ray_mask, "conf_coefficient": conf_coefficient}
+
     def get_outputs(self, ray_bundle):
         if self.mlp_base is None:
             raise ValueError("populate_fields() must be called before get_outputs")
         if not self.training and not torch.is_grad_enabled() and self._fusable():
             return self._get_outputs_fused(ray_bundle)
+        if self.training and torch.is_grad_enabled() and self._fusable() and \
+                getattr(self.config, "hip_fused_training", True):
+            return self._get_outputs_fused_train(ray_bundle)
         return self._get_outputs_autograd(ray_bundle)
 
     # ---- the reference's op sequence (training) -----------------------------------------------------------

@@ -243,6 +243,8 @@ class RendererHIP:
         self._tmid = {}
         self._cam_cache = {}
         self.cap_samples = 0
+        self.calls = 0          # render calls so far (a backward must follow ITS render directly)
+        self._last = None
 
     def _workspace(self, R: int, cap: int, dev):
         key = (R, cap, self.opts.K)
@@ -310,6 +312,7 @@ class RendererHIP:
         while True:
             ws = self._workspace(R, cap, dev)
             self._last = (d, R, arr, n, rc, int(rays_per_cam), cap)
+            self.calls += 1
             with torch.cuda.device(dev):
                 _lib.check(self.lib.pnr_render_views(
                     self.scene.handle, self.weights.handle, _ptr(d), R, arr, n, _ptr(rc), int(rays_per_cam), _ptr(tm),

@@ -83,6 +83,39 @@ def test_training_get_outputs_matches_oracle_and_backpropagates(oracle, gpu_devi
     assert torch.isfinite(out2["coarse_raycolor"]).all()
 
 
+def test_fused_training_step_equals_autograd_path(oracle, gpu_device):
+    """One training step through the fused path (pnr_render + pnr_render_backward behind an autograd.Function)
+    against the reference's op sequence under torch autograd (hip_fused_training = False): same loss, same
+    gradients for every parameter group, points_conf included (it is reached through the loss only)."""
+    model, bundle, ref = _model_and_bundle(oracle, gpu_device, N=40000, H=24, W=24)
+    model.train()
+    model.neural_points.jitter = 0.0
+    model.config.hip_mlp_mode = "fp32"
+    torch.manual_seed(3)
+    image = torch.rand(bundle.directions.shape[0], 3, device=gpu_device)
+
+    def step(fused):
+        model.config.hip_fused_training = fused
+        model.zero_grad(set_to_none=True)
+        out = model(bundle)
+        loss = sum(model.get_loss_dict(out, {"image": image}).values())
+        loss.backward()
+        return loss.item(), out, {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    l_ref, out_ref, g_ref = step(False)
+    l_fus, out_fus, g_fus = step(True)
+    assert model._renderer_train is not None and model._renderer_train.calls >= 1
+    assert torch.equal(out_ref["ray_mask"], out_fus["ray_mask"])
+    assert (out_ref["coarse_raycolor"] - out_fus["coarse_raycolor"]).abs().max().item() <= 1e-4
+    assert abs(l_ref - l_fus) <= 1e-5 * max(1.0, abs(l_ref))
+    assert set(g_ref) == set(g_fus)
+    for n in g_ref:
+        scale = g_ref[n].abs().max().item()
+        err = (g_ref[n] - g_fus[n]).abs().max().item()
+        assert err <= 2e-3 * scale + 1e-12, f"{n}: {err:.3e} vs scale {scale:.3e}"
+    assert "neural_points.points_conf" in g_fus and g_fus["neural_points.points_conf"].abs().sum().item() > 0
+
+
 def test_dropin_query_op_signature(oracle, gpu_device):
     """The 17-argument call of studio_utils.py:172-188, verbatim."""
     from pointnerf2studio_amd.neural_points import QueryWorldcoordsHIP
