@@ -325,6 +325,44 @@ def main():
                  "note": "rays stop being shaded once their transmittance is below eps (chunks of 3, 3, 6, 12, rest "
                          "samples); the reference shades every sample, so this is reported beside `value`, never as it"}
 
+    # the training step of SURVEY.md section 8f rank 1, for the record (NOT part of `value`): pnr_render without clamp
+    # at the reference's 0.3 jitter + pnr_render_backward on random pixels of view 0 -- 4096 rays is the batch
+    # `ns-train pointnerf-original` draws (studio_config.py:20-21), 65536 shows the throughput regime
+    train = None
+    if world == 1 and not emulate and not args.no_other_mode:
+        train = []
+        full = synthetic.make_rays(H, W, cams[0][0], cams[0][1]).to(dev)
+        gen = torch.Generator().manual_seed(11)
+        for n_rays in (4096, 65536):
+            pick = torch.randperm(full.shape[0], generator=gen)[:n_rays].to(dev)
+            dirs_t = full.index_select(0, pick).contiguous()
+            rnd_t = RendererHIP(scene, wh, SR=SR, K=K, D=400, radius_limit=4 * max(VSIZE[0], VSIZE[1]),
+                                vsize_z=VSIZE[2], precision=args.precision, eval_clamp=False, jitter=0.3, seed=1)
+            g_rgb = torch.randn(n_rays, 3, generator=gen).to(dev)
+            fw, bw = [], []
+            for it in range(5):
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                ev[0].record()
+                o = rnd_t.render(dirs_t, cams[0][0], cams[0][1], 2.0, 6.0)
+                ev[1].record()
+                rnd_t.backward(g_rgb, weights, cfgd["N"])
+                ev[2].record()
+                torch.cuda.synchronize()
+                if it >= 2:
+                    fw.append(ev[0].elapsed_time(ev[1]))
+                    bw.append(ev[1].elapsed_time(ev[2]))
+            c = o["counters"]
+            bwd_flops = 3 * (c["pairs_valid"] * FLOPS_PER_PAIR + c["samples_valid"] * FLOPS_PER_SAMPLE)
+            f_ms, b_ms = sorted(fw)[1], sorted(bw)[1]
+            train.append({"rays": n_rays, "forward_ms": f_ms, "backward_ms": b_ms,
+                          "rays_per_sec": n_rays / ((f_ms + b_ms) * 1e-3), "pairs_valid": c["pairs_valid"],
+                          "samples_valid": c["samples_valid"],
+                          "backward_tflops": bwd_flops / (b_ms * 1e-3) / 1e12,
+                          "note": "backward = fp32 recompute of the MLPs with a row-major tape + data and weight "
+                                  "gradients (3 x the forward FLOPs) on v_mfma_f32_32x32x2_f32 GEMMs, peak 157.3; time "
+                                  "includes zero-filling the dense [N,32] gradient"})
+            del rnd_t
+
     if rank == 0 or emulate:
         samples = acc_cnt[3]
         result = {
@@ -352,6 +390,8 @@ def main():
             result["other_mode"] = alt
         if early is not None:
             result["with_early_ray_termination"] = early
+        if train is not None:
+            result["training_step"] = train
         if world == 1 and not emulate and args.cpu_rays_side > 0:
             cb, ref, dirs, campos, camrot = cpu_baseline(points, weights, cfgd, args.cpu_rays_side, azimuths[0])
             # parity on the very same rays: HIP render vs the oracle that was just timed

@@ -270,20 +270,32 @@ __global__ void k_train_s2v(const int *__restrict__ vs_list, const int *__restri
     for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < S; v += gridDim.x * blockDim.x) s2v[vs_list[v]] = v;
 }
 
-// dst[out, ld] = src[out, in] zero-padded
-__global__ void k_pad_weights(const float *__restrict__ src, int n_out, int n_in, int ld, float *__restrict__ dst)
+// the nine Linear layers in one launch (blockIdx.y = layer): dst[out, ld] = src[out, in] zero-padded
+struct NineMats {
+    const float *src[9];
+    float *dst[9];
+    int n_out[9], n_in[9], ld[9];
+};
+__global__ void k_pad_weights(NineMats m)
 {
-    const int n = n_out * ld;
+    const int l = blockIdx.y;
+    const int ld = m.ld[l], n_in = m.n_in[l], n = m.n_out[l] * ld;
+    const float *__restrict__ src = m.src[l];
+    float *__restrict__ dst = m.dst[l];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int o = i / ld, c = i - o * ld;
         dst[i] = c < n_in ? src[(int64_t)o * n_in + c] : 0.f;
     }
 }
 
-// dst[out, in] += src[out, ld]
-__global__ void k_unpad_add(const float *__restrict__ src, int n_out, int n_in, int ld, float *__restrict__ dst)
+// dst[out, in] += src[out, ld]  (dst null: skipped)
+__global__ void k_unpad_add(NineMats m)
 {
-    const int n = n_out * n_in;
+    const int l = blockIdx.y;
+    if (!m.dst[l]) return;
+    const int ld = m.ld[l], n_in = m.n_in[l], n = m.n_out[l] * n_in;
+    const float *__restrict__ src = m.src[l];
+    float *__restrict__ dst = m.dst[l];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int o = i / n_in, c = i - o * n_in;
         dst[i] += src[(int64_t)o * ld + c];
@@ -844,8 +856,17 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
     PNR_HIP_CHECK(hipMemsetAsync(tw.dw_begin, 0, tw.dw_floats * 4, st));
     PNR_HIP_CHECK(hipMemsetAsync(tw.d_out, 0, (size_t)cap_samples * 16, st));
     hipLaunchKernelGGL(k_train_s2v, dim3(256), eb, 0, st, ws.vs_list, tw.cnt, tw.s2v);
-    for (int i = 0; i < 9; ++i)
-        hipLaunchKernelGGL(k_pad_weights, dim3(64), eb, 0, st, d_w[i], W_OUT[i], W_IN[i], W_LD[i], tw.Wp[i]);
+    {
+        NineMats m{};
+        for (int i = 0; i < 9; ++i) {
+            m.src[i] = d_w[i];
+            m.dst[i] = tw.Wp[i];
+            m.n_out[i] = W_OUT[i];
+            m.n_in[i] = W_IN[i];
+            m.ld[i] = W_LD[i];
+        }
+        hipLaunchKernelGGL(k_pad_weights, dim3(32, 9), eb, 0, st, m);
+    }
 
     // ---- forward with tape -----------------------------------------------------------------------
     hipLaunchKernelGGL(k_train_rows, eg, eb, 0, st, P, tw);
@@ -874,7 +895,7 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
     hipLaunchKernelGGL(k_colsum, dim3(512), eb, 0, st, tw.C1, LD_C, 128, n_smp, tw.dbp[5]);
     gemm_data(st, tw.C1, LD_C, tw.Wp[5], 288, tw.XC, LD_XC, 256, 128, 0, n_smp, smp_max);   // XC[:, :256] <- dAGG
     // density head + aggregation
-    hipLaunchKernelGGL(k_train_head_agg_bwd, dim3(512), eb, 0, st, tw, K, d_w[4]);          // G2 <- dZ4
+    hipLaunchKernelGGL(k_train_head_agg_bwd, dim3(2048), eb, 0, st, tw, K, d_w[4]);          // G2 <- dZ4
     // mlp_head
     gemm_weight(st, tw.G2, LD_H, tw.G1, LD_H, tw.dWp[3], 256, 256, 256, n_rows, rows_max);
     hipLaunchKernelGGL(k_colsum, dim3(1024), eb, 0, st, tw.G2, LD_H, 256, n_rows, tw.dbp[3]);
@@ -892,11 +913,22 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
     // point tensors
     hipLaunchKernelGGL(k_train_scatter, eg, eb, 0, st, P, tw, grads->d_embedding, grads->d_color, grads->d_dir);
     // weight gradients out of the padded buffers
-    for (int i = 0; i < 9; ++i) {
-        if (grads->d_w[i])
-            hipLaunchKernelGGL(k_unpad_add, dim3(64), eb, 0, st, tw.dWp[i], W_OUT[i], W_IN[i], W_LD[i], grads->d_w[i]);
-        if (grads->d_b[i])
-            hipLaunchKernelGGL(k_unpad_add, dim3(1), eb, 0, st, tw.dbp[i], 1, W_OUT[i], W_OUT[i], grads->d_b[i]);
+    {
+        NineMats mw{}, mb{};
+        for (int i = 0; i < 9; ++i) {
+            mw.src[i] = tw.dWp[i];
+            mw.dst[i] = grads->d_w[i];
+            mw.n_out[i] = W_OUT[i];
+            mw.n_in[i] = W_IN[i];
+            mw.ld[i] = W_LD[i];
+            mb.src[i] = tw.dbp[i];
+            mb.dst[i] = grads->d_b[i];
+            mb.n_out[i] = 1;
+            mb.n_in[i] = W_OUT[i];
+            mb.ld[i] = W_OUT[i];
+        }
+        hipLaunchKernelGGL(k_unpad_add, dim3(32, 9), eb, 0, st, mw);
+        hipLaunchKernelGGL(k_unpad_add, dim3(1, 9), eb, 0, st, mb);
     }
     PNR_HIP_CHECK(hipGetLastError());
     return PNR_OK;

@@ -353,9 +353,15 @@ class RendererHIP:
             grads.d_embedding, grads.d_color, grads.d_dir = (out["embedding"].data_ptr(), out["color"].data_ptr(),
                                                              out["dir"].data_ptr())
         if weight_grads:
+            # one zero-filled buffer, viewed per tensor (64-float aligned slices)
+            sizes = [((sh[0] * sh[1] + 63) // 64 * 64, (sh[0] + 63) // 64 * 64) for sh in MLP_SHAPES]
+            flat = torch.zeros(sum(a + b for a, b in sizes), dtype=torch.float32, device=dev)
+            off = 0
             for i, (name, shape) in enumerate(zip(MLP_TENSOR_ORDER, MLP_SHAPES)):
-                out[name + ".weight"] = torch.zeros(shape, dtype=torch.float32, device=dev)
-                out[name + ".bias"] = torch.zeros((shape[0],), dtype=torch.float32, device=dev)
+                out[name + ".weight"] = flat[off:off + shape[0] * shape[1]].view(shape)
+                off += sizes[i][0]
+                out[name + ".bias"] = flat[off:off + shape[0]]
+                off += sizes[i][1]
                 grads.d_w[i] = out[name + ".weight"].data_ptr()
                 grads.d_b[i] = out[name + ".bias"].data_ptr()
         nbytes = self.lib.pnr_backward_workspace_bytes(cap, self.opts.K)
