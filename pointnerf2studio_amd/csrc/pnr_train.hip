@@ -41,12 +41,20 @@ struct GemmArgs {
     const float *bias;      // EPI_BIAS_LEAKY
     const float *mask;      // EPI_MASK: taped post-activation, same leading dimension as C
     int mask_cols;          // columns >= mask_cols pass unmasked
+    float *colsum;          // TA only, may be null: colsum[m] += sum_k A[k][m]  (bias gradient = dZ^T . 1)
 };
 
-constexpr int TM = 128, TN = 128, TK = 16, LDT = TM + 4;
+#ifndef PNR_GEMM_WGS
+#define PNR_GEMM_WGS 2
+#endif
+#ifndef PNR_GEMM_TK
+#define PNR_GEMM_TK 16
+#endif
+constexpr int TM = 128, TN = 128, TK = PNR_GEMM_TK, LDT = TM + 4;
+constexpr int NLD = TK / 8;   // float4 loads per thread and operand per chunk
 
 template <bool TA, bool TB, int EPI>
-__global__ void __launch_bounds__(256, 2) k_gemm(GemmArgs g)
+__global__ void __launch_bounds__(256, PNR_GEMM_WGS) k_gemm(GemmArgs g)
 {
     __shared__ float As[2][TK][LDT];
     __shared__ float Bs[2][TK][LDT];
@@ -55,7 +63,10 @@ __global__ void __launch_bounds__(256, 2) k_gemm(GemmArgs g)
     const int rows = *g.dev_rows;
     const int M = TA ? g.M : rows;
     const int N = g.N;
-    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
+    // row GEMMs (TA = false): the column tile is the FAST grid dimension, so the workgroups that share a row tile of A
+    // run together and its second read comes from L2 (the tapes are 1 GB each: launched row-tile-major per column
+    // tile, A was fetched from HBM once per column tile)
+    const int m0 = (TA ? blockIdx.x : blockIdx.y) * TM, n0 = (TA ? blockIdx.y : blockIdx.x) * TN;
     if (m0 >= M || n0 >= N) return;
     int k_begin = 0, k_end = TA ? rows : g.K;
     if (TA) {
@@ -68,17 +79,19 @@ __global__ void __launch_bounds__(256, 2) k_gemm(GemmArgs g)
     }
     const int wm = wave & 1, wn = wave >> 1;
 
-    float4 ra[2], rb[2];
+    float4 ra[NLD], rb[NLD];
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool want_csum = TA && g.colsum && (TA ? blockIdx.y : blockIdx.x) == 0;
     auto load_tiles = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (TA) {  // natural: 16 rows (k) x 128 contiguous m
+        for (int i = 0; i < NLD; ++i) {
+            if (TA) {  // natural: TK rows (k) x 128 contiguous m
                 const int kr = (tid >> 5) + 8 * i, c4 = (tid & 31) * 4;
                 const int k = k0 + kr, m = m0 + c4;
                 ra[i] = (k < k_end && m < M) ? *reinterpret_cast<const float4 *>(g.A + (int64_t)k * g.lda + m)
                                              : make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {  // transposing: 128 rows (m) x 16 contiguous k
-                const int mr = (tid >> 2) + 64 * i, kq = (tid & 3) * 4;
+            } else {  // transposing: 128 rows (m) x TK contiguous k; thread = (row tid >> 3 + 32 i', float4 tid & 7)
+                const int mr = (tid / (TK / 4)) + (1024 / TK) * i, kq = (tid % (TK / 4)) * 4;
                 const int m = m0 + mr, k = k0 + kq;
                 ra[i] = (m < M && k < k_end) ? *reinterpret_cast<const float4 *>(g.A + (int64_t)m * g.lda + k)
                                              : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -89,7 +102,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm(GemmArgs g)
                 rb[i] = (k < k_end && n < N) ? *reinterpret_cast<const float4 *>(g.B + (int64_t)k * g.ldb + n)
                                              : make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
-                const int nr = (tid >> 2) + 64 * i, kq = (tid & 3) * 4;
+                const int nr = (tid / (TK / 4)) + (1024 / TK) * i, kq = (tid % (TK / 4)) * 4;
                 const int n = n0 + nr, k = k0 + kq;
                 rb[i] = (n < N && k < k_end) ? *reinterpret_cast<const float4 *>(g.B + (int64_t)n * g.ldb + k)
                                              : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -98,12 +111,18 @@ __global__ void __launch_bounds__(256, 2) k_gemm(GemmArgs g)
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NLD; ++i) {
             if (TA) {
                 const int kr = (tid >> 5) + 8 * i, c4 = (tid & 31) * 4;
                 *reinterpret_cast<float4 *>(&As[buf][kr][c4]) = ra[i];
+                if (want_csum) {
+                    csum.x += ra[i].x;
+                    csum.y += ra[i].y;
+                    csum.z += ra[i].z;
+                    csum.w += ra[i].w;
+                }
             } else {
-                const int mr = (tid >> 2) + 64 * i, kq = (tid & 3) * 4;
+                const int mr = (tid / (TK / 4)) + (1024 / TK) * i, kq = (tid % (TK / 4)) * 4;
                 As[buf][kq + 0][mr] = ra[i].x;
                 As[buf][kq + 1][mr] = ra[i].y;
                 As[buf][kq + 2][mr] = ra[i].z;
@@ -113,7 +132,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm(GemmArgs g)
                 const int kr = (tid >> 5) + 8 * i, c4 = (tid & 31) * 4;
                 *reinterpret_cast<float4 *>(&Bs[buf][kr][c4]) = rb[i];
             } else {
-                const int nr = (tid >> 2) + 64 * i, kq = (tid & 3) * 4;
+                const int nr = (tid / (TK / 4)) + (1024 / TK) * i, kq = (tid % (TK / 4)) * 4;
                 Bs[buf][kq + 0][nr] = rb[i].x;
                 Bs[buf][kq + 1][nr] = rb[i].y;
                 Bs[buf][kq + 2][nr] = rb[i].z;
@@ -148,6 +167,16 @@ __global__ void __launch_bounds__(256, 2) k_gemm(GemmArgs g)
         }
         if (c + 1 < nchunks) store_tiles(buf ^ 1);
         __syncthreads();
+    }
+    if (want_csum) {
+        // bias gradient: every thread summed the A elements it loaded (columns m0 + 4 (tid & 31) .. + 3)
+        const int m = m0 + (tid & 31) * 4;
+        if (m < M) {
+            unsafeAtomicAdd(g.colsum + m + 0, csum.x);
+            unsafeAtomicAdd(g.colsum + m + 1, csum.y);
+            unsafeAtomicAdd(g.colsum + m + 2, csum.z);
+            unsafeAtomicAdd(g.colsum + m + 3, csum.w);
+        }
     }
 
     // accumulator register r of lane (j, h): row (r & 3) + 8 (r >> 2) + 4 h, column j of the 32x32 block
@@ -367,30 +396,28 @@ __global__ void __launch_bounds__(256) k_train_rows(TrainParams P, TrainWs w)
             dd[5] = pcz - scz;
         }
         float *x0 = w.X0 + (int64_t)row * LD_X0;
-        for (int c = lane; c < LD_X0; c += 64) {
-            float val = 0.f;
-            if (valid) {
-                if (c < 32) {
-                    val = emb[c];
-                } else if (c < 224) {
-                    const int q = c - 32, d = q / 6, f = (q - 6 * d) >> 1;
-                    float sn, cs;
-                    sincosf(emb[d] * (float)(1 << f), &sn, &cs);
-                    val = (q & 1) ? cs : sn;
-                } else if (c < 284) {
-                    const int q = c - 224, d = q / 10, f = (q - 10 * d) >> 1;
-                    float dv = dd[0];
-                    dv = d == 1 ? dd[1] : dv;
-                    dv = d == 2 ? dd[2] : dv;
-                    dv = d == 3 ? dd[3] : dv;
-                    dv = d == 4 ? dd[4] : dv;
-                    dv = d == 5 ? dd[5] : dv;
-                    float sn, cs;
-                    sincosf(dv * (float)(1 << f), &sn, &cs);
-                    val = (q & 1) ? cs : sn;
-                }
+        // columns 32 + 2u, 32 + 2u + 1 = (sin, cos) pair u: u < 96 embedding channel u / 3 at octave u % 3,
+        // u >= 96 distance component (u - 96) / 5 at octave (u - 96) % 5 -- one sincosf per pair
+        if (lane < 32) x0[lane] = valid ? emb[lane] : 0.f;
+        if (lane < 4) x0[284 + lane] = 0.f;
+        for (int u = lane; u < 126; u += 64) {
+            float arg;
+            if (u < 96) {
+                const int d = u / 3, f = u - 3 * d;
+                arg = emb[d] * (float)(1 << f);
+            } else {
+                const int q = u - 96, d = q / 5, f = q - 5 * d;
+                float dv = dd[0];
+                dv = d == 1 ? dd[1] : dv;
+                dv = d == 2 ? dd[2] : dv;
+                dv = d == 3 ? dd[3] : dv;
+                dv = d == 4 ? dd[4] : dv;
+                dv = d == 5 ? dd[5] : dv;
+                arg = dv * (float)(1 << f);
             }
-            x0[c] = val;
+            float sn, cs;
+            sincosf(arg, &sn, &cs);
+            *reinterpret_cast<float2 *>(x0 + 32 + 2 * u) = valid ? make_float2(sn, cs) : make_float2(0.f, 0.f);
         }
         if (lane < 8) {
             float sdx, sdy, sdz, vx, vy, vz;
@@ -663,18 +690,6 @@ __global__ void __launch_bounds__(256) k_train_head_agg_bwd(TrainWs w, int K, co
     if (lane == 0) unsafeAtomicAdd(w.dbp[4], db);
 }
 
-// column sums of a [rows, ld] matrix (bias gradients): out[c] += sum_r A[r][c]
-__global__ void __launch_bounds__(256) k_colsum(const float *__restrict__ A, int ld, int ncols,
-                                                const int *__restrict__ dev_rows, float *__restrict__ out)
-{
-    const int rows = *dev_rows;
-    const int c = threadIdx.x;  // ncols <= 256
-    if (c >= ncols) return;
-    float s = 0.f;
-    for (int r = blockIdx.x; r < rows; r += gridDim.x) s += A[(int64_t)r * ld + c];
-    unsafeAtomicAdd(out + c, s);
-}
-
 // One wavefront per row: gradients of the point tensors, scattered with float atomics (index_select backward).
 //   dX0 [row, 0:224] is in G2, the taped encodings in X0, d[color | sdir - view | <sdir, view>] in H2[:, 256:263]
 __global__ void __launch_bounds__(256) k_train_scatter(TrainParams P, TrainWs w, float *__restrict__ d_emb,
@@ -722,7 +737,8 @@ __global__ void __launch_bounds__(256) k_train_scatter(TrainParams P, TrainWs w,
 template <bool TA, bool TB, int EPI>
 static void gemm(hipStream_t st, const GemmArgs &g, int m_max, int nsplit = 1)
 {
-    const dim3 grid((unsigned)((m_max + TM - 1) / TM), (unsigned)((g.N + TN - 1) / TN), (unsigned)nsplit);
+    const unsigned mt = (unsigned)((m_max + TM - 1) / TM), nt = (unsigned)((g.N + TN - 1) / TN);
+    const dim3 grid(TA ? mt : nt, TA ? nt : mt, (unsigned)nsplit);
     hipLaunchKernelGGL((k_gemm<TA, TB, EPI>), grid, dim3(256), 0, st, g);
 }
 
@@ -749,13 +765,13 @@ static void gemm_data(hipStream_t st, const float *dZ, int lda, const float *W, 
         gemm<false, false, EPI_STORE>(st, g, (int)rows_max);
 }
 
-// dW[M, N] += dZ[rows, M]^T . X[rows, N]
+// dW[M, N] += dZ[rows, M]^T . X[rows, N];  db[M] += column sums of dZ
 static void gemm_weight(hipStream_t st, const float *dZ, int lda, const float *X, int ldx, float *dW, int ldw, int M,
-                        int N, const int *dev_rows, int64_t rows_max)
+                        int N, const int *dev_rows, int64_t rows_max, float *db)
 {
     GemmArgs g{};
     g.A = dZ; g.B = X; g.C = dW; g.lda = lda; g.ldb = ldx; g.ldc = ldw; g.M = M; g.N = N; g.K = 0;
-    g.dev_rows = dev_rows;
+    g.dev_rows = dev_rows; g.colsum = db;
     const int tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
     int nsplit = (int)std::min<int64_t>(std::max<int64_t>(1, 768 / tiles), (rows_max + 4 * TK - 1) / (4 * TK));
     nsplit = std::max(nsplit, 1);
@@ -885,30 +901,23 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
                        ws.ray_off, ws.ray_flag, ws.smp_loc, ws.n_sel, tw, d_grad_rgb, d_rgb_recomputed);
     // colour MLP
     hipLaunchKernelGGL(k_train_color_head_bwd, dim3(256), eb, 0, st, tw, d_w[8]);  // C3 <- dZ7
-    gemm_weight(st, tw.C3, LD_C, tw.C2, LD_C, tw.dWp[7], 128, 128, 128, n_smp, smp_max);
-    hipLaunchKernelGGL(k_colsum, dim3(512), eb, 0, st, tw.C3, LD_C, 128, n_smp, tw.dbp[7]);
+    gemm_weight(st, tw.C3, LD_C, tw.C2, LD_C, tw.dWp[7], 128, 128, 128, n_smp, smp_max, tw.dbp[7]);
     gemm_data(st, tw.C3, LD_C, tw.Wp[7], 128, tw.C2, LD_C, 128, 128, 128, n_smp, smp_max);  // C2 <- dZ6
-    gemm_weight(st, tw.C2, LD_C, tw.C1, LD_C, tw.dWp[6], 128, 128, 128, n_smp, smp_max);
-    hipLaunchKernelGGL(k_colsum, dim3(512), eb, 0, st, tw.C2, LD_C, 128, n_smp, tw.dbp[6]);
+    gemm_weight(st, tw.C2, LD_C, tw.C1, LD_C, tw.dWp[6], 128, 128, 128, n_smp, smp_max, tw.dbp[6]);
     gemm_data(st, tw.C2, LD_C, tw.Wp[6], 128, tw.C1, LD_C, 128, 128, 128, n_smp, smp_max);  // C1 <- dZ5
-    gemm_weight(st, tw.C1, LD_C, tw.XC, LD_XC, tw.dWp[5], 288, 128, 288, n_smp, smp_max);
-    hipLaunchKernelGGL(k_colsum, dim3(512), eb, 0, st, tw.C1, LD_C, 128, n_smp, tw.dbp[5]);
+    gemm_weight(st, tw.C1, LD_C, tw.XC, LD_XC, tw.dWp[5], 288, 128, 288, n_smp, smp_max, tw.dbp[5]);
     gemm_data(st, tw.C1, LD_C, tw.Wp[5], 288, tw.XC, LD_XC, 256, 128, 0, n_smp, smp_max);   // XC[:, :256] <- dAGG
     // density head + aggregation
     hipLaunchKernelGGL(k_train_head_agg_bwd, dim3(2048), eb, 0, st, tw, K, d_w[4]);          // G2 <- dZ4
     // mlp_head
-    gemm_weight(st, tw.G2, LD_H, tw.G1, LD_H, tw.dWp[3], 256, 256, 256, n_rows, rows_max);
-    hipLaunchKernelGGL(k_colsum, dim3(1024), eb, 0, st, tw.G2, LD_H, 256, n_rows, tw.dbp[3]);
+    gemm_weight(st, tw.G2, LD_H, tw.G1, LD_H, tw.dWp[3], 256, 256, 256, n_rows, rows_max, tw.dbp[3]);
     gemm_data(st, tw.G2, LD_H, tw.Wp[3], 256, tw.G1, LD_H, 256, 256, 256, n_rows, rows_max);   // G1 <- dZ3
-    gemm_weight(st, tw.G1, LD_H, tw.H2, LD_H2, tw.dWp[2], 264, 256, 264, n_rows, rows_max);
-    hipLaunchKernelGGL(k_colsum, dim3(1024), eb, 0, st, tw.G1, LD_H, 256, n_rows, tw.dbp[2]);
+    gemm_weight(st, tw.G1, LD_H, tw.H2, LD_H2, tw.dWp[2], 264, 256, 264, n_rows, rows_max, tw.dbp[2]);
     gemm_data(st, tw.G1, LD_H, tw.Wp[2], 264, tw.H2, LD_H2, 264, 256, 256, n_rows, rows_max);  // H2 <- [dZ2 | d extras]
     // mlp_base
-    gemm_weight(st, tw.H2, LD_H2, tw.H1, LD_H, tw.dWp[1], 256, 256, 256, n_rows, rows_max);
-    hipLaunchKernelGGL(k_colsum, dim3(1024), eb, 0, st, tw.H2, LD_H2, 256, n_rows, tw.dbp[1]);
+    gemm_weight(st, tw.H2, LD_H2, tw.H1, LD_H, tw.dWp[1], 256, 256, 256, n_rows, rows_max, tw.dbp[1]);
     gemm_data(st, tw.H2, LD_H2, tw.Wp[1], 256, tw.H1, LD_H, 256, 256, 256, n_rows, rows_max);  // H1 <- dZ1
-    gemm_weight(st, tw.H1, LD_H, tw.X0, LD_X0, tw.dWp[0], 288, 256, 288, n_rows, rows_max);
-    hipLaunchKernelGGL(k_colsum, dim3(1024), eb, 0, st, tw.H1, LD_H, 256, n_rows, tw.dbp[0]);
+    gemm_weight(st, tw.H1, LD_H, tw.X0, LD_X0, tw.dWp[0], 288, 256, 288, n_rows, rows_max, tw.dbp[0]);
     gemm_data(st, tw.H1, LD_H, tw.Wp[0], 288, tw.G2, LD_H, 224, 256, 0, n_rows, rows_max);     // G2 <- dX0[:, :224]
     // point tensors
     hipLaunchKernelGGL(k_train_scatter, eg, eb, 0, st, P, tw, grads->d_embedding, grads->d_color, grads->d_dir);

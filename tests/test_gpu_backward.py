@@ -111,3 +111,96 @@ def test_backward_rejects_bad_arguments(oracle, gpu_device):
     rnd.render(dirs.to(gpu_device), campos, camrot, 2.0, 6.0)
     with pytest.raises(RuntimeError, match="early_stop_eps"):
         rnd.backward(torch.zeros(64, 3, device=gpu_device), w, 20000)
+
+
+def test_backward_with_training_jitter_and_short_rays(oracle, gpu_device):
+    """The reference trains at jitter 0.3 (studio_utils.py:166); SR = 8 makes most rays fill every slot, which
+    exercises the composite's last-slot segment (`vsize`) and the rays cut at SR in the reverse scan."""
+    N, SR, K, P = 80000, 8, 8, 12
+    pts = small_scene(N)
+    cfg = oracle_cfg(oracle, SR=SR, K=K, P=P)
+    w = synthetic.make_weights(0, sigma_scale=300.0, bias_scale=0.1)
+    campos, camrot, dirs = camera_rays(28, 28, az=50.0)
+    R = dirs.shape[0]
+    u = oracle.jitter_uniforms(R, cfg.z_depth_dim, seed=7)
+    torch.manual_seed(9)
+    G = torch.randn(R, 3)
+    ref, want = _oracle_grads(oracle, pts, w, cfg, campos, camrot, dirs, G, True, jitter=0.3, u=u)
+    assert (ref["blend_weight"] > 0).sum(-1).max().item() == SR      # some ray uses all SR slots
+    scene, wh, hyp, info = build_hip(pts, cfg, gpu_device, weights=w)
+    rnd = RendererHIP(scene, wh, SR=SR, K=K, D=cfg.z_depth_dim, radius_limit=float(oracle.radius_limit(cfg)),
+                      vsize_z=cfg.vsize[2], precision="fp32", eval_clamp=False, jitter=0.3, seed=7)
+    rnd.render(dirs.to(gpu_device), campos, camrot, 2.0, 6.0)
+    got = rnd.backward(G.to(gpu_device), w, N)
+    assert (got["rgb"].cpu() - ref["coarse_raycolor"]).abs().max().item() <= 1e-4
+    for k in ("embedding", "color", "dir"):
+        _compare(k, got[k].cpu(), want[k])
+    for name in MLP_TENSOR_ORDER:
+        for suf in (".weight", ".bias"):
+            _compare(name + suf, got[name + suf].cpu(), want[name + suf])
+
+
+def test_backward_of_multi_camera_render_is_the_sum_of_the_views(oracle, gpu_device):
+    """pnr_render_views + pnr_render_backward with three cameras in one call (shuffled rays, explicit camera
+    index) equals the sum of three single-camera backward calls on the same cotangents."""
+    N, K = 80000, 8
+    pts = small_scene(N)
+    cfg = oracle_cfg(oracle, K=K)
+    w = synthetic.make_weights(0, sigma_scale=300.0, bias_scale=0.1)
+    scene, wh, hyp, info = build_hip(pts, cfg, gpu_device, weights=w)
+    rnd = RendererHIP(scene, wh, K=K, precision="fp32", eval_clamp=False)
+    cams, dirs = [], []
+    for az in (15.0, 140.0, 260.0):
+        campos, camrot, d = camera_rays(20, 20, az=az)
+        cams.append((campos, camrot, 2.0, 6.0))
+        dirs.append(d.to(gpu_device))
+    n = dirs[0].shape[0]
+    torch.manual_seed(2)
+    G = torch.randn(3 * n, 3, device=gpu_device)
+    total = None
+    for v in range(3):
+        rnd.render(dirs[v], cams[v][0], cams[v][1], 2.0, 6.0)
+        g = rnd.backward(G[v * n:(v + 1) * n], w, N)
+        g.pop("rgb")
+        total = g if total is None else {k: total[k] + g[k] for k in g}
+    perm = torch.randperm(3 * n, generator=torch.Generator().manual_seed(0)).to(gpu_device)
+    rnd.render_views(torch.cat(dirs)[perm], cams, n, ray_cam=(perm // n).to(torch.int32))
+    got = rnd.backward(G[perm], w, N)
+    for k, v in total.items():
+        _compare(k, got[k], v)
+
+
+def test_backward_accumulates_into_caller_buffers(oracle, gpu_device):
+    """The C ABI adds to the gradient buffers (torch .grad semantics) and skips null pointers."""
+    import ctypes as C
+    from pointnerf2studio_amd import _lib
+    from pointnerf2studio_amd.renderer import MLP_SHAPES, _ptr, _stream_ptr
+    N = 40000
+    pts = small_scene(N)
+    cfg = oracle_cfg(oracle, SR=24)
+    w = synthetic.make_weights(0, sigma_scale=300.0, bias_scale=0.1)
+    scene, wh, hyp, info = build_hip(pts, cfg, gpu_device, weights=w)
+    rnd = RendererHIP(scene, wh, SR=24, precision="fp32", eval_clamp=False)
+    campos, camrot, dirs = camera_rays(16, 16, az=35.0)
+    rnd.render(dirs.to(gpu_device), campos, camrot, 2.0, 6.0)
+    G = torch.ones(dirs.shape[0], 3, device=gpu_device)
+    once = rnd.backward(G, w, N)
+    d, R, arr, n, rc, rpc, cap = rnd._last
+    ws_t = [w[nm + ".weight"].to(gpu_device).contiguous() for nm in MLP_TENSOR_ORDER]
+    bs_t = [w[nm + ".bias"].to(gpu_device).contiguous() for nm in MLP_TENSOR_ORDER]
+    wp = (C.c_void_p * 9)(*[t.data_ptr() for t in ws_t])
+    bp = (C.c_void_p * 9)(*[t.data_ptr() for t in bs_t])
+    emb = torch.full((N, 32), 1.0, device=gpu_device)
+    w0 = torch.full(MLP_SHAPES[0], 2.0, device=gpu_device)
+    grads = _lib.GradsC()
+    grads.d_embedding = emb.data_ptr()
+    grads.d_w[0] = w0.data_ptr()
+    lib = _lib.load()
+    for _ in range(2):
+        _lib.check(lib.pnr_render_backward(scene.handle, wh.handle, C.byref(wp), C.byref(bp), _ptr(d), R, arr, n,
+                                           _ptr(rc), rpc, C.byref(rnd.opts), _ptr(G), _ptr(rnd._ws), rnd._ws.numel(),
+                                           cap, _ptr(rnd._tws), rnd._tws.numel(), C.byref(grads), None,
+                                           _stream_ptr(gpu_device)), "pnr_render_backward")
+    torch.cuda.synchronize()
+    _compare("embedding (+= twice)", emb - 1.0, 2 * once["embedding"])
+    _compare("mlp_base.0.weight (+= twice)", w0 - 2.0, 2 * once["mlp_base.layers.0.weight"])
