@@ -87,3 +87,89 @@ def test_shards_partition_the_image_and_interleave():
         for s in shards:
             ys = s.pixels[:s.n_valid] // W
             assert ys.min() < H // 4 and ys.max() > 3 * H // 4
+
+
+# ---- data-parallel training step: gradient exchange ---------------------------------------------------------------
+def _grad_worker(rank, world, port, N, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pointnerf2studio_amd.distributed import GradExchange
+
+        def local_grads(r):
+            g = torch.Generator().manual_seed(100 + r)
+            u = 50 + 37 * r                                      # ranks touch different numbers of points ...
+            idx = torch.randperm(N, generator=g)[:u]
+            idx[0] = 3                                           # ... and share some of them
+            idx[1] = N - 1 if N - 1 not in idx[2:].tolist() else idx[1]
+            idx = idx.unique()
+            emb, col, dr = torch.zeros(N, 32), torch.zeros(N, 3), torch.zeros(N, 3)
+            emb[idx] = torch.randn(idx.numel(), 32, generator=g)
+            col[idx] = torch.randn(idx.numel(), 3, generator=g)
+            dr[idx] = torch.randn(idx.numel(), 3, generator=g)
+            flat = torch.randn(1000, generator=g)
+            return idx, emb, col, dr, flat
+
+        idx, emb, col, dr, flat = local_grads(rank)
+        everyone = [local_grads(r) for r in range(world)]
+        ok = True
+        for average in (False, True):
+            e, c, d, f = emb.clone(), col.clone(), dr.clone(), flat.clone()
+            ex = GradExchange(average=average)
+            views = [f[:600].view(20, 30), f[600:]]              # views of one flat buffer: reduced without a copy
+            ex.reduce_mlp(views)
+            got_rows = ex.reduce_points(idx, e, c, d)
+            scale = world if average else 1
+            ok = ok and torch.allclose(e, sum(x[1] for x in everyone) / scale, atol=1e-6)
+            ok = ok and torch.allclose(c, sum(x[2] for x in everyone) / scale, atol=1e-6)
+            ok = ok and torch.allclose(d, sum(x[3] for x in everyone) / scale, atol=1e-6)
+            ok = ok and torch.allclose(f, sum(x[4] for x in everyone) / scale, atol=1e-6)
+            ok = ok and got_rows == sum(x[0].numel() for r, x in enumerate(everyone) if r != rank)
+            # separate tensors (not views of one buffer) take the copying path
+            a, b = flat[:10].clone(), flat[10:30].clone()
+            ex.reduce_mlp([a, b])
+            ok = ok and torch.allclose(a, sum(x[4][:10] for x in everyone) / scale, atol=1e-6)
+            ok = ok and torch.allclose(b, sum(x[4][10:30] for x in everyone) / scale, atol=1e-6)
+        # a rank whose rays hit nothing contributes zero rows
+        e, c, d = torch.zeros(N, 32), torch.zeros(N, 3), torch.zeros(N, 3)
+        mine = idx if rank == 0 else idx[:0]
+        if rank == 0:
+            e[idx] = 1.0
+        GradExchange(average=False).reduce_points(mine, e, c, d)
+        ok = ok and float(e.sum()) == 32.0 * everyone[0][0].numel()
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,N", [(2, 5000), (3, 20_000_000 // 1000)])
+def test_gradient_exchange_sparse_points_and_flat_mlp(world, N):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, N, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
+
+
+def test_gradient_exchange_is_a_no_op_on_one_rank():
+    from pointnerf2studio_amd.distributed import GradExchange
+    ex = GradExchange(world=1)
+    e = torch.ones(10, 32)
+    assert ex.reduce_points(torch.arange(3), e, torch.zeros(10, 3), torch.zeros(10, 3)) == 0
+    t = torch.ones(5)
+    ex.reduce_mlp([t])
+    assert torch.equal(e, torch.ones(10, 32)) and torch.equal(t, torch.ones(5))
+
+
+def test_point_index_survives_the_float_block():
+    from pointnerf2studio_amd.distributed import _index_from_f32_halves, _index_to_f32_halves
+    idx = torch.tensor([0, 1, 16777215, 16777216, 16777217, 19_999_999, 2 ** 31 + 5, 2 ** 40 + 123456789])
+    lo, hi = _index_to_f32_halves(idx)
+    assert torch.equal(_index_from_f32_halves(lo, hi), idx)
