@@ -245,6 +245,7 @@ class RendererHIP:
         self.cap_samples = 0
         self.calls = 0          # render calls so far (a backward must follow ITS render directly)
         self._last = None
+        self.last_counters = None
 
     def _workspace(self, R: int, cap: int, dev):
         key = (R, cap, self.opts.K)
@@ -322,6 +323,7 @@ class RendererHIP:
                 return out
             cnt = out["counters_dev"].cpu().tolist()
             out["counters"] = dict(zip(_lib.COUNTER_NAMES, cnt))
+            self.last_counters = out["counters"]
             if cnt[6] == 0:
                 return out
             # overflow: grow to what the frame actually needs (+12 %) and render again
@@ -376,6 +378,17 @@ class RendererHIP:
                 self._tws.numel(), C.byref(grads), _ptr(out["rgb"]), _stream_ptr(dev)), "pnr_render_backward")
             torch.cuda.current_stream(dev).synchronize()  # the converted inputs above may be temporaries
         return out
+
+    def touched_points(self) -> torch.Tensor:
+        """Unique neighbour points of the last render call (int64, ascending): the rows of the point gradients that
+        can be non-zero -- what a data-parallel step exchanges (distributed.GradExchange.reduce_points)."""
+        if self._last is None:
+            raise RuntimeError("RendererHIP.touched_points: no render call yet")
+        R = self._last[1]
+        taps = self.taps(R)
+        n = int(taps["ray_off"][-1].item() + taps["ray_cnt"][-1].item())   # selected samples of the call
+        pidx = taps["smp_pidx"].reshape(-1)[:min(n, self.cap_samples) * self.opts.K]
+        return torch.unique(pidx[pidx >= 0]).to(torch.long)
 
     def taps(self, R: int):
         """Views into the last frame's workspace (tests): per selected sample loc+t, ray, pidx, decoded."""
