@@ -44,6 +44,38 @@ struct GemmArgs {
     float *colsum;          // TA only, may be null: colsum[m] += sum_k A[k][m]  (bias gradient = dZ^T . 1)
 };
 
+// accumulator register r of lane (j, h): row (r & 3) + 8 (r >> 2) + 4 h, column j of the 32x32 block
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, const f32x16 (&acc)[2][2], int M, int N, int m0, int n0,
+                                              int wm, int wn, int j, int h)
+{
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = n0 + wn * 64 + b * 32 + j;
+            if (col >= N) continue;
+            const float bias = (EPI == EPI_BIAS_LEAKY) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row >= M) continue;
+                float v = acc[a][b][r];
+                float *dst = g.C + (int64_t)row * g.ldc + col;
+                if (EPI == EPI_BIAS_LEAKY) {
+                    v += bias;
+                    v = v > 0.f ? v : 0.1f * v;
+                } else if (EPI == EPI_MASK) {
+                    if (col < g.mask_cols) v *= (g.mask[(int64_t)row * g.ldc + col] > 0.f) ? 1.0f : 0.1f;
+                }
+                if (EPI == EPI_ATOMIC)
+                    unsafeAtomicAdd(dst, v);
+                else
+                    *dst = v;
+            }
+        }
+}
+
 #ifndef PNR_GEMM_WGS
 #define PNR_GEMM_WGS 2
 #endif
@@ -66,7 +98,13 @@ __global__ void __launch_bounds__(256, PNR_GEMM_WGS) k_gemm(GemmArgs g)
     // row GEMMs (TA = false): the column tile is the FAST grid dimension, so the workgroups that share a row tile of A
     // run together and its second read comes from L2 (the tapes are 1 GB each: launched row-tile-major per column
     // tile, A was fetched from HBM once per column tile)
-    const int m0 = (TA ? blockIdx.x : blockIdx.y) * TM, n0 = (TA ? blockIdx.y : blockIdx.x) * TN;
+    // Row GEMMs are PERSISTENT: a fixed grid walks the (row tile, column tile) pairs of the row count found on the
+    // device -- a grid sized for the capacity of the workspace would launch ~10x more workgroups than have work
+    // (an empty workgroup still costs ~2 us of a CU slot: 0.4 ms per GEMM at 114 k of them).
+    const int n_nt = (N + TN - 1) / TN;
+    const int total = TA ? 1 : n_nt * ((M + TM - 1) / TM);
+    for (int it = TA ? 0 : (int)blockIdx.x; it < total; it += TA ? 1 : (int)gridDim.x) {
+    const int m0 = (TA ? (int)blockIdx.x : it / n_nt) * TM, n0 = (TA ? (int)blockIdx.y : it % n_nt) * TN;
     if (m0 >= M || n0 >= N) return;
     int k_begin = 0, k_end = TA ? rows : g.K;
     if (TA) {
@@ -81,7 +119,7 @@ __global__ void __launch_bounds__(256, PNR_GEMM_WGS) k_gemm(GemmArgs g)
 
     float4 ra[NLD], rb[NLD];
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool want_csum = TA && g.colsum && (TA ? blockIdx.y : blockIdx.x) == 0;
+    const bool want_csum = TA && g.colsum && blockIdx.y == 0;
     auto load_tiles = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
@@ -179,32 +217,111 @@ __global__ void __launch_bounds__(256, PNR_GEMM_WGS) k_gemm(GemmArgs g)
         }
     }
 
-    // accumulator register r of lane (j, h): row (r & 3) + 8 (r >> 2) + 4 h, column j of the 32x32 block
+    gemm_epilogue<EPI>(g, acc, M, N, m0, n0, wm, wn, j, h);
+    }
+}
+
+// The same GEMM for the two row shapes (forward, data gradient: both C[M,N] = A[M,K] . B[N,K]^T once the data
+// gradient is given W^T) in the bf16x3 arithmetic of the render's default mode: every fp32 product is
+// ah*bh + ah*bl + al*bh on bf16 hi/lo splits with fp32 accumulation (v_mfma_f32_32x32x16_bf16, relative error
+// ~2^-16 per product).  Operands are split ONCE, when a chunk is written to LDS (each element then feeds 128
+// products); LDS holds hi and lo planes in k-group-major order [k / 8][row][8 bf16], so a lane's 16-byte fragment
+// read is conflict-free and IS the MFMA operand.  3 MFMAs of 32 cycles replace 8 of 64: these GEMMs become
+// HBM-bound (1 GB of tape in, 1 GB out per layer).
+constexpr int BK = 32;  // k per chunk = two MFMA steps
+
+template <int EPI>
+__global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16x3(GemmArgs g)
+{
+    // [buffer][plane: A hi, A lo, B hi, B lo][k group][row]
+    __shared__ u32x4 planes[2][4][BK / 8][TM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int M = *g.dev_rows, N = g.N, K = g.K;
+    const int wm = wave & 1, wn = wave >> 1;
+    constexpr int NL = BK / 8;  // float4 loads per thread and operand per chunk
+    // persistent over the (row tile, column tile) pairs, column tile fastest (see k_gemm)
+    const int n_nt = (N + TN - 1) / TN;
+    const int total = n_nt * ((M + TM - 1) / TM);
+    for (int it = blockIdx.x; it < total; it += gridDim.x) {
+    const int m0 = (it / n_nt) * TM, n0 = (it % n_nt) * TN;
+    float4 ra[NL], rb[NL];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int r = (tid >> 3) + 32 * i, k = k0 + (tid & 7) * 4;
+            ra[i] = (m0 + r < M && k < K) ? *reinterpret_cast<const float4 *>(g.A + (int64_t)(m0 + r) * g.lda + k)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[i] = (n0 + r < N && k < K) ? *reinterpret_cast<const float4 *>(g.B + (int64_t)(n0 + r) * g.ldb + k)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto split4 = [](const float4 &v, uint2 &hi, uint2 &lo) {
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        const float x[4] = {v.x, v.y, v.z, v.w};
+        bf16x4 hv, lv;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const __bf16 hb = (__bf16)x[i];
+            hv[i] = hb;
+            lv[i] = (__bf16)(x[i] - (float)hb);
+        }
+        hi = __builtin_bit_cast(uint2, hv);
+        lo = __builtin_bit_cast(uint2, lv);
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int r = (tid >> 3) + 32 * i, kq = (tid & 7) * 4;
+            const int kg = kq >> 3, half = (kq >> 2) & 1;
+            uint2 hi, lo;
+            split4(ra[i], hi, lo);
+            reinterpret_cast<uint2 *>(&planes[buf][0][kg][r])[half] = hi;
+            reinterpret_cast<uint2 *>(&planes[buf][1][kg][r])[half] = lo;
+            split4(rb[i], hi, lo);
+            reinterpret_cast<uint2 *>(&planes[buf][2][kg][r])[half] = hi;
+            reinterpret_cast<uint2 *>(&planes[buf][3][kg][r])[half] = lo;
+        }
+    };
+    f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int col = n0 + wn * 64 + b * 32 + j;
-            if (col >= N) continue;
-            const float bias = (EPI == EPI_BIAS_LEAKY) ? g.bias[col] : 0.f;
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row >= M) continue;
-                float v = acc[a][b][r];
-                float *dst = g.C + (int64_t)row * g.ldc + col;
-                if (EPI == EPI_BIAS_LEAKY) {
-                    v += bias;
-                    v = v > 0.f ? v : 0.1f * v;
-                } else if (EPI == EPI_MASK) {
-                    if (col < g.mask_cols) v *= (g.mask[(int64_t)row * g.ldc + col] > 0.f) ? 1.0f : 0.1f;
-                }
-                if (EPI == EPI_ATOMIC)
-                    unsafeAtomicAdd(dst, v);
-                else
-                    *dst = v;
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int nchunks = (K + BK - 1) / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) load_tiles((c + 1) * BK);
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            const int kg = 2 * s + h;
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                ah[q] = __builtin_bit_cast(bf16x8, planes[buf][0][kg][wm * 64 + q * 32 + j]);
+                al[q] = __builtin_bit_cast(bf16x8, planes[buf][1][kg][wm * 64 + q * 32 + j]);
+                bh[q] = __builtin_bit_cast(bf16x8, planes[buf][2][kg][wn * 64 + q * 32 + j]);
+                bl[q] = __builtin_bit_cast(bf16x8, planes[buf][3][kg][wn * 64 + q * 32 + j]);
             }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                }
         }
+        if (c + 1 < nchunks) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+    gemm_epilogue<EPI>(g, acc, M, N, m0, n0, wm, wn, j, h);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -230,6 +347,7 @@ struct TrainWs {
     float *X0, *H1, *H2, *G1, *G2;  // [cap * K, ld]
     float *XC, *C1, *C2, *C3;       // [cap, ld]
     float *Wp[9], *dWp[9], *dbp[9];
+    float *WT[9];                   // W^T, [W_LD (inputs, zero rows beyond in) , out]: B operand of the bf16x3 data GEMMs
     float *dw_begin;                // dWp / dbp are contiguous: [dw_begin, dw_begin + dw_floats)
     size_t dw_floats;
     size_t total;
@@ -266,6 +384,7 @@ static TrainWs carve_train_ws(void *base, int64_t cap, int K)
     w.C2 = (float *)take(smp * LD_C * 4);
     w.C3 = (float *)take(smp * LD_C * 4);
     for (int i = 0; i < 9; ++i) w.Wp[i] = (float *)take((size_t)W_OUT[i] * W_LD[i] * 4);
+    for (int i = 0; i < 9; ++i) w.WT[i] = (float *)take((size_t)W_OUT[i] * W_LD[i] * 4);
     const size_t dw0 = off;
     for (int i = 0; i < 9; ++i) w.dWp[i] = (float *)take((size_t)W_OUT[i] * W_LD[i] * 4);
     for (int i = 0; i < 9; ++i) w.dbp[i] = (float *)take((size_t)W_OUT[i] * 4);
@@ -303,6 +422,7 @@ __global__ void k_train_s2v(const int *__restrict__ vs_list, const int *__restri
 struct NineMats {
     const float *src[9];
     float *dst[9];
+    float *dstT[9];   // k_pad_weights only: transposed copy [ld, out]
     int n_out[9], n_in[9], ld[9];
 };
 __global__ void k_pad_weights(NineMats m)
@@ -311,9 +431,13 @@ __global__ void k_pad_weights(NineMats m)
     const int ld = m.ld[l], n_in = m.n_in[l], n = m.n_out[l] * ld;
     const float *__restrict__ src = m.src[l];
     float *__restrict__ dst = m.dst[l];
+    float *__restrict__ dstT = m.dstT[l];
+    const int n_out = m.n_out[l];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int o = i / ld, c = i - o * ld;
-        dst[i] = c < n_in ? src[(int64_t)o * n_in + c] : 0.f;
+        const float v = c < n_in ? src[(int64_t)o * n_in + c] : 0.f;
+        dst[i] = v;
+        if (dstT) dstT[(int64_t)c * n_out + o] = v;
     }
 }
 
@@ -734,31 +858,53 @@ __global__ void __launch_bounds__(256) k_train_scatter(TrainParams P, TrainWs w,
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+constexpr int PERSISTENT_WGS = 256 * 2 * 4;  // 256 CUs x 2 resident workgroups x 4 rounds of slack for balance
+
 template <bool TA, bool TB, int EPI>
 static void gemm(hipStream_t st, const GemmArgs &g, int m_max, int nsplit = 1)
 {
     const unsigned mt = (unsigned)((m_max + TM - 1) / TM), nt = (unsigned)((g.N + TN - 1) / TN);
-    const dim3 grid(TA ? mt : nt, TA ? nt : mt, (unsigned)nsplit);
+    const dim3 grid(TA ? mt : std::min(mt * nt, (unsigned)PERSISTENT_WGS), TA ? nt : 1u, (unsigned)nsplit);
     hipLaunchKernelGGL((k_gemm<TA, TB, EPI>), grid, dim3(256), 0, st, g);
 }
 
 // C[rows, N] = leaky(A[rows, K] . W[N, K]^T + b)
-static void gemm_forward(hipStream_t st, const float *A, int lda, const float *W, int ldw, const float *b, float *C,
-                         int ldc, int N, int K, const int *dev_rows, int64_t rows_max)
+template <int EPI>
+static void gemm_bf(hipStream_t st, const GemmArgs &g, int m_max)
+{
+    const unsigned tiles = (unsigned)((g.N + TN - 1) / TN) * (unsigned)((m_max + TM - 1) / TM);
+    hipLaunchKernelGGL((k_gemm_nt_bf16x3<EPI>), dim3(std::min(tiles, (unsigned)PERSISTENT_WGS)), dim3(256), 0, st, g);
+}
+
+static void gemm_forward(hipStream_t st, bool bf, const float *A, int lda, const float *W, int ldw, const float *b,
+                         float *C, int ldc, int N, int K, const int *dev_rows, int64_t rows_max)
 {
     GemmArgs g{};
     g.A = A; g.B = W; g.C = C; g.lda = lda; g.ldb = ldw; g.ldc = ldc; g.M = 0; g.N = N; g.K = K;
     g.dev_rows = dev_rows; g.bias = b;
-    gemm<false, true, EPI_BIAS_LEAKY>(st, g, (int)rows_max);
+    if (bf)
+        gemm_bf<EPI_BIAS_LEAKY>(st, g, (int)rows_max);
+    else
+        gemm<false, true, EPI_BIAS_LEAKY>(st, g, (int)rows_max);
 }
 
 // C[rows, N] = (dZ[rows, K] . W[K, N]) * leaky'(C) for columns < mask_cols (in place over the taped activation)
-static void gemm_data(hipStream_t st, const float *dZ, int lda, const float *W, int ldw, float *C, int ldc, int N,
-                      int K, int mask_cols, const int *dev_rows, int64_t rows_max)
+// (bf16x3: the B operand is WT = W^T [N, K] with leading dimension K)
+static void gemm_data(hipStream_t st, bool bf, const float *dZ, int lda, const float *W, int ldw, const float *WT,
+                      float *C, int ldc, int N, int K, int mask_cols, const int *dev_rows, int64_t rows_max)
 {
     GemmArgs g{};
     g.A = dZ; g.B = W; g.C = C; g.lda = lda; g.ldb = ldw; g.ldc = ldc; g.M = 0; g.N = N; g.K = K;
     g.dev_rows = dev_rows; g.mask = C; g.mask_cols = mask_cols;
+    if (bf) {
+        g.B = WT;
+        g.ldb = K;
+        if (mask_cols > 0)
+            gemm_bf<EPI_MASK>(st, g, (int)rows_max);
+        else
+            gemm_bf<EPI_STORE>(st, g, (int)rows_max);
+        return;
+    }
     if (mask_cols > 0)
         gemm<false, false, EPI_MASK>(st, g, (int)rows_max);
     else
@@ -830,6 +976,7 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
         return PNR_ERR_WORKSPACE;
     }
     const int K = opts->K;
+    const bool bf = opts->precision == PNR_PRECISION_BF16X3;
     RenderWs ws = carve_render_ws(d_render_workspace, R, cap_samples, K, scene->N, scene->info[2]);
     TrainWs tw = carve_train_ws(d_train_workspace, cap_samples, K);
 
@@ -877,6 +1024,7 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
         for (int i = 0; i < 9; ++i) {
             m.src[i] = d_w[i];
             m.dst[i] = tw.Wp[i];
+            m.dstT[i] = tw.WT[i];
             m.n_out[i] = W_OUT[i];
             m.n_in[i] = W_IN[i];
             m.ld[i] = W_LD[i];
@@ -886,14 +1034,14 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
 
     // ---- forward with tape -----------------------------------------------------------------------
     hipLaunchKernelGGL(k_train_rows, eg, eb, 0, st, P, tw);
-    gemm_forward(st, tw.X0, LD_X0, tw.Wp[0], 288, d_b[0], tw.H1, LD_H, 256, 288, n_rows, rows_max);
-    gemm_forward(st, tw.H1, LD_H, tw.Wp[1], 256, d_b[1], tw.H2, LD_H2, 256, 256, n_rows, rows_max);
-    gemm_forward(st, tw.H2, LD_H2, tw.Wp[2], 264, d_b[2], tw.G1, LD_H, 256, 264, n_rows, rows_max);
-    gemm_forward(st, tw.G1, LD_H, tw.Wp[3], 256, d_b[3], tw.G2, LD_H, 256, 256, n_rows, rows_max);
+    gemm_forward(st, bf, tw.X0, LD_X0, tw.Wp[0], 288, d_b[0], tw.H1, LD_H, 256, 288, n_rows, rows_max);
+    gemm_forward(st, bf, tw.H1, LD_H, tw.Wp[1], 256, d_b[1], tw.H2, LD_H2, 256, 256, n_rows, rows_max);
+    gemm_forward(st, bf, tw.H2, LD_H2, tw.Wp[2], 264, d_b[2], tw.G1, LD_H, 256, 264, n_rows, rows_max);
+    gemm_forward(st, bf, tw.G1, LD_H, tw.Wp[3], 256, d_b[3], tw.G2, LD_H, 256, 256, n_rows, rows_max);
     hipLaunchKernelGGL(k_train_head_agg, eg, eb, 0, st, P, tw, d_w[4], d_b[4]);
-    gemm_forward(st, tw.XC, LD_XC, tw.Wp[5], 288, d_b[5], tw.C1, LD_C, 128, 288, n_smp, smp_max);
-    gemm_forward(st, tw.C1, LD_C, tw.Wp[6], 128, d_b[6], tw.C2, LD_C, 128, 128, n_smp, smp_max);
-    gemm_forward(st, tw.C2, LD_C, tw.Wp[7], 128, d_b[7], tw.C3, LD_C, 128, 128, n_smp, smp_max);
+    gemm_forward(st, bf, tw.XC, LD_XC, tw.Wp[5], 288, d_b[5], tw.C1, LD_C, 128, 288, n_smp, smp_max);
+    gemm_forward(st, bf, tw.C1, LD_C, tw.Wp[6], 128, d_b[6], tw.C2, LD_C, 128, 128, n_smp, smp_max);
+    gemm_forward(st, bf, tw.C2, LD_C, tw.Wp[7], 128, d_b[7], tw.C3, LD_C, 128, 128, n_smp, smp_max);
     hipLaunchKernelGGL(k_train_color_head, eg, eb, 0, st, tw, d_w[8], d_b[8]);
 
     // ---- backward --------------------------------------------------------------------------------
@@ -902,23 +1050,23 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
     // colour MLP
     hipLaunchKernelGGL(k_train_color_head_bwd, dim3(256), eb, 0, st, tw, d_w[8]);  // C3 <- dZ7
     gemm_weight(st, tw.C3, LD_C, tw.C2, LD_C, tw.dWp[7], 128, 128, 128, n_smp, smp_max, tw.dbp[7]);
-    gemm_data(st, tw.C3, LD_C, tw.Wp[7], 128, tw.C2, LD_C, 128, 128, 128, n_smp, smp_max);  // C2 <- dZ6
+    gemm_data(st, bf, tw.C3, LD_C, tw.Wp[7], 128, tw.WT[7], tw.C2, LD_C, 128, 128, 128, n_smp, smp_max);  // C2 <- dZ6
     gemm_weight(st, tw.C2, LD_C, tw.C1, LD_C, tw.dWp[6], 128, 128, 128, n_smp, smp_max, tw.dbp[6]);
-    gemm_data(st, tw.C2, LD_C, tw.Wp[6], 128, tw.C1, LD_C, 128, 128, 128, n_smp, smp_max);  // C1 <- dZ5
+    gemm_data(st, bf, tw.C2, LD_C, tw.Wp[6], 128, tw.WT[6], tw.C1, LD_C, 128, 128, 128, n_smp, smp_max);  // C1 <- dZ5
     gemm_weight(st, tw.C1, LD_C, tw.XC, LD_XC, tw.dWp[5], 288, 128, 288, n_smp, smp_max, tw.dbp[5]);
-    gemm_data(st, tw.C1, LD_C, tw.Wp[5], 288, tw.XC, LD_XC, 256, 128, 0, n_smp, smp_max);   // XC[:, :256] <- dAGG
+    gemm_data(st, bf, tw.C1, LD_C, tw.Wp[5], 288, tw.WT[5], tw.XC, LD_XC, 256, 128, 0, n_smp, smp_max);   // XC[:, :256] <- dAGG
     // density head + aggregation
     hipLaunchKernelGGL(k_train_head_agg_bwd, dim3(2048), eb, 0, st, tw, K, d_w[4]);          // G2 <- dZ4
     // mlp_head
     gemm_weight(st, tw.G2, LD_H, tw.G1, LD_H, tw.dWp[3], 256, 256, 256, n_rows, rows_max, tw.dbp[3]);
-    gemm_data(st, tw.G2, LD_H, tw.Wp[3], 256, tw.G1, LD_H, 256, 256, 256, n_rows, rows_max);   // G1 <- dZ3
+    gemm_data(st, bf, tw.G2, LD_H, tw.Wp[3], 256, tw.WT[3], tw.G1, LD_H, 256, 256, 256, n_rows, rows_max);   // G1 <- dZ3
     gemm_weight(st, tw.G1, LD_H, tw.H2, LD_H2, tw.dWp[2], 264, 256, 264, n_rows, rows_max, tw.dbp[2]);
-    gemm_data(st, tw.G1, LD_H, tw.Wp[2], 264, tw.H2, LD_H2, 264, 256, 256, n_rows, rows_max);  // H2 <- [dZ2 | d extras]
+    gemm_data(st, bf, tw.G1, LD_H, tw.Wp[2], 264, tw.WT[2], tw.H2, LD_H2, 264, 256, 256, n_rows, rows_max);  // H2 <- [dZ2 | d extras]
     // mlp_base
     gemm_weight(st, tw.H2, LD_H2, tw.H1, LD_H, tw.dWp[1], 256, 256, 256, n_rows, rows_max, tw.dbp[1]);
-    gemm_data(st, tw.H2, LD_H2, tw.Wp[1], 256, tw.H1, LD_H, 256, 256, 256, n_rows, rows_max);  // H1 <- dZ1
+    gemm_data(st, bf, tw.H2, LD_H2, tw.Wp[1], 256, tw.WT[1], tw.H1, LD_H, 256, 256, 256, n_rows, rows_max);  // H1 <- dZ1
     gemm_weight(st, tw.H1, LD_H, tw.X0, LD_X0, tw.dWp[0], 288, 256, 288, n_rows, rows_max, tw.dbp[0]);
-    gemm_data(st, tw.H1, LD_H, tw.Wp[0], 288, tw.G2, LD_H, 224, 256, 0, n_rows, rows_max);     // G2 <- dX0[:, :224]
+    gemm_data(st, bf, tw.H1, LD_H, tw.Wp[0], 288, tw.WT[0], tw.G2, LD_H, 224, 256, 0, n_rows, rows_max);     // G2 <- dX0[:, :224]
     // point tensors
     hipLaunchKernelGGL(k_train_scatter, eg, eb, 0, st, P, tw, grads->d_embedding, grads->d_color, grads->d_dir);
     // weight gradients out of the padded buffers

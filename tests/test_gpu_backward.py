@@ -2,8 +2,9 @@
 autograd through the CPU oracle of NeuralPoints.forward + PointNerf.get_outputs (studio_model.py:263-399,
 studio_utils.py:190-209) -- the very computation `ns-train pointnerf-original` differentiates.
 
-Tolerance: every gradient tensor within 2e-3 of its own largest magnitude (fp32 MFMA products summed in a
-different order than torch's CPU GEMMs, float atomics), the recomputed image within 1e-4 abs."""
+Tolerance: fp32 mode -- every gradient tensor within 2e-3 of its own largest magnitude (fp32 MFMA products summed
+in a different order than torch's CPU GEMMs, float atomics; measured ~1e-6); bf16x3 mode -- see BF16X3_* below; the
+recomputed image within 1e-4 abs in both."""
 import pytest
 import torch
 
@@ -31,20 +32,35 @@ def _oracle_grads(oracle, pts, w, cfg, campos, camrot, dirs, G, training, jitter
     return ref, grads
 
 
-def _compare(name, got, want):
+# bf16x3 backward: the MLP forward is recomputed with 2^-16-relative products, so a few hundred of the ~70 M
+# pre-activations that lie within ~1e-5 of zero land on the other side of the LeakyReLU kink than in the fp32 oracle;
+# each such unit changes its own gradient contribution by 0.9x.  The gradient is exact for the function the bf16x3
+# mode computes; against the fp32 oracle it shows as ~sqrt(flipped fraction) = a few 1e-3 in relative L2 and up to a
+# few 1e-2 of the largest magnitude on single entries (tensors behind few kinks -- colour MLP, heads -- agree to 1e-5).
+BF16X3_L2_TOL = 2e-2
+BF16X3_MAX_TOL = 1e-1
+
+
+def _compare(name, got, want, bf16x3=False):
     scale = want.abs().max().item()
     err = (got - want).abs().max().item()
     assert scale > 0, f"{name}: the oracle gradient is identically zero (test scene too empty)"
+    if bf16x3:
+        l2 = (got - want).norm().item() / want.norm().item()
+        assert l2 <= BF16X3_L2_TOL and err <= BF16X3_MAX_TOL * scale, \
+            f"{name}: rel L2 {l2:.3e}, max abs err {err:.3e} vs scale {scale:.3e}"
+        return l2
     assert err <= GRAD_REL_TOL * scale, f"{name}: max abs err {err:.3e} vs scale {scale:.3e} ({err / scale:.2e} rel)"
     return err / scale
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])   # arithmetic of the backward's forward / data GEMMs
 @pytest.mark.parametrize("N,SR,K,P,H,W,az,training", [
     (60000, 80, 8, 12, 24, 24, 35.0, True),      # training composite (no clamp)
     (50000, 32, 8, 12, 32, 32, 200.0, False),    # eval clamp: gradient passes only inside [0, 1]
     (200000, 24, 12, 26, 20, 20, 300.0, True),   # K = 12
 ])
-def test_backward_matches_oracle_autograd(oracle, gpu_device, N, SR, K, P, H, W, az, training):
+def test_backward_matches_oracle_autograd(oracle, gpu_device, N, SR, K, P, H, W, az, training, precision):
     pts = small_scene(N)
     cfg = oracle_cfg(oracle, SR=SR, K=K, P=P)
     w = synthetic.make_weights(0, sigma_scale=300.0, bias_scale=0.1)
@@ -56,7 +72,7 @@ def test_backward_matches_oracle_autograd(oracle, gpu_device, N, SR, K, P, H, W,
 
     scene, wh, hyp, info = build_hip(pts, cfg, gpu_device, weights=w)
     rnd = RendererHIP(scene, wh, SR=SR, K=K, D=cfg.z_depth_dim, radius_limit=float(oracle.radius_limit(cfg)),
-                      vsize_z=cfg.vsize[2], precision="fp32", eval_clamp=not training)
+                      vsize_z=cfg.vsize[2], precision=precision, eval_clamp=not training)
     out = rnd.render(dirs.to(gpu_device), campos, camrot, 2.0, 6.0)
     assert out["counters"]["overflow"] == 0
     got = rnd.backward(G.to(gpu_device), w, pts["xyz"].shape[0])
@@ -66,16 +82,20 @@ def test_backward_matches_oracle_autograd(oracle, gpu_device, N, SR, K, P, H, W,
     err2 = (got["rgb"] - out["rgb"]).abs().max().item()
     assert err2 <= 1e-4, f"recomputed image differs from pnr_render by {err2:.3e}"
     rel = {}
+    bf = precision == "bf16x3"
     for k in ("embedding", "color", "dir"):
-        rel[k] = _compare(k, got[k].cpu(), want[k])
+        rel[k] = _compare(k, got[k].cpu(), want[k], bf)
     for name in MLP_TENSOR_ORDER:
         for suf in (".weight", ".bias"):
-            rel[name + suf] = _compare(name + suf, got[name + suf].cpu(), want[name + suf])
+            rel[name + suf] = _compare(name + suf, got[name + suf].cpu(), want[name + suf], bf)
+    if bf:   # few kinks between these tensors and the loss: plain arithmetic agreement
+        for name in ("mlp_color.layers.0", "mlp_color.layers.2", "field_output_color.net", "field_output_density.net"):
+            assert rel[name + ".weight"] <= 2e-4, (name, rel[name + ".weight"])
     print("relative gradient errors:", {k: f"{v:.1e}" for k, v in rel.items()})
 
 
 def test_backward_after_bf16x3_render_and_accumulation(oracle, gpu_device):
-    """The render may run in the default bf16x3 mode (the backward recomputes in fp32 from its sample lists), and a
+    """After a render in the default bf16x3 mode the backward runs its forward / data GEMMs in bf16x3 too, and a
     second backward call with other cotangents returns the gradients of THAT call (buffers are fresh zeros)."""
     N, SR, K, P = 60000, 80, 8, 12
     pts = small_scene(N)
@@ -93,9 +113,9 @@ def test_backward_after_bf16x3_render_and_accumulation(oracle, gpu_device):
     got = rnd.backward(G.to(gpu_device), w, N)
     assert (first["embedding"] - got["embedding"]).abs().max().item() > 0
     for k in ("embedding", "color", "dir"):
-        _compare(k, got[k].cpu(), want[k])
+        _compare(k, got[k].cpu(), want[k], True)
     for name in MLP_TENSOR_ORDER:
-        _compare(name + ".weight", got[name + ".weight"].cpu(), want[name + ".weight"])
+        _compare(name + ".weight", got[name + ".weight"].cpu(), want[name + ".weight"], True)
 
 
 def test_backward_rejects_bad_arguments(oracle, gpu_device):
