@@ -22,6 +22,12 @@
 
 namespace pnr {
 
+// diagnostic builds only (results wrong by construction): bit0 = no epilogue memory traffic, bit1 = no MFMA in the
+// bf16x3 row GEMM
+#ifndef PNR_GEMM_ABL
+#define PNR_GEMM_ABL 0
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // fp32 MFMA GEMM   C[M,N] = op(A) . op(B)      (all matrices row-major, leading dimensions multiples of 4)
 //   TA = false: A is [M, K] (tile rows m, contiguous k)     TA = true: A is [K, M] (A'[m][k] = A[k][m])
@@ -56,17 +62,29 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, const f32x16 (&
             const int col = n0 + wn * 64 + b * 32 + j;
             if (col >= N) continue;
             const float bias = (EPI == EPI_BIAS_LEAKY) ? g.bias[col] : 0.f;
+            // the mask is the taped activation this GEMM overwrites (mask == C): all 16 loads of the block are issued
+            // BEFORE its first store -- interleaved, every load waited behind the store in front of it (they may
+            // alias as far as the compiler knows) and the epilogue ran at one memory latency per element
+            float mk[16];
+            if (EPI == EPI_MASK) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    mk[r] = (row < M && col < g.mask_cols) ? g.mask[(int64_t)row * g.ldc + col] : 1.0f;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (row >= M) continue;
                 float v = acc[a][b][r];
+                if ((PNR_GEMM_ABL & 1) && v != 12345.678f) continue;
                 float *dst = g.C + (int64_t)row * g.ldc + col;
                 if (EPI == EPI_BIAS_LEAKY) {
                     v += bias;
                     v = v > 0.f ? v : 0.1f * v;
                 } else if (EPI == EPI_MASK) {
-                    if (col < g.mask_cols) v *= (g.mask[(int64_t)row * g.ldc + col] > 0.f) ? 1.0f : 0.1f;
+                    v *= mk[r] > 0.f ? 1.0f : 0.1f;
                 }
                 if (EPI == EPI_ATOMIC)
                     unsafeAtomicAdd(dst, v);
@@ -312,6 +330,10 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16x3(GemmArgs g)
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
+                    if (PNR_GEMM_ABL & 2) {
+                        asm volatile("" ::"v"(ah[a]), "v"(al[a]), "v"(bh[b]), "v"(bl[b]));
+                        continue;
+                    }
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
