@@ -358,9 +358,11 @@ def main():
                           "rays_per_sec": n_rays / ((f_ms + b_ms) * 1e-3), "pairs_valid": c["pairs_valid"],
                           "samples_valid": c["samples_valid"],
                           "backward_tflops": bwd_flops / (b_ms * 1e-3) / 1e12,
-                          "note": "backward = fp32 recompute of the MLPs with a row-major tape + data and weight "
-                                  "gradients (3 x the forward FLOPs) on v_mfma_f32_32x32x2_f32 GEMMs, peak 157.3; time "
-                                  "includes zero-filling the dense [N,32] gradient"})
+                          "mode": args.precision,
+                          "note": "backward = recompute of the MLPs with a row-major tape + data and weight gradients "
+                                  "(3 x the forward FLOPs) as GEMMs: fp32 mode v_mfma_f32_32x32x2_f32 throughout (peak "
+                                  "157.3); bf16x3 mode forward / data gradients on bf16 hi/lo splits, weight gradients "
+                                  "fp32; time includes zero-filling the dense [N,32] gradient"})
             del rnd_t
 
     if rank == 0 or emulate:
