@@ -6,7 +6,8 @@
 //
 // First HIP version of this row: correct and matrix-core bound, not yet fused.  The query products of the
 // preceding pnr_render call (sample lists, neighbour indices) are taken from its workspace; the MLP forward is
-// recomputed in fp32 with every activation kept ROW-MAJOR in HBM (the "tape"), then walked backwards:
+// recomputed (fp32, or bf16x3 as the render's default mode) with every activation kept ROW-MAJOR in HBM (the "tape"),
+// then walked backwards:
 //   * every Linear is one of three shapes of ONE hand-written fp32 MFMA GEMM (k_gemm: 128x128 tiles,
 //     v_mfma_f32_32x32x2_f32, LDS double buffer): forward X.W^T (+bias, LeakyReLU), data gradient dZ.W (times
 //     LeakyReLU' from the taped activation, written IN PLACE over that activation), weight gradient dZ^T.X
