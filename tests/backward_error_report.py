@@ -1,3 +1,5 @@
+"""Not a test: per-tensor gradient errors of pnr_render_backward in both arithmetic modes against autograd through the
+CPU oracle (run on a GPU box: python tests/backward_error_report.py).  Lives under tests/ because it uses the oracle."""
 import sys, os
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [root, os.path.join(root, "tests"), os.path.join(root, "oracle")]
