@@ -36,7 +36,7 @@ namespace pnr {
 // The row count that comes from the device (pairs / samples of the call) is read from *dev_rows: it is M when
 // TA = false and the reduction length K when TA = true (weight gradients, split over gridDim.z).
 // ------------------------------------------------------------------------------------------------
-enum { EPI_STORE = 0, EPI_BIAS_LEAKY = 1, EPI_MASK = 2, EPI_ATOMIC = 3 };
+enum { EPI_STORE = 0, EPI_BIAS_LEAKY = 1, EPI_MASK = 2, EPI_PARTIAL = 3 };
 
 struct GemmArgs {
     const float *A;
@@ -48,7 +48,7 @@ struct GemmArgs {
     const float *bias;      // EPI_BIAS_LEAKY
     const float *mask;      // EPI_MASK: taped post-activation, same leading dimension as C
     int mask_cols;          // columns >= mask_cols pass unmasked
-    float *colsum;          // TA only, may be null: colsum[m] += sum_k A[k][m]  (bias gradient = dZ^T . 1)
+    float *colsum;          // TA only, may be null: colsum[z][m] = sum over split z's rows of A[k][m]  (bias gradient)
 };
 
 // accumulator register r of lane (j, h): row (r & 3) + 8 (r >> 2) + 4 h, column j of the 32x32 block
@@ -87,10 +87,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, const f32x16 (&
                 } else if (EPI == EPI_MASK) {
                     v *= mk[r] > 0.f ? 1.0f : 0.1f;
                 }
-                if (EPI == EPI_ATOMIC)
-                    unsafeAtomicAdd(dst, v);
-                else
-                    *dst = v;
+                *dst = v;
             }
         }
 }
@@ -103,6 +100,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, const f32x16 (&
 #endif
 constexpr int TM = 128, TN = 128, TK = PNR_GEMM_TK, LDT = TM + 4;
 constexpr int NLD = TK / 8;   // float4 loads per thread and operand per chunk
+
+// weight gradients: the grid offers gridDim.z splits of the rows (sized for the workspace capacity); a split is worth
+// its fixed costs (prologue, a 64-KB partial tile) only with >= 256 rows, so the kernel and the reducer agree on
+// this number from the row count found on the device
+constexpr int MIN_ROWS_PER_SPLIT = 256;
+__device__ __forceinline__ int active_splits(int rows, int nz_grid)
+{
+    return min(nz_grid, max(1, (rows + MIN_ROWS_PER_SPLIT - 1) / MIN_ROWS_PER_SPLIT));
+}
 
 template <bool TA, bool TB, int EPI>
 __global__ void __launch_bounds__(256, PNR_GEMM_WGS) k_gemm(GemmArgs g)
@@ -128,7 +134,8 @@ __global__ void __launch_bounds__(256, PNR_GEMM_WGS) k_gemm(GemmArgs g)
     int k_begin = 0, k_end = TA ? rows : g.K;
     if (TA) {
         // split of the reduction over gridDim.z, in multiples of TK
-        const int nz = gridDim.z;
+        const int nz = active_splits(rows, gridDim.z);
+        if ((int)blockIdx.z >= nz) return;
         const int chunk = ((rows + nz - 1) / nz + TK - 1) / TK * TK;
         k_begin = min(rows, (int)blockIdx.z * chunk);
         k_end = min(rows, k_begin + chunk);
@@ -226,17 +233,62 @@ __global__ void __launch_bounds__(256, PNR_GEMM_WGS) k_gemm(GemmArgs g)
         __syncthreads();
     }
     if (want_csum) {
-        // bias gradient: every thread summed the A elements it loaded (columns m0 + 4 (tid & 31) .. + 3)
-        const int m = m0 + (tid & 31) * 4;
-        if (m < M) {
-            unsafeAtomicAdd(g.colsum + m + 0, csum.x);
-            unsafeAtomicAdd(g.colsum + m + 1, csum.y);
-            unsafeAtomicAdd(g.colsum + m + 2, csum.z);
-            unsafeAtomicAdd(g.colsum + m + 3, csum.w);
-        }
+        // bias gradient: every thread summed the A elements it loaded (columns m0 + 4 (tid & 31) .. + 3, eight threads
+        // per column group): folded in LDS, one partial row per split (global atomics here meant 6 k adds per address)
+        float *cs = &As[0][0][0];
+        if (tid < TM) cs[tid] = 0.f;
+        __syncthreads();
+        const int c4 = (tid & 31) * 4;
+        atomicAdd(&cs[c4 + 0], csum.x);
+        atomicAdd(&cs[c4 + 1], csum.y);
+        atomicAdd(&cs[c4 + 2], csum.z);
+        atomicAdd(&cs[c4 + 3], csum.w);
+        __syncthreads();
+        if (tid < TM && m0 + tid < M) g.colsum[(int64_t)blockIdx.z * g.M + m0 + tid] = cs[tid];
     }
+    if (EPI == EPI_PARTIAL) {
+        // weight gradients: split z writes its partial [M, ldc] block; k_reduce_parts sums the blocks (12.6 M float
+        // atomics per GEMM -- 768 workgroups x 16 K -- cost more than the GEMM itself at training-batch sizes)
+        GemmArgs gp = g;
+        gp.C = g.C + (int64_t)blockIdx.z * g.M * g.ldc;
+        gemm_epilogue<EPI>(gp, acc, M, N, m0, n0, wm, wn, j, h);
+    } else {
+        gemm_epilogue<EPI>(g, acc, M, N, m0, n0, wm, wn, j, h);
+    }
+    }
+}
 
-    gemm_epilogue<EPI>(g, acc, M, N, m0, n0, wm, wn, j, h);
+// dst[m][n] += sum over the active splits of part[z][m][n]  (part: [nz, M, ld], dst: [M, ld]);
+// db[m] += sum over the active splits of csum[z][m]
+__global__ void __launch_bounds__(256) k_reduce_parts(const float *__restrict__ part, const float *__restrict__ csum,
+                                                      int nz_grid, int M, int N, int ld,
+                                                      const int *__restrict__ dev_rows, float *__restrict__ dst,
+                                                      float *__restrict__ db)
+{
+    const int rows = *dev_rows;
+    const int nz = active_splits(rows, nz_grid);
+    const int chunk = ((rows + nz - 1) / nz + TK - 1) / TK * TK;
+    const int used = chunk > 0 ? min(nz, (rows + chunk - 1) / chunk) : 0;   // splits with k_begin < rows
+    const int n = M * ld;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n + M; i += gridDim.x * blockDim.x) {
+        const bool is_b = i >= n;
+        if (!is_b && i % ld >= N) continue;
+        const float *src = is_b ? csum + (i - n) : part + i;
+        const int stride = is_b ? M : n;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int z = 0;
+        for (; z + 4 <= used; z += 4) {   // four independent loads in flight
+            a0 += src[(int64_t)(z + 0) * stride];
+            a1 += src[(int64_t)(z + 1) * stride];
+            a2 += src[(int64_t)(z + 2) * stride];
+            a3 += src[(int64_t)(z + 3) * stride];
+        }
+        for (; z < used; ++z) a0 += src[(int64_t)z * stride];
+        const float t = (a0 + a1) + (a2 + a3);
+        if (is_b)
+            db[i - n] += t;
+        else
+            dst[i] += t;
     }
 }
 
@@ -356,6 +408,10 @@ static const int W_OUT[9] = {256, 256, 256, 256, 1, 128, 128, 128, 3};
 static const int W_IN[9] = {284, 256, 263, 256, 256, 280, 128, 128, 128};
 static const int W_LD[9] = {288, 256, 264, 256, 256, 288, 128, 128, 128};
 
+constexpr int MAX_SPLIT_WGS = 768;                                  // workgroups of one weight-gradient GEMM
+constexpr size_t PART_FLOATS = (size_t)MAX_SPLIT_WGS * TM * TN;     // their partial tiles
+constexpr size_t CSUM_FLOATS = (size_t)MAX_SPLIT_WGS * 256;         // + one partial bias-gradient row per split
+
 struct TrainWs {
     int *cnt;        // [0] rows = S * K, [1] S valid samples
     int *s2v;        // [cap] sample index -> valid index or -1
@@ -371,6 +427,7 @@ struct TrainWs {
     float *XC, *C1, *C2, *C3;       // [cap, ld]
     float *Wp[9], *dWp[9], *dbp[9];
     float *WT[9];                   // W^T, [W_LD (inputs, zero rows beyond in) , out]: B operand of the bf16x3 data GEMMs
+    float *part;                    // partial tiles of the weight-gradient GEMM in flight: [splits, M, ld]
     float *dw_begin;                // dWp / dbp are contiguous: [dw_begin, dw_begin + dw_floats)
     size_t dw_floats;
     size_t total;
@@ -408,6 +465,7 @@ static TrainWs carve_train_ws(void *base, int64_t cap, int K)
     w.C3 = (float *)take(smp * LD_C * 4);
     for (int i = 0; i < 9; ++i) w.Wp[i] = (float *)take((size_t)W_OUT[i] * W_LD[i] * 4);
     for (int i = 0; i < 9; ++i) w.WT[i] = (float *)take((size_t)W_OUT[i] * W_LD[i] * 4);
+    w.part = (float *)take((size_t)(PART_FLOATS + CSUM_FLOATS) * 4);
     const size_t dw0 = off;
     for (int i = 0; i < 9; ++i) w.dWp[i] = (float *)take((size_t)W_OUT[i] * W_LD[i] * 4);
     for (int i = 0; i < 9; ++i) w.dbp[i] = (float *)take((size_t)W_OUT[i] * 4);
@@ -830,11 +888,29 @@ __global__ void __launch_bounds__(256) k_train_head_agg_bwd(TrainWs w, int K, co
             *gp = o;
         }
     }
-    unsafeAtomicAdd(w.dWp[4] + 4 * lane + 0, dw.x);
-    unsafeAtomicAdd(w.dWp[4] + 4 * lane + 1, dw.y);
-    unsafeAtomicAdd(w.dWp[4] + 4 * lane + 2, dw.z);
-    unsafeAtomicAdd(w.dWp[4] + 4 * lane + 3, dw.w);
-    if (lane == 0) unsafeAtomicAdd(w.dbp[4], db);
+    // one set of atomics per workgroup (8192 waves x 257 atomics on 257 addresses took 0.8 ms, whatever the batch)
+    __shared__ float4 red[4][64];
+    __shared__ float redb[4];
+    const int wave = threadIdx.x >> 6;
+    red[wave][lane] = dw;
+    if (lane == 0) redb[wave] = db;
+    __syncthreads();
+    if (wave == 0) {
+        float4 t = red[0][lane];
+        float tb = redb[0];
+        for (int q = 1; q < 4; ++q) {
+            t.x += red[q][lane].x;
+            t.y += red[q][lane].y;
+            t.z += red[q][lane].z;
+            t.w += red[q][lane].w;
+            tb += redb[q];
+        }
+        unsafeAtomicAdd(w.dWp[4] + 4 * lane + 0, t.x);
+        unsafeAtomicAdd(w.dWp[4] + 4 * lane + 1, t.y);
+        unsafeAtomicAdd(w.dWp[4] + 4 * lane + 2, t.z);
+        unsafeAtomicAdd(w.dWp[4] + 4 * lane + 3, t.w);
+        if (lane == 0) unsafeAtomicAdd(w.dbp[4], tb);
+    }
 }
 
 // One wavefront per row: gradients of the point tensors, scattered with float atomics (index_select backward).
@@ -936,15 +1012,19 @@ static void gemm_data(hipStream_t st, bool bf, const float *dZ, int lda, const f
 
 // dW[M, N] += dZ[rows, M]^T . X[rows, N];  db[M] += column sums of dZ
 static void gemm_weight(hipStream_t st, const float *dZ, int lda, const float *X, int ldx, float *dW, int ldw, int M,
-                        int N, const int *dev_rows, int64_t rows_max, float *db)
+                        int N, const int *dev_rows, int64_t rows_max, float *db, float *part)
 {
     GemmArgs g{};
-    g.A = dZ; g.B = X; g.C = dW; g.lda = lda; g.ldb = ldx; g.ldc = ldw; g.M = M; g.N = N; g.K = 0;
-    g.dev_rows = dev_rows; g.colsum = db;
+    g.A = dZ; g.B = X; g.C = part; g.lda = lda; g.ldb = ldx; g.ldc = ldw; g.M = M; g.N = N; g.K = 0;
+    g.dev_rows = dev_rows; g.colsum = part + PART_FLOATS;
     const int tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
-    int nsplit = (int)std::min<int64_t>(std::max<int64_t>(1, 768 / tiles), (rows_max + 4 * TK - 1) / (4 * TK));
+    int nsplit = (int)std::min<int64_t>(std::max<int64_t>(1, MAX_SPLIT_WGS / tiles), (rows_max + 4 * TK - 1) / (4 * TK));
     nsplit = std::max(nsplit, 1);
-    gemm<true, false, EPI_ATOMIC>(st, g, M, nsplit);
+    // the partial blocks are [M, ldw] each: nsplit * M * ldw <= PART_FLOATS by construction (ldw <= tiles-per-row * TN)
+    while ((size_t)nsplit * M * ldw > PART_FLOATS && nsplit > 1) --nsplit;
+    gemm<true, false, EPI_PARTIAL>(st, g, M, nsplit);
+    hipLaunchKernelGGL(k_reduce_parts, dim3(288), dim3(256), 0, st, part, part + PART_FLOATS, nsplit, M, N, ldw, dev_rows,
+                       dW, db);
 }
 
 }  // namespace pnr
@@ -1072,23 +1152,23 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
                        ws.ray_off, ws.ray_flag, ws.smp_loc, ws.n_sel, tw, d_grad_rgb, d_rgb_recomputed);
     // colour MLP
     hipLaunchKernelGGL(k_train_color_head_bwd, dim3(256), eb, 0, st, tw, d_w[8]);  // C3 <- dZ7
-    gemm_weight(st, tw.C3, LD_C, tw.C2, LD_C, tw.dWp[7], 128, 128, 128, n_smp, smp_max, tw.dbp[7]);
+    gemm_weight(st, tw.C3, LD_C, tw.C2, LD_C, tw.dWp[7], 128, 128, 128, n_smp, smp_max, tw.dbp[7], tw.part);
     gemm_data(st, bf, tw.C3, LD_C, tw.Wp[7], 128, tw.WT[7], tw.C2, LD_C, 128, 128, 128, n_smp, smp_max);  // C2 <- dZ6
-    gemm_weight(st, tw.C2, LD_C, tw.C1, LD_C, tw.dWp[6], 128, 128, 128, n_smp, smp_max, tw.dbp[6]);
+    gemm_weight(st, tw.C2, LD_C, tw.C1, LD_C, tw.dWp[6], 128, 128, 128, n_smp, smp_max, tw.dbp[6], tw.part);
     gemm_data(st, bf, tw.C2, LD_C, tw.Wp[6], 128, tw.WT[6], tw.C1, LD_C, 128, 128, 128, n_smp, smp_max);  // C1 <- dZ5
-    gemm_weight(st, tw.C1, LD_C, tw.XC, LD_XC, tw.dWp[5], 288, 128, 288, n_smp, smp_max, tw.dbp[5]);
+    gemm_weight(st, tw.C1, LD_C, tw.XC, LD_XC, tw.dWp[5], 288, 128, 288, n_smp, smp_max, tw.dbp[5], tw.part);
     gemm_data(st, bf, tw.C1, LD_C, tw.Wp[5], 288, tw.WT[5], tw.XC, LD_XC, 256, 128, 0, n_smp, smp_max);   // XC[:, :256] <- dAGG
     // density head + aggregation
-    hipLaunchKernelGGL(k_train_head_agg_bwd, dim3(2048), eb, 0, st, tw, K, d_w[4]);          // G2 <- dZ4
+    hipLaunchKernelGGL(k_train_head_agg_bwd, dim3(1024), eb, 0, st, tw, K, d_w[4]);          // G2 <- dZ4
     // mlp_head
-    gemm_weight(st, tw.G2, LD_H, tw.G1, LD_H, tw.dWp[3], 256, 256, 256, n_rows, rows_max, tw.dbp[3]);
+    gemm_weight(st, tw.G2, LD_H, tw.G1, LD_H, tw.dWp[3], 256, 256, 256, n_rows, rows_max, tw.dbp[3], tw.part);
     gemm_data(st, bf, tw.G2, LD_H, tw.Wp[3], 256, tw.WT[3], tw.G1, LD_H, 256, 256, 256, n_rows, rows_max);   // G1 <- dZ3
-    gemm_weight(st, tw.G1, LD_H, tw.H2, LD_H2, tw.dWp[2], 264, 256, 264, n_rows, rows_max, tw.dbp[2]);
+    gemm_weight(st, tw.G1, LD_H, tw.H2, LD_H2, tw.dWp[2], 264, 256, 264, n_rows, rows_max, tw.dbp[2], tw.part);
     gemm_data(st, bf, tw.G1, LD_H, tw.Wp[2], 264, tw.WT[2], tw.H2, LD_H2, 264, 256, 256, n_rows, rows_max);  // H2 <- [dZ2 | d extras]
     // mlp_base
-    gemm_weight(st, tw.H2, LD_H2, tw.H1, LD_H, tw.dWp[1], 256, 256, 256, n_rows, rows_max, tw.dbp[1]);
+    gemm_weight(st, tw.H2, LD_H2, tw.H1, LD_H, tw.dWp[1], 256, 256, 256, n_rows, rows_max, tw.dbp[1], tw.part);
     gemm_data(st, bf, tw.H2, LD_H2, tw.Wp[1], 256, tw.WT[1], tw.H1, LD_H, 256, 256, 256, n_rows, rows_max);  // H1 <- dZ1
-    gemm_weight(st, tw.H1, LD_H, tw.X0, LD_X0, tw.dWp[0], 288, 256, 288, n_rows, rows_max, tw.dbp[0]);
+    gemm_weight(st, tw.H1, LD_H, tw.X0, LD_X0, tw.dWp[0], 288, 256, 288, n_rows, rows_max, tw.dbp[0], tw.part);
     gemm_data(st, bf, tw.H1, LD_H, tw.Wp[0], 288, tw.WT[0], tw.G2, LD_H, 224, 256, 0, n_rows, rows_max);     // G2 <- dX0[:, :224]
     // point tensors
     hipLaunchKernelGGL(k_train_scatter, eg, eb, 0, st, P, tw, grads->d_embedding, grads->d_color, grads->d_dir);

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for v in "$@"; do
   if [ $v = base ]; then export PNR_LIB=""; else export PNR_LIB="$PWD/pointnerf2studio_amd/_abl/libpnr_$v.so"; fi
   rm -rf gpurun_out/gt_$v
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/gt_$v -- python tools/train_step_bench.py --skip-autograd --steps 4 --warmup 2 --rays 65536 > /dev/null 2> gpurun_out/gt_$v.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/gt_$v -- python tools/train_step_bench.py --skip-autograd --steps 4 --warmup 2 --rays ${RAYS:-65536} > /dev/null 2> gpurun_out/gt_$v.err
   python - <<PY
 import csv,glob
 f=glob.glob("gpurun_out/gt_$v/**/*kernel_stats.csv",recursive=True)[0]
