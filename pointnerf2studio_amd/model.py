@@ -95,6 +95,10 @@ class PointNerfConfig(ModelConfig):
     hip_mlp_mode: str = "bf16x3"   # "bf16x3" (3 bf16 MFMA products per fp32 product) or "fp32" (exact)
     hip_early_stop_eps: float = 0.0  # eval only: > 0 stops shading a ray once its transmittance is below eps
     hip_fused_training: bool = True  # training: fused HIP render + pnr_render_backward instead of torch autograd
+    # opt-in (a behaviour change: the reference discards them, studio_utils.py:84-90): initialise the plugin MLPs from
+    # the `aggregator.*` tensors of the legacy checkpoint (same layer shapes; the legacy net was trained with
+    # LeakyReLU slope 0.01 and a Softplus density, so this is a warm start, not an equivalence)
+    hip_load_aggregator_weights: bool = False
 
     def __post_init__(self):
         if self.path_point_cloud is not None:
@@ -168,7 +172,39 @@ class PointNerf(Model):
         else:
             raise RuntimeError("The point_cloud_path must be specified.")
         self.neural_points = NeuralPoints(state_dict, self._device, self.config)
+        if getattr(self.config, "hip_load_aggregator_weights", False):
+            self.load_aggregator_weights(state_dict)
         self._point_initialized = True
+
+    # legacy PointAggregator module -> plugin module (models/aggregators/point_aggregators.py:193-290 against
+    # studio_model.py:193-221; layer shapes are identical, verified in SURVEY.md section 8c)
+    AGGREGATOR_MAP = {
+        "aggregator.block1.0": "mlp_base.layers.0", "aggregator.block1.2": "mlp_base.layers.1",
+        "aggregator.block3.0": "mlp_head.layers.0", "aggregator.block3.2": "mlp_head.layers.1",
+        "aggregator.alpha_branch.0": "field_output_density.net",
+        "aggregator.color_branch.0": "mlp_color.layers.0", "aggregator.color_branch.2": "mlp_color.layers.1",
+        "aggregator.color_branch.4": "mlp_color.layers.2", "aggregator.color_branch.6": "field_output_color.net",
+    }
+
+    def load_aggregator_weights(self, state_dict: Dict[str, torch.Tensor]) -> int:
+        """Copies the nine Linear layers of a legacy checkpoint's `aggregator.*` into the plugin MLPs; every tensor must
+        be present with the plugin's shape (nothing is partially loaded).  Returns the number of tensors copied."""
+        todo = []
+        for src, dst in self.AGGREGATOR_MAP.items():
+            mod = self.get_submodule(dst)
+            for suf, param in ((".weight", mod.weight), (".bias", mod.bias)):
+                if src + suf not in state_dict:
+                    raise RuntimeError(f"hip_load_aggregator_weights: checkpoint has no {src + suf}")
+                t = state_dict[src + suf]
+                if tuple(t.shape) != tuple(param.shape):
+                    raise RuntimeError(f"hip_load_aggregator_weights: {src + suf} has shape {tuple(t.shape)}, "
+                                       f"{dst + suf} needs {tuple(param.shape)}")
+                todo.append((param, t))
+        with torch.no_grad():
+            for param, t in todo:
+                param.copy_(t.to(param.dtype))
+        self._weights_key = None
+        return len(todo)
 
     def populate_modules(self):
         """studio_model.py:169-237 (metrics modules are outside the hot path and omitted)."""

@@ -148,3 +148,41 @@ def test_loads_reference_checkpoint_layout(tmp_path, monkeypatch):
     assert m.neural_points.points_xyz.shape == (500, 3)
     assert torch.equal(m.neural_points.points_embeding.detach(), sd_new["neural_points.points_embeding"])
     assert not any(k.startswith("aggregator") for k in m.state_dict())
+
+
+def test_optional_aggregator_warm_start(tmp_path, monkeypatch):
+    """hip_load_aggregator_weights (opt-in): the legacy checkpoint's `aggregator.*` Linear
+    layers initialise the plugin MLPs by the name map of SURVEY.md section 8c; a missing or mis-shaped tensor is an
+    error and leaves the model untouched."""
+    from pointnerf2studio_amd import synthetic
+    sd = _state_dict(400)
+    w = synthetic.make_weights(3, sigma_scale=1.0, bias_scale=0.2)
+    for src, dst in PointNerf.AGGREGATOR_MAP.items():
+        sd[src + ".weight"] = w[dst + ".weight"].clone()
+        sd[src + ".bias"] = w[dst + ".bias"].clone()
+    d = tmp_path / "ckpt"
+    d.mkdir()
+    torch.save(sd, d / "100_net_ray_marching.pth")
+    torch.save({"epoch_count": 1, "total_steps": 100}, d / "100_states.pth")
+    orig = PointNerf._init_pointnerf
+
+    def _init(self):
+        self._device = "cpu"
+        orig(self)
+    monkeypatch.setattr(PointNerf, "_init_pointnerf", _init)
+    plain = PointNerf(PointNerfConfig(path_point_cloud=d))
+    assert not torch.equal(plain.mlp_base.layers[0].weight.detach(), w["mlp_base.layers.0.weight"])
+    m = PointNerf(PointNerfConfig(path_point_cloud=d, hip_load_aggregator_weights=True))
+    for name in w:
+        assert torch.equal(m.state_dict()[name], w[name]), name
+    # a checkpoint without the colour head: refused, nothing half-loaded
+    bad = dict(sd)
+    del bad["aggregator.color_branch.6.weight"]
+    before = {k: v.clone() for k, v in plain.state_dict().items()}
+    with pytest.raises(RuntimeError, match="color_branch.6.weight"):
+        plain.load_aggregator_weights(bad)
+    bad = dict(sd)
+    bad["aggregator.block3.0.weight"] = torch.zeros(256, 256)
+    with pytest.raises(RuntimeError, match="shape"):
+        plain.load_aggregator_weights(bad)
+    assert all(torch.equal(v, plain.state_dict()[k]) for k, v in before.items())
