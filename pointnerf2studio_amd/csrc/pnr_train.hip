@@ -52,44 +52,67 @@ struct GemmArgs {
 };
 
 // accumulator register r of lane (j, h): row (r & 3) + 8 (r >> 2) + 4 h, column j of the 32x32 block
+// Epilogue of a 128x128 tile.  In accumulator order (register r of lane (j, h): row (r & 3) + 8 (r >> 2) + 4 h, column j
+// of a 32x32 block) a store instruction writes 4 bytes per lane into two rows; 64 of them per lane (plus 64 loads in
+// the masked shape) made the epilogue 40-60 % of a GEMM.  Each wave therefore passes its 64x64 sub-tile through a
+// private 8-KiB LDS region, 32 rows at a time: written in accumulator order (conflict-free: the lanes of a half wave
+// hold consecutive columns), read back as float4 along the rows -- 16 lanes cover 256 contiguous bytes of a row, one
+// instruction 4 rows, 16 store (and 16 load) instructions of 16 B per lane for the whole sub-tile.
+// `lds_wave`: 32 x 64 floats private to the wave; every wave of the workgroup must have finished with the operand
+// buffers before the call, and the caller synchronises before reusing them.
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, const f32x16 (&acc)[2][2], int M, int N, int m0, int n0,
-                                              int wm, int wn, int j, int h)
+                                              int wm, int wn, int lane, float *lds_wave)
 {
+    const int j = lane & 31, h = lane >> 5;
+    const int rr = lane >> 4, c4 = (lane & 15) * 4;   // read phase: row rr + 4 i, columns c4 .. c4 + 3
+    const int col = n0 + wn * 64 + c4;
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EPI == EPI_BIAS_LEAKY && col < N) bias = *reinterpret_cast<const float4 *>(g.bias + col);
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int col = n0 + wn * 64 + b * 32 + j;
-            if (col >= N) continue;
-            const float bias = (EPI == EPI_BIAS_LEAKY) ? g.bias[col] : 0.f;
-            // the mask is the taped activation this GEMM overwrites (mask == C): all 16 loads of the block are issued
-            // BEFORE its first store -- interleaved, every load waited behind the store in front of it (they may
-            // alias as far as the compiler knows) and the epilogue ran at one memory latency per element
-            float mk[16];
-            if (EPI == EPI_MASK) {
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    mk[r] = (row < M && col < g.mask_cols) ? g.mask[(int64_t)row * g.ldc + col] : 1.0f;
-                }
-            }
+            for (int r = 0; r < 16; ++r)
+                lds_wave[((r & 3) + 8 * (r >> 2) + 4 * h) * 64 + b * 32 + j] = acc[a][b][r];
+        __builtin_amdgcn_wave_barrier();
+        const int row0 = m0 + wm * 64 + a * 32 + rr;
+        // the mask is the taped activation this GEMM overwrites (mask == C): all loads before the first store
+        float4 mk[8];
+        if (EPI == EPI_MASK) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row >= M) continue;
-                float v = acc[a][b][r];
-                if ((PNR_GEMM_ABL & 1) && v != 12345.678f) continue;
-                float *dst = g.C + (int64_t)row * g.ldc + col;
-                if (EPI == EPI_BIAS_LEAKY) {
-                    v += bias;
-                    v = v > 0.f ? v : 0.1f * v;
-                } else if (EPI == EPI_MASK) {
-                    v *= mk[r] > 0.f ? 1.0f : 0.1f;
-                }
-                *dst = v;
+            for (int i = 0; i < 8; ++i) {
+                const int row = row0 + 4 * i;
+                mk[i] = (row < M && col < g.mask_cols) ? *reinterpret_cast<const float4 *>(g.mask + (int64_t)row * g.ldc + col)
+                                                       : make_float4(1.f, 1.f, 1.f, 1.f);
             }
         }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = row0 + 4 * i;
+            float4 v = *reinterpret_cast<const float4 *>(lds_wave + (rr + 4 * i) * 64 + c4);
+            if (row >= M || col >= N) continue;
+            if ((PNR_GEMM_ABL & 1) && v.x != 12345.678f) continue;
+            if (EPI == EPI_BIAS_LEAKY) {
+                v.x += bias.x;
+                v.y += bias.y;
+                v.z += bias.z;
+                v.w += bias.w;
+                v.x = v.x > 0.f ? v.x : 0.1f * v.x;
+                v.y = v.y > 0.f ? v.y : 0.1f * v.y;
+                v.z = v.z > 0.f ? v.z : 0.1f * v.z;
+                v.w = v.w > 0.f ? v.w : 0.1f * v.w;
+            } else if (EPI == EPI_MASK) {
+                v.x *= mk[i].x > 0.f ? 1.0f : 0.1f;
+                v.y *= mk[i].y > 0.f ? 1.0f : 0.1f;
+                v.z *= mk[i].z > 0.f ? 1.0f : 0.1f;
+                v.w *= mk[i].w > 0.f ? 1.0f : 0.1f;
+            }
+            *reinterpret_cast<float4 *>(g.C + (int64_t)row * g.ldc + col) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 #ifndef PNR_GEMM_WGS
@@ -114,6 +137,7 @@ template <bool TA, bool TB, int EPI>
 __global__ void __launch_bounds__(256, PNR_GEMM_WGS) k_gemm(GemmArgs g)
 {
     __shared__ float As[2][TK][LDT];
+    static_assert(2 * TK * LDT >= 4096, "two 8-KiB epilogue regions per operand buffer");
     __shared__ float Bs[2][TK][LDT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -245,16 +269,20 @@ __global__ void __launch_bounds__(256, PNR_GEMM_WGS) k_gemm(GemmArgs g)
         atomicAdd(&cs[c4 + 3], csum.w);
         __syncthreads();
         if (tid < TM && m0 + tid < M) g.colsum[(int64_t)blockIdx.z * g.M + m0 + tid] = cs[tid];
+        __syncthreads();   // cs lies in the epilogue region of wave 0
     }
+    // (the loop's last barrier is behind every read of the operand buffers: they are free for the epilogue)
+    float *lds_wave = (wave < 2 ? &As[0][0][0] : &Bs[0][0][0]) + (wave & 1) * 2048;
     if (EPI == EPI_PARTIAL) {
         // weight gradients: split z writes its partial [M, ldc] block; k_reduce_parts sums the blocks (12.6 M float
         // atomics per GEMM -- 768 workgroups x 16 K -- cost more than the GEMM itself at training-batch sizes)
         GemmArgs gp = g;
         gp.C = g.C + (int64_t)blockIdx.z * g.M * g.ldc;
-        gemm_epilogue<EPI>(gp, acc, M, N, m0, n0, wm, wn, j, h);
+        gemm_epilogue<EPI>(gp, acc, M, N, m0, n0, wm, wn, lane, lds_wave);
     } else {
-        gemm_epilogue<EPI>(g, acc, M, N, m0, n0, wm, wn, j, h);
+        gemm_epilogue<EPI>(g, acc, M, N, m0, n0, wm, wn, lane, lds_wave);
     }
+    __syncthreads();   // before the next tile's operands overwrite the epilogue regions
     }
 }
 
@@ -395,7 +423,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16x3(GemmArgs g)
         if (c + 1 < nchunks) store_tiles(buf ^ 1);
         __syncthreads();
     }
-    gemm_epilogue<EPI>(g, acc, M, N, m0, n0, wm, wn, j, h);
+    gemm_epilogue<EPI>(g, acc, M, N, m0, n0, wm, wn, lane, reinterpret_cast<float *>(&planes[0][0][0][0]) + wave * 2048);
+    __syncthreads();   // before the next tile's operands overwrite the epilogue regions
     }
 }
 
