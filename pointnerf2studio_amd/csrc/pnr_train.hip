@@ -289,13 +289,13 @@ __global__ void __launch_bounds__(256, PNR_GEMM_WGS) k_gemm(GemmArgs g)
 // dst[m][n] += sum over the active splits of part[z][m][n]  (part: [nz, M, ld], dst: [M, ld]);
 // db[m] += sum over the active splits of csum[z][m]
 __global__ void __launch_bounds__(256) k_reduce_parts(const float *__restrict__ part, const float *__restrict__ csum,
-                                                      int nz_grid, int M, int N, int ld,
+                                                      int nz_grid, int gran, int M, int N, int ld,
                                                       const int *__restrict__ dev_rows, float *__restrict__ dst,
                                                       float *__restrict__ db)
 {
     const int rows = *dev_rows;
     const int nz = active_splits(rows, nz_grid);
-    const int chunk = ((rows + nz - 1) / nz + TK - 1) / TK * TK;
+    const int chunk = ((rows + nz - 1) / nz + gran - 1) / gran * gran;   // gran: the GEMM kernel's chunk depth
     const int used = chunk > 0 ? min(nz, (rows + chunk - 1) / chunk) : 0;   // splits with k_begin < rows
     const int n = M * ld;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n + M; i += gridDim.x * blockDim.x) {
@@ -426,6 +426,127 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16x3(GemmArgs g)
     gemm_epilogue<EPI>(g, acc, M, N, m0, n0, wm, wn, lane, reinterpret_cast<float *>(&planes[0][0][0][0]) + wave * 2048);
     __syncthreads();   // before the next tile's operands overwrite the epilogue regions
     }
+}
+
+// Weight gradients in the same arithmetic: C[M, N] (partial of split z) = sum over the split's rows k of A[k][m] B[k][n],
+// both operands K-MAJOR in memory (dZ and the taped input, [rows, features]).  The MFMA wants 8 consecutive k per
+// lane, so the loader transposes in registers: a thread fetches an 8 (k) x 4 (m) block -- eight float4, 512
+// contiguous bytes per row over the 32 threads of a k group -- splits it and writes, for each of its four columns, the
+// 8 k values as ONE 16-byte hi and ONE lo fragment into the k-group-major planes of k_gemm_nt_bf16x3.  Threads
+// 0..127 serve the A operand, 128..255 the B operand.  Splits, partial tiles and partial bias rows as in k_gemm<TA>.
+__global__ void __launch_bounds__(256, 2) k_gemm_tn_bf16x3(GemmArgs g)
+{
+    __shared__ u32x4 planes[2][4][BK / 8][TM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int rows = *g.dev_rows, M = g.M, N = g.N;
+    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
+    const int nz = active_splits(rows, gridDim.z);
+    if ((int)blockIdx.z >= nz) return;
+    const int chunk = ((rows + nz - 1) / nz + BK - 1) / BK * BK;
+    const int k_begin = min(rows, (int)blockIdx.z * chunk), k_end = min(rows, k_begin + chunk);
+    if (k_begin >= k_end) return;
+    const int wm = wave & 1, wn = wave >> 1;
+    const bool isB = tid >= 128;
+    const int t = tid & 127, kg = t >> 5, q4 = (t & 31) * 4;      // this thread's k group and column quad
+    const float *src = isB ? g.B : g.A;
+    const int ld = isB ? g.ldb : g.lda;
+    const int c0 = (isB ? n0 : m0) + q4;
+    const bool col_ok = c0 < (isB ? N : M);
+    const bool want_csum = g.colsum && blockIdx.y == 0 && !isB;
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 rg[8];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = k0 + kg * 8 + i;
+            rg[i] = (col_ok && k < k_end) ? *reinterpret_cast<const float4 *>(src + (int64_t)k * ld + c0)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        const int plane = isB ? 2 : 0;
+        float col[4][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            col[0][i] = rg[i].x;
+            col[1][i] = rg[i].y;
+            col[2][i] = rg[i].z;
+            col[3][i] = rg[i].w;
+            if (want_csum) {
+                csum.x += rg[i].x;
+                csum.y += rg[i].y;
+                csum.z += rg[i].z;
+                csum.w += rg[i].w;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            bf16x8 hv, lv;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const __bf16 hb = (__bf16)col[c][i];
+                hv[i] = hb;
+                lv[i] = (__bf16)(col[c][i] - (float)hb);
+            }
+            planes[buf][plane][kg][q4 + c] = __builtin_bit_cast(u32x4, hv);
+            planes[buf][plane + 1][kg][q4 + c] = __builtin_bit_cast(u32x4, lv);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int nchunks = (k_end - k_begin + BK - 1) / BK;
+    load_tiles(k_begin);
+    store_tiles(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) load_tiles(k_begin + (c + 1) * BK);
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            const int kgs = 2 * s + h;
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                ah[q] = __builtin_bit_cast(bf16x8, planes[buf][0][kgs][wm * 64 + q * 32 + j]);
+                al[q] = __builtin_bit_cast(bf16x8, planes[buf][1][kgs][wm * 64 + q * 32 + j]);
+                bh[q] = __builtin_bit_cast(bf16x8, planes[buf][2][kgs][wn * 64 + q * 32 + j]);
+                bl[q] = __builtin_bit_cast(bf16x8, planes[buf][3][kgs][wn * 64 + q * 32 + j]);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                }
+        }
+        if (c + 1 < nchunks) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+    float *ldsf = reinterpret_cast<float *>(&planes[0][0][0][0]);
+    if (g.colsum && blockIdx.y == 0) {   // uniform over the workgroup
+        float *cs = ldsf + 4 * 2048;     // behind the four epilogue regions
+        if (tid < TM) cs[tid] = 0.f;
+        __syncthreads();
+        if (!isB) {
+            atomicAdd(&cs[q4 + 0], csum.x);
+            atomicAdd(&cs[q4 + 1], csum.y);
+            atomicAdd(&cs[q4 + 2], csum.z);
+            atomicAdd(&cs[q4 + 3], csum.w);
+        }
+        __syncthreads();
+        if (tid < TM && m0 + tid < M) g.colsum[(int64_t)blockIdx.z * g.M + m0 + tid] = cs[tid];
+    }
+    GemmArgs gp = g;
+    gp.C = g.C + (int64_t)blockIdx.z * g.M * g.ldc;
+    gemm_epilogue<EPI_PARTIAL>(gp, acc, M, N, m0, n0, wm, wn, lane, ldsf + wave * 2048);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1040,7 +1161,7 @@ static void gemm_data(hipStream_t st, bool bf, const float *dZ, int lda, const f
 }
 
 // dW[M, N] += dZ[rows, M]^T . X[rows, N];  db[M] += column sums of dZ
-static void gemm_weight(hipStream_t st, const float *dZ, int lda, const float *X, int ldx, float *dW, int ldw, int M,
+static void gemm_weight(hipStream_t st, bool bf, const float *dZ, int lda, const float *X, int ldx, float *dW, int ldw, int M,
                         int N, const int *dev_rows, int64_t rows_max, float *db, float *part)
 {
     GemmArgs g{};
@@ -1051,9 +1172,14 @@ static void gemm_weight(hipStream_t st, const float *dZ, int lda, const float *X
     nsplit = std::max(nsplit, 1);
     // the partial blocks are [M, ldw] each: nsplit * M * ldw <= PART_FLOATS by construction (ldw <= tiles-per-row * TN)
     while ((size_t)nsplit * M * ldw > PART_FLOATS && nsplit > 1) --nsplit;
-    gemm<true, false, EPI_PARTIAL>(st, g, M, nsplit);
-    hipLaunchKernelGGL(k_reduce_parts, dim3(288), dim3(256), 0, st, part, part + PART_FLOATS, nsplit, M, N, ldw, dev_rows,
-                       dW, db);
+    if (bf) {
+        const dim3 grid((unsigned)((M + TM - 1) / TM), (unsigned)((N + TN - 1) / TN), (unsigned)nsplit);
+        hipLaunchKernelGGL(k_gemm_tn_bf16x3, grid, dim3(256), 0, st, g);
+    } else {
+        gemm<true, false, EPI_PARTIAL>(st, g, M, nsplit);
+    }
+    hipLaunchKernelGGL(k_reduce_parts, dim3(288), dim3(256), 0, st, part, part + PART_FLOATS, nsplit, bf ? BK : TK, M, N,
+                       ldw, dev_rows, dW, db);
 }
 
 }  // namespace pnr
@@ -1181,23 +1307,23 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
                        ws.ray_off, ws.ray_flag, ws.smp_loc, ws.n_sel, tw, d_grad_rgb, d_rgb_recomputed);
     // colour MLP
     hipLaunchKernelGGL(k_train_color_head_bwd, dim3(256), eb, 0, st, tw, d_w[8]);  // C3 <- dZ7
-    gemm_weight(st, tw.C3, LD_C, tw.C2, LD_C, tw.dWp[7], 128, 128, 128, n_smp, smp_max, tw.dbp[7], tw.part);
+    gemm_weight(st, bf, tw.C3, LD_C, tw.C2, LD_C, tw.dWp[7], 128, 128, 128, n_smp, smp_max, tw.dbp[7], tw.part);
     gemm_data(st, bf, tw.C3, LD_C, tw.Wp[7], 128, tw.WT[7], tw.C2, LD_C, 128, 128, 128, n_smp, smp_max);  // C2 <- dZ6
-    gemm_weight(st, tw.C2, LD_C, tw.C1, LD_C, tw.dWp[6], 128, 128, 128, n_smp, smp_max, tw.dbp[6], tw.part);
+    gemm_weight(st, bf, tw.C2, LD_C, tw.C1, LD_C, tw.dWp[6], 128, 128, 128, n_smp, smp_max, tw.dbp[6], tw.part);
     gemm_data(st, bf, tw.C2, LD_C, tw.Wp[6], 128, tw.WT[6], tw.C1, LD_C, 128, 128, 128, n_smp, smp_max);  // C1 <- dZ5
-    gemm_weight(st, tw.C1, LD_C, tw.XC, LD_XC, tw.dWp[5], 288, 128, 288, n_smp, smp_max, tw.dbp[5], tw.part);
+    gemm_weight(st, bf, tw.C1, LD_C, tw.XC, LD_XC, tw.dWp[5], 288, 128, 288, n_smp, smp_max, tw.dbp[5], tw.part);
     gemm_data(st, bf, tw.C1, LD_C, tw.Wp[5], 288, tw.WT[5], tw.XC, LD_XC, 256, 128, 0, n_smp, smp_max);   // XC[:, :256] <- dAGG
     // density head + aggregation
     hipLaunchKernelGGL(k_train_head_agg_bwd, dim3(1024), eb, 0, st, tw, K, d_w[4]);          // G2 <- dZ4
     // mlp_head
-    gemm_weight(st, tw.G2, LD_H, tw.G1, LD_H, tw.dWp[3], 256, 256, 256, n_rows, rows_max, tw.dbp[3], tw.part);
+    gemm_weight(st, bf, tw.G2, LD_H, tw.G1, LD_H, tw.dWp[3], 256, 256, 256, n_rows, rows_max, tw.dbp[3], tw.part);
     gemm_data(st, bf, tw.G2, LD_H, tw.Wp[3], 256, tw.WT[3], tw.G1, LD_H, 256, 256, 256, n_rows, rows_max);   // G1 <- dZ3
-    gemm_weight(st, tw.G1, LD_H, tw.H2, LD_H2, tw.dWp[2], 264, 256, 264, n_rows, rows_max, tw.dbp[2], tw.part);
+    gemm_weight(st, bf, tw.G1, LD_H, tw.H2, LD_H2, tw.dWp[2], 264, 256, 264, n_rows, rows_max, tw.dbp[2], tw.part);
     gemm_data(st, bf, tw.G1, LD_H, tw.Wp[2], 264, tw.WT[2], tw.H2, LD_H2, 264, 256, 256, n_rows, rows_max);  // H2 <- [dZ2 | d extras]
     // mlp_base
-    gemm_weight(st, tw.H2, LD_H2, tw.H1, LD_H, tw.dWp[1], 256, 256, 256, n_rows, rows_max, tw.dbp[1], tw.part);
+    gemm_weight(st, bf, tw.H2, LD_H2, tw.H1, LD_H, tw.dWp[1], 256, 256, 256, n_rows, rows_max, tw.dbp[1], tw.part);
     gemm_data(st, bf, tw.H2, LD_H2, tw.Wp[1], 256, tw.WT[1], tw.H1, LD_H, 256, 256, 256, n_rows, rows_max);  // H1 <- dZ1
-    gemm_weight(st, tw.H1, LD_H, tw.X0, LD_X0, tw.dWp[0], 288, 256, 288, n_rows, rows_max, tw.dbp[0], tw.part);
+    gemm_weight(st, bf, tw.H1, LD_H, tw.X0, LD_X0, tw.dWp[0], 288, 256, 288, n_rows, rows_max, tw.dbp[0], tw.part);
     gemm_data(st, bf, tw.H1, LD_H, tw.Wp[0], 288, tw.WT[0], tw.G2, LD_H, 224, 256, 0, n_rows, rows_max);     // G2 <- dX0[:, :224]
     // point tensors
     hipLaunchKernelGGL(k_train_scatter, eg, eb, 0, st, P, tw, grads->d_embedding, grads->d_color, grads->d_dir);
