@@ -361,8 +361,8 @@ def main():
                           "mode": args.precision,
                           "note": "backward = recompute of the MLPs with a row-major tape + data and weight gradients "
                                   "(3 x the forward FLOPs) as GEMMs: fp32 mode v_mfma_f32_32x32x2_f32 throughout (peak "
-                                  "157.3); bf16x3 mode forward / data gradients on bf16 hi/lo splits, weight gradients "
-                                  "fp32; time includes zero-filling the dense [N,32] gradient"})
+                                  "157.3); bf16x3 mode: all three GEMM shapes on bf16 hi/lo splits; time includes zero-filling the "
+                                  "dense [N,32] gradient"})
             del rnd_t
 
     if rank == 0 or emulate:

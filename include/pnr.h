@@ -228,9 +228,8 @@ size_t pnr_backward_workspace_bytes(int64_t cap_samples, int32_t K);
 /* Call after pnr_render / pnr_render_views with the SAME scene, rays, cameras, options, cap_samples and render
  * workspace (its sample lists and neighbour indices are reused; nothing else may have used that workspace in
  * between).  The MLP forward is recomputed with a tape of activations in the arithmetic of opts->precision: FP32 =
- * every product in fp32 (gradients agree with fp32 autograd to ~1e-6 relative); BF16X3 = the forward and the data-gradient
- * GEMMs on bf16 hi/lo splits (3 products, 2^-16 relative; weight gradients stay fp32) -- the gradient of the function
- * that mode renders.  d_w / d_b are the
+ * every product in fp32 (gradients agree with fp32 autograd to ~1e-6 relative); BF16X3 = every GEMM on bf16 hi/lo
+ * splits (3 products, 2^-16 relative) -- the gradient of the function that mode renders.  d_w / d_b are the
  * raw weights (as given to pnr_weights_pack; `weights` only supplies Rw2c), d_grad_rgb [R,3] is d loss / d rgb.
  * opts->early_stop_eps must be 0.  d_rgb_recomputed (may be null) receives the fp32 rgb [R,3] of the recomputed
  * forward.  No host synchronisation; everything is queued on `stream`. */

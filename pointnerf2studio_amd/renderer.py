@@ -335,7 +335,7 @@ class RendererHIP:
         color [N,3], dir [N,3], '<module>.weight', '<module>.bias'} for grad_rgb = d loss / d rgb [R,3].  `state` holds
         the raw MLP tensors the weights were packed from.  What torch autograd derives for studio_model.py:263-399;
         the MLP forward is recomputed in the renderer's precision ('rgb' in the result is that recomputed image; fp32:
-        gradients agree with fp32 autograd to ~1e-6, bf16x3: forward / data-gradient GEMMs on bf16 hi/lo splits)."""
+        gradients agree with fp32 autograd to ~1e-6, bf16x3: the GEMMs on bf16 hi/lo splits)."""
         if getattr(self, "_last", None) is None:
             raise RuntimeError("RendererHIP.backward: no render call to differentiate")
         d, R, arr, n, rc, rays_per_cam, cap = self._last
