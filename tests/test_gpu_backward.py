@@ -224,3 +224,42 @@ def test_backward_accumulates_into_caller_buffers(oracle, gpu_device):
     torch.cuda.synchronize()
     _compare("embedding (+= twice)", emb - 1.0, 2 * once["embedding"])
     _compare("mlp_base.0.weight (+= twice)", w0 - 2.0, 2 * once["mlp_base.layers.0.weight"])
+
+
+def test_backward_edge_cases(oracle, gpu_device):
+    """Rays that hit nothing (zero rows on the device: every kernel and GEMM split must be a no-op), and K = 20 (the
+    generic sample segments of the render, more neighbour slots than a DPP row)."""
+    N = 60000
+    pts = small_scene(N)
+    w = synthetic.make_weights(0, sigma_scale=300.0, bias_scale=0.1)
+    cfg = oracle_cfg(oracle, SR=24, K=8, P=12)
+    scene, wh, hyp, info = build_hip(pts, cfg, gpu_device, weights=w)
+    for precision in ("fp32", "bf16x3"):
+        rnd = RendererHIP(scene, wh, SR=24, K=8, D=cfg.z_depth_dim, radius_limit=float(oracle.radius_limit(cfg)),
+                          vsize_z=cfg.vsize[2], precision=precision, eval_clamp=False)
+        campos, camrot, dirs = camera_rays(16, 16, az=35.0)
+        away = -dirs                                             # looking away from the object
+        out = rnd.render(away.to(gpu_device), campos, camrot, 2.0, 6.0)
+        assert out["counters"]["rays_hit"] == 0
+        got = rnd.backward(torch.ones(away.shape[0], 3, device=gpu_device), w, N)
+        assert torch.equal(got["rgb"], torch.ones_like(got["rgb"]))
+        for k, v in got.items():
+            if k != "rgb":
+                assert torch.isfinite(v).all() and float(v.abs().max()) == 0.0, k
+    # K = 20
+    K = 20
+    cfg = oracle_cfg(oracle, SR=16, K=K, P=26)
+    scene, wh, hyp, info = build_hip(pts, cfg, gpu_device, weights=w)
+    campos, camrot, dirs = camera_rays(16, 16, az=120.0)
+    torch.manual_seed(8)
+    G = torch.randn(dirs.shape[0], 3)
+    ref, want = _oracle_grads(oracle, pts, w, cfg, campos, camrot, dirs, G, True)
+    rnd = RendererHIP(scene, wh, SR=16, K=K, D=cfg.z_depth_dim, radius_limit=float(oracle.radius_limit(cfg)),
+                      vsize_z=cfg.vsize[2], precision="fp32", eval_clamp=False)
+    rnd.render(dirs.to(gpu_device), campos, camrot, 2.0, 6.0)
+    got = rnd.backward(G.to(gpu_device), w, N)
+    assert (got["rgb"].cpu() - ref["coarse_raycolor"]).abs().max().item() <= 1e-4
+    for k in ("embedding", "color", "dir"):
+        _compare(k, got[k].cpu(), want[k])
+    for name in MLP_TENSOR_ORDER:
+        _compare(name + ".weight", got[name + ".weight"].cpu(), want[name + ".weight"])
