@@ -998,12 +998,36 @@ __global__ void __launch_bounds__(256) k_train_color_head_bwd(TrainWs w, const f
 #pragma unroll
         for (int c = 0; c < 3; ++c) db[c] += dz[c];
     }
+    // one partial row [3 x 128 weights | 3 biases] per WAVE, summed by k_reduce_rows (atomics: 1024 adds per address)
+    float *dst = w.part + (int64_t)wv * 388;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        unsafeAtomicAdd(w.dWp[8] + c * 128 + lane, dw[c][0]);
-        unsafeAtomicAdd(w.dWp[8] + c * 128 + 64 + lane, dw[c][1]);
-        if (lane == 0) unsafeAtomicAdd(w.dbp[8] + c, db[c]);
+        dst[c * 128 + lane] = dw[c][0];
+        dst[c * 128 + 64 + lane] = dw[c][1];
+        if (lane == 0) dst[384 + c] = db[c];
     }
+}
+
+// dstA[c] += sum_b part[b * stride + c] for c < na;  dstB[c - na] likewise for na <= c < n
+__global__ void __launch_bounds__(256) k_reduce_rows(const float *__restrict__ part, int nrows, int stride, int n, int na,
+                                                     float *__restrict__ dstA, float *__restrict__ dstB)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int b = 0;
+    for (; b + 4 <= nrows; b += 4) {
+        a0 += part[(int64_t)(b + 0) * stride + c];
+        a1 += part[(int64_t)(b + 1) * stride + c];
+        a2 += part[(int64_t)(b + 2) * stride + c];
+        a3 += part[(int64_t)(b + 3) * stride + c];
+    }
+    for (; b < nrows; ++b) a0 += part[(int64_t)b * stride + c];
+    const float t = (a0 + a1) + (a2 + a3);
+    if (c < na)
+        dstA[c] += t;
+    else
+        dstB[c - na] += t;
 }
 
 // density head + K-aggregation backwards (dAGG arrives in XC[:, 0:256], d sigma in d_out.x):
@@ -1038,7 +1062,8 @@ __global__ void __launch_bounds__(256) k_train_head_agg_bwd(TrainWs w, int K, co
             *gp = o;
         }
     }
-    // one set of atomics per workgroup (8192 waves x 257 atomics on 257 addresses took 0.8 ms, whatever the batch)
+    // per-workgroup partial rows, summed by k_reduce_head (8192 waves x 257 atomics on 257 addresses took 0.8 ms whatever
+    // the batch; one set of atomics per workgroup still 1024 adds per address)
     __shared__ float4 red[4][64];
     __shared__ float redb[4];
     const int wave = threadIdx.x >> 6;
@@ -1055,11 +1080,9 @@ __global__ void __launch_bounds__(256) k_train_head_agg_bwd(TrainWs w, int K, co
             t.w += red[q][lane].w;
             tb += redb[q];
         }
-        unsafeAtomicAdd(w.dWp[4] + 4 * lane + 0, t.x);
-        unsafeAtomicAdd(w.dWp[4] + 4 * lane + 1, t.y);
-        unsafeAtomicAdd(w.dWp[4] + 4 * lane + 2, t.z);
-        unsafeAtomicAdd(w.dWp[4] + 4 * lane + 3, t.w);
-        if (lane == 0) unsafeAtomicAdd(w.dbp[4], tb);
+        float *dst = w.part + (int64_t)blockIdx.x * 260;
+        *reinterpret_cast<float4 *>(dst + 4 * lane) = t;
+        if (lane == 0) dst[256] = tb;
     }
 }
 
@@ -1307,6 +1330,7 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
                        ws.ray_off, ws.ray_flag, ws.smp_loc, ws.n_sel, tw, d_grad_rgb, d_rgb_recomputed);
     // colour MLP
     hipLaunchKernelGGL(k_train_color_head_bwd, dim3(256), eb, 0, st, tw, d_w[8]);  // C3 <- dZ7
+    hipLaunchKernelGGL(k_reduce_rows, dim3(2), eb, 0, st, tw.part, 1024, 388, 387, 384, tw.dWp[8], tw.dbp[8]);
     gemm_weight(st, bf, tw.C3, LD_C, tw.C2, LD_C, tw.dWp[7], 128, 128, 128, n_smp, smp_max, tw.dbp[7], tw.part);
     gemm_data(st, bf, tw.C3, LD_C, tw.Wp[7], 128, tw.WT[7], tw.C2, LD_C, 128, 128, 128, n_smp, smp_max);  // C2 <- dZ6
     gemm_weight(st, bf, tw.C2, LD_C, tw.C1, LD_C, tw.dWp[6], 128, 128, 128, n_smp, smp_max, tw.dbp[6], tw.part);
@@ -1315,6 +1339,7 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
     gemm_data(st, bf, tw.C1, LD_C, tw.Wp[5], 288, tw.WT[5], tw.XC, LD_XC, 256, 128, 0, n_smp, smp_max);   // XC[:, :256] <- dAGG
     // density head + aggregation
     hipLaunchKernelGGL(k_train_head_agg_bwd, dim3(1024), eb, 0, st, tw, K, d_w[4]);          // G2 <- dZ4
+    hipLaunchKernelGGL(k_reduce_rows, dim3(2), eb, 0, st, tw.part, 1024, 260, 257, 256, tw.dWp[4], tw.dbp[4]);
     // mlp_head
     gemm_weight(st, bf, tw.G2, LD_H, tw.G1, LD_H, tw.dWp[3], 256, 256, 256, n_rows, rows_max, tw.dbp[3], tw.part);
     gemm_data(st, bf, tw.G2, LD_H, tw.Wp[3], 256, tw.WT[3], tw.G1, LD_H, 256, 256, 256, n_rows, rows_max);   // G1 <- dZ3
