@@ -332,6 +332,7 @@ def main():
     if world == 1 and not emulate and not args.no_other_mode:
         train = []
         full = synthetic.make_rays(H, W, cams[0][0], cams[0][1]).to(dev)
+        w_dev = {k: v.to(dev) for k, v in weights.items()}   # the trainer's parameters live on the GPU
         gen = torch.Generator().manual_seed(11)
         for n_rays in (4096, 65536):
             pick = torch.randperm(full.shape[0], generator=gen)[:n_rays].to(dev)
@@ -345,7 +346,7 @@ def main():
                 ev[0].record()
                 o = rnd_t.render(dirs_t, cams[0][0], cams[0][1], 2.0, 6.0)
                 ev[1].record()
-                rnd_t.backward(g_rgb, weights, cfgd["N"])
+                rnd_t.backward(g_rgb, w_dev, cfgd["N"])
                 ev[2].record()
                 torch.cuda.synchronize()
                 if it >= 2:
