@@ -18,6 +18,7 @@
 // (studio_utils.py:84-103: only embedding / conf / dir / color are Parameters with requires_grad; conf does not
 // enter the render, studio_model.py:285-292).
 #include <algorithm>
+#include <type_traits>
 
 #include "pnr_shade_common.h"
 
@@ -450,6 +451,140 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16x3(GemmArgs g)
 #endif
     gemm_epilogue<EPI>(g, acc, M, N, m0, n0, wm, wn, lane, reinterpret_cast<float *>(&planes[0][0][0][0]) + wave * 2048);
     __syncthreads();   // before the next tile's operands overwrite the epilogue regions
+    }
+}
+
+// The row GEMM with its chunk loop FULLY UNROLLED (NCH = ceil(K / 32) is 4, 8 or 9 for this network) and THREE register
+// stages: the global loads of chunk c + 3 are issued before the MFMAs of chunk c.  Stamps of the rolled kernel above
+// showed a chunk waiting ~3 k cycles for loads issued one chunk (~2 k cycles) earlier -- a memory round trip is ~4.5 k
+// cycles here; in straight-line code hipcc counts vmcnt exactly (a loop back-edge makes it wait for everything), and
+// the barriers wait for LDS only.
+template <int EPI, int NCH>
+__global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16x3_u(GemmArgs g)
+{
+    __shared__ u32x4 planes[2][4][BK / 8][TM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int M = *g.dev_rows, N = g.N, K = g.K;
+    const int wm = wave & 1, wn = wave >> 1;
+    constexpr int NL = BK / 8;
+    const int n_nt = (N + TN - 1) / TN;
+    const int total = n_nt * ((M + TM - 1) / TM);
+    auto lds_barrier = [] {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    for (int it = blockIdx.x; it < total; it += gridDim.x) {
+        const int m0 = (it / n_nt) * TM, n0 = (it % n_nt) * TN;
+        float4 ra[3][NL], rb[3][NL];
+        const int lr = tid >> 3, lk = (tid & 7) * 4;
+        // branch-free loads (a predicated load is its own basic block, and hipcc then waits vmcnt(0) at every merge):
+        // rows clamped into the matrix, k beyond K read from the row's tail / the next row (every buffer has slack
+        // behind it) -- both replaced by zeros with selects when the chunk is written to LDS
+        const float *pa[NL], *pb[NL];
+        bool oka[NL], okb[NL];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int r = lr + 32 * i;
+            oka[i] = m0 + r < M;
+            okb[i] = n0 + r < N;
+            pa[i] = g.A + (int64_t)min(m0 + r, M - 1) * g.lda + lk;
+            pb[i] = g.B + (int64_t)min(n0 + r, N - 1) * g.ldb + lk;
+        }
+        auto load_tiles = [&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int P = c % 3;
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                ra[P][i] = *reinterpret_cast<const float4 *>(pa[i] + c * BK);
+                rb[P][i] = *reinterpret_cast<const float4 *>(pb[i] + c * BK);
+            }
+        };
+        auto split4 = [](const float4 &v, uint2 &hi, uint2 &lo) {
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            const float x[4] = {v.x, v.y, v.z, v.w};
+            bf16x4 hv, lv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const __bf16 hb = (__bf16)x[i];
+                hv[i] = hb;
+                lv[i] = (__bf16)(x[i] - (float)hb);
+            }
+            hi = __builtin_bit_cast(uint2, hv);
+            lo = __builtin_bit_cast(uint2, lv);
+        };
+        auto store_tiles = [&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int P = c % 3, buf = c & 1;
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const int r = lr + 32 * i;
+                const int kg = lk >> 3, half = (lk >> 2) & 1;
+                uint2 hi, lo;
+                const bool kin = c * BK + lk < K;
+                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                split4((oka[i] && kin) ? ra[P][i] : z4, hi, lo);
+                reinterpret_cast<uint2 *>(&planes[buf][0][kg][r])[half] = hi;
+                reinterpret_cast<uint2 *>(&planes[buf][1][kg][r])[half] = lo;
+                split4((okb[i] && kin) ? rb[P][i] : z4, hi, lo);
+                reinterpret_cast<uint2 *>(&planes[buf][2][kg][r])[half] = hi;
+                reinterpret_cast<uint2 *>(&planes[buf][3][kg][r])[half] = lo;
+            }
+        };
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        auto mfma_chunk = [&](int buf) {
+#pragma unroll
+            for (int s = 0; s < BK / 16; ++s) {
+                const int kg = 2 * s + h;
+                bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    ah[q] = __builtin_bit_cast(bf16x8, planes[buf][0][kg][wm * 64 + q * 32 + j]);
+                    al[q] = __builtin_bit_cast(bf16x8, planes[buf][1][kg][wm * 64 + q * 32 + j]);
+                    bh[q] = __builtin_bit_cast(bf16x8, planes[buf][2][kg][wn * 64 + q * 32 + j]);
+                    bl[q] = __builtin_bit_cast(bf16x8, planes[buf][3][kg][wn * 64 + q * 32 + j]);
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                    }
+            }
+        };
+        // prologue: three chunks in flight, the first one into LDS
+        load_tiles(std::integral_constant<int, 0>());
+        if constexpr (NCH > 1) load_tiles(std::integral_constant<int, 1>());
+        if constexpr (NCH > 2) load_tiles(std::integral_constant<int, 2>());
+        store_tiles(std::integral_constant<int, 0>());
+        lds_barrier();
+        auto step = [&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            if constexpr (c + 3 < NCH) load_tiles(std::integral_constant<int, c + 3>());   // into the stage chunk c left
+            mfma_chunk(c & 1);
+            if constexpr (c + 1 < NCH) store_tiles(std::integral_constant<int, c + 1>());
+            lds_barrier();
+        };
+        step(std::integral_constant<int, 0>());
+        if constexpr (NCH > 1) step(std::integral_constant<int, 1>());
+        if constexpr (NCH > 2) step(std::integral_constant<int, 2>());
+        if constexpr (NCH > 3) step(std::integral_constant<int, 3>());
+        if constexpr (NCH > 4) step(std::integral_constant<int, 4>());
+        if constexpr (NCH > 5) step(std::integral_constant<int, 5>());
+        if constexpr (NCH > 6) step(std::integral_constant<int, 6>());
+        if constexpr (NCH > 7) step(std::integral_constant<int, 7>());
+        if constexpr (NCH > 8) step(std::integral_constant<int, 8>());
+        static_assert(NCH <= 9, "unrolled for K <= 288");
+        gemm_epilogue<EPI>(g, acc, M, N, m0, n0, wm, wn, lane, reinterpret_cast<float *>(&planes[0][0][0][0]) + wave * 2048);
+        lds_barrier();
     }
 }
 
@@ -1170,7 +1305,23 @@ template <int EPI>
 static void gemm_bf(hipStream_t st, const GemmArgs &g, int m_max)
 {
     const unsigned tiles = (unsigned)((g.N + TN - 1) / TN) * (unsigned)((m_max + TM - 1) / TM);
-    hipLaunchKernelGGL((k_gemm_nt_bf16x3<EPI>), dim3(std::min(tiles, (unsigned)PERSISTENT_WGS)), dim3(256), 0, st, g);
+    const dim3 grid(std::min(tiles, (unsigned)PERSISTENT_WGS));
+    const int nch = (g.K + BK - 1) / BK;
+#ifndef PNR_GEMM_ROLLED
+    if (nch == 4) {
+        hipLaunchKernelGGL((k_gemm_nt_bf16x3_u<EPI, 4>), grid, dim3(256), 0, st, g);
+        return;
+    }
+    if (nch == 8) {
+        hipLaunchKernelGGL((k_gemm_nt_bf16x3_u<EPI, 8>), grid, dim3(256), 0, st, g);
+        return;
+    }
+    if (nch == 9) {
+        hipLaunchKernelGGL((k_gemm_nt_bf16x3_u<EPI, 9>), grid, dim3(256), 0, st, g);
+        return;
+    }
+#endif
+    hipLaunchKernelGGL((k_gemm_nt_bf16x3<EPI>), grid, dim3(256), 0, st, g);
 }
 
 static void gemm_forward(hipStream_t st, bool bf, const float *A, int lda, const float *W, int ldw, const float *b,
