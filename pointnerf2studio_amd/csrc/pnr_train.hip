@@ -531,6 +531,26 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16x3_u(GemmArgs g)
                 reinterpret_cast<uint2 *>(&planes[buf][3][kg][r])[half] = lo;
             }
         };
+        // one float4 of chunk c's staged registers (q = 0..7: operand q & 1, row group q >> 1): split + two LDS stores
+        auto store_piece = [&](auto cc, int q) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int P = c % 3, buf = c & 1;
+            const int i = q >> 1;
+            const int r = lr + 32 * i;
+            const int kg = lk >> 3, half = (lk >> 2) & 1;
+            const bool kin = c * BK + lk < K;
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            uint2 hi, lo;
+            if ((q & 1) == 0) {
+                split4((oka[i] && kin) ? ra[P][i] : z4, hi, lo);
+                reinterpret_cast<uint2 *>(&planes[buf][0][kg][r])[half] = hi;
+                reinterpret_cast<uint2 *>(&planes[buf][1][kg][r])[half] = lo;
+            } else {
+                split4((okb[i] && kin) ? rb[P][i] : z4, hi, lo);
+                reinterpret_cast<uint2 *>(&planes[buf][2][kg][r])[half] = hi;
+                reinterpret_cast<uint2 *>(&planes[buf][3][kg][r])[half] = lo;
+            }
+        };
         f32x16 acc[2][2];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -538,7 +558,10 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16x3_u(GemmArgs g)
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-        auto mfma_chunk = [&](int buf) {
+        // the MFMAs of the chunk in LDS buffer `buf`; with NEXT, the split + LDS store of the following chunk is cut into
+        // eight pieces and placed behind each block's three MFMAs: an in-order wave cannot issue VALU work that stands
+        // behind a whole block of MFMAs, and two waves per SIMD did not overlap the two phases on their own
+        auto mfma_chunk = [&](int buf, auto next, auto has_next) {
 #pragma unroll
             for (int s = 0; s < BK / 16; ++s) {
                 const int kg = 2 * s + h;
@@ -554,9 +577,12 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16x3_u(GemmArgs g)
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
                     for (int b = 0; b < 2; ++b) {
+                        __builtin_amdgcn_sched_barrier(0);
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                        if constexpr (decltype(has_next)::value) store_piece(next, 4 * s + 2 * a + b);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
             }
         };
@@ -569,8 +595,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16x3_u(GemmArgs g)
         auto step = [&](auto cc) {
             constexpr int c = decltype(cc)::value;
             if constexpr (c + 3 < NCH) load_tiles(std::integral_constant<int, c + 3>());   // into the stage chunk c left
-            mfma_chunk(c & 1);
-            if constexpr (c + 1 < NCH) store_tiles(std::integral_constant<int, c + 1>());
+            mfma_chunk(c & 1, std::integral_constant<int, (c + 1 < NCH ? c + 1 : c)>(), std::bool_constant<(c + 1 < NCH)>());
             lds_barrier();
         };
         step(std::integral_constant<int, 0>());
