@@ -897,86 +897,91 @@ __device__ __forceinline__ float wave_sum(float v)
 // (studio_model.py:270-286).  Unfilled slots (pidx < 0) get zero inputs and weight 0: their gradient vanishes.
 __global__ void __launch_bounds__(256) k_train_rows(TrainParams P, TrainWs w)
 {
+    // one wavefront per SAMPLE: the sample's position, ray, camera and its K neighbour indices / positions are loaded
+    // once (lane k < K holds slot k) and handed to the K rows with cross-lane reads -- a wavefront per row paid the
+    // four dependent load levels vs_list -> sample -> neighbour list -> point row for every row
     const int lane = threadIdx.x & 63;
     const int wv = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwv = (gridDim.x * blockDim.x) >> 6;
-    const int rows = w.cnt[0], K = P.K;
-    for (int row = wv; row < rows; row += nwv) {
-        const int v = row / K, k = row - v * K;
+    const int S = w.cnt[1], K = P.K;
+    for (int v = wv; v < S; v += nwv) {
         const int s = P.vs_list[v];
         const float4 loc = P.smp_loc[s];
         const int ray = P.smp_ray[s];
-        // normalised weights: every lane < K looks at one slot of the sample
+        const int pk = lane < K ? P.smp_pidx[(int64_t)s * K + lane] : -1;
+        float4 ak = make_float4(0.f, 0.f, 0.f, 0.f);
         float wl = 0.f;
-        if (lane < K) {
-            const int pk = P.smp_pidx[(int64_t)s * K + lane];
-            if (pk >= 0) {
-                const float4 a = P.point_rows[(int64_t)pk * 12];
-                const float dx = a.x - loc.x, dy = a.y - loc.y, dz = a.z - loc.z;
-                wl = 1.0f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-6f);
-            }
+        if (pk >= 0) {
+            ak = P.point_rows[(int64_t)pk * 12];
+            const float dx = ak.x - loc.x, dy = ak.y - loc.y, dz = ak.z - loc.z;
+            wl = 1.0f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-6f);
         }
-        const float wsum = wave_sum(wl);
-        const float wk = __shfl(wl, k, 64) / fmaxf(wsum, 1e-8f);
-        const int pidx = P.smp_pidx[(int64_t)s * K + k];
-        const bool valid = pidx >= 0;
-        const float4 *prow = P.point_rows + (int64_t)max(pidx, 0) * 12;
-        const float4 a0 = prow[0], c0 = prow[1], c1 = prow[2];
-        const float *emb = reinterpret_cast<const float *>(prow + 4);
+        const float wsum = fmaxf(wave_sum(wl), 1e-8f);
         const Camera cam = load_cam(P.cr, cam_id(P.cr, ray));
-        const float dwx = a0.x - loc.x, dwy = a0.y - loc.y, dwz = a0.z - loc.z;
-        float dd[6];
-        rot_rows(P.Rw2c, dwx, dwy, dwz, dd[0], dd[1], dd[2]);
-        {
-            float pcx, pcy, pcz, scx, scy, scz;
-            to_cam(cam, a0.x, a0.y, a0.z, pcx, pcy, pcz);
-            to_cam(cam, loc.x, loc.y, loc.z, scx, scy, scz);
-            const float ppx = pcx / pcz, ppy = pcy / pcz, spx = scx / scz, spy = scy / scz;
-            dd[3] = ppx * pcz - spx * scz;
-            dd[4] = ppy * pcz - spy * scz;
-            dd[5] = pcz - scz;
-        }
-        float *x0 = w.X0 + (int64_t)row * LD_X0;
-        // columns 32 + 2u, 32 + 2u + 1 = (sin, cos) pair u: u < 96 embedding channel u / 3 at octave u % 3,
-        // u >= 96 distance component (u - 96) / 5 at octave (u - 96) % 5 -- one sincosf per pair
-        if (lane < 32) x0[lane] = valid ? emb[lane] : 0.f;
-        if (lane < 4) x0[284 + lane] = 0.f;
-        for (int u = lane; u < 126; u += 64) {
-            float arg;
-            if (u < 96) {
-                const int d = u / 3, f = u - 3 * d;
-                arg = emb[d] * (float)(1 << f);
-            } else {
-                const int q = u - 96, d = q / 5, f = q - 5 * d;
-                float dv = dd[0];
-                dv = d == 1 ? dd[1] : dv;
-                dv = d == 2 ? dd[2] : dv;
-                dv = d == 3 ? dd[3] : dv;
-                dv = d == 4 ? dd[4] : dv;
-                dv = d == 5 ? dd[5] : dv;
-                arg = dv * (float)(1 << f);
+        float vx, vy, vz, scx, scy, scz;
+        rot_rows(P.Rw2c, P.dirs[3 * (int64_t)ray], P.dirs[3 * (int64_t)ray + 1], P.dirs[3 * (int64_t)ray + 2], vx, vy, vz);
+        to_cam(cam, loc.x, loc.y, loc.z, scx, scy, scz);
+        const float spx = scx / scz, spy = scy / scz;
+        for (int k = 0; k < K; ++k) {
+            const int row = v * K + k;
+            const int pidx = __shfl(pk, k, 64);
+            const bool valid = pidx >= 0;
+            const float a0x = __shfl(ak.x, k, 64), a0y = __shfl(ak.y, k, 64), a0z = __shfl(ak.z, k, 64);
+            const float wk = __shfl(wl, k, 64) / wsum;
+            const float4 *prow = P.point_rows + (int64_t)max(pidx, 0) * 12;
+            const float *emb = reinterpret_cast<const float *>(prow + 4);
+            const float dwx = a0x - loc.x, dwy = a0y - loc.y, dwz = a0z - loc.z;
+            float dd[6];
+            rot_rows(P.Rw2c, dwx, dwy, dwz, dd[0], dd[1], dd[2]);
+            {
+                float pcx, pcy, pcz;
+                to_cam(cam, a0x, a0y, a0z, pcx, pcy, pcz);
+                const float ppx = pcx / pcz, ppy = pcy / pcz;
+                dd[3] = ppx * pcz - spx * scz;
+                dd[4] = ppy * pcz - spy * scz;
+                dd[5] = pcz - scz;
             }
-            float sn, cs;
-            sincosf(arg, &sn, &cs);
-            *reinterpret_cast<float2 *>(x0 + 32 + 2 * u) = valid ? make_float2(sn, cs) : make_float2(0.f, 0.f);
-        }
-        if (lane < 8) {
-            float sdx, sdy, sdz, vx, vy, vz;
-            rot_rows(P.Rw2c, c0.w, c1.x, c1.y, sdx, sdy, sdz);
-            rot_rows(P.Rw2c, P.dirs[3 * (int64_t)ray], P.dirs[3 * (int64_t)ray + 1], P.dirs[3 * (int64_t)ray + 2], vx, vy,
-                     vz);
-            float e = 0.f;
-            e = lane == 0 ? c0.x : e;
-            e = lane == 1 ? c0.y : e;
-            e = lane == 2 ? c0.z : e;
-            e = lane == 3 ? sdx - vx : e;
-            e = lane == 4 ? sdy - vy : e;
-            e = lane == 5 ? sdz - vz : e;
-            e = lane == 6 ? sdx * vx + sdy * vy + sdz * vz : e;
-            w.H2[(int64_t)row * LD_H2 + 256 + lane] = valid ? e : 0.f;
-        }
-        if (lane == 0) {
-            w.row_pidx[row] = pidx;
-            w.row_w[row] = valid ? wk : 0.f;
+            float *x0 = w.X0 + (int64_t)row * LD_X0;
+            // columns 32 + 2u, 32 + 2u + 1 = (sin, cos) pair u: u < 96 embedding channel u / 3 at octave u % 3,
+            // u >= 96 distance component (u - 96) / 5 at octave (u - 96) % 5 -- one sincosf per pair
+            if (lane < 32) x0[lane] = valid ? emb[lane] : 0.f;
+            if (lane < 4) x0[284 + lane] = 0.f;
+            for (int u = lane; u < 126; u += 64) {
+                float arg;
+                if (u < 96) {
+                    const int d = u / 3, f = u - 3 * d;
+                    arg = emb[d] * (float)(1 << f);
+                } else {
+                    const int q = u - 96, d = q / 5, f = q - 5 * d;
+                    float dv = dd[0];
+                    dv = d == 1 ? dd[1] : dv;
+                    dv = d == 2 ? dd[2] : dv;
+                    dv = d == 3 ? dd[3] : dv;
+                    dv = d == 4 ? dd[4] : dv;
+                    dv = d == 5 ? dd[5] : dv;
+                    arg = dv * (float)(1 << f);
+                }
+                float sn, cs;
+                sincosf(arg, &sn, &cs);
+                *reinterpret_cast<float2 *>(x0 + 32 + 2 * u) = valid ? make_float2(sn, cs) : make_float2(0.f, 0.f);
+            }
+            if (lane < 8) {
+                const float4 c0 = prow[1], c1 = prow[2];
+                float sdx, sdy, sdz;
+                rot_rows(P.Rw2c, c0.w, c1.x, c1.y, sdx, sdy, sdz);
+                float e = 0.f;
+                e = lane == 0 ? c0.x : e;
+                e = lane == 1 ? c0.y : e;
+                e = lane == 2 ? c0.z : e;
+                e = lane == 3 ? sdx - vx : e;
+                e = lane == 4 ? sdy - vy : e;
+                e = lane == 5 ? sdz - vz : e;
+                e = lane == 6 ? sdx * vx + sdy * vy + sdz * vz : e;
+                w.H2[(int64_t)row * LD_H2 + 256 + lane] = valid ? e : 0.f;
+            }
+            if (lane == 0) {
+                w.row_pidx[row] = pidx;
+                w.row_w[row] = valid ? wk : 0.f;
+            }
         }
     }
 }
