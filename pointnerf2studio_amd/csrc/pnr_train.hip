@@ -895,6 +895,7 @@ __device__ __forceinline__ float wave_sum(float v)
 // [emb(32) | (sin, cos)(emb * 2^f), f < 3 (192) | (sin, cos)(dist * 2^f), f < 5 (60)]  (studio_model.py:309-317,
 // studio_utils.py:58-68), the 7 extra inputs of mlp_head layer 0 and the row's aggregation weight
 // (studio_model.py:270-286).  Unfilled slots (pidx < 0) get zero inputs and weight 0: their gradient vanishes.
+template <bool FAST_PE>
 __global__ void __launch_bounds__(256) k_train_rows(TrainParams P, TrainWs w)
 {
     // one wavefront per SAMPLE: the sample's position, ray, camera and its K neighbour indices / positions are loaded
@@ -945,24 +946,51 @@ __global__ void __launch_bounds__(256) k_train_rows(TrainParams P, TrainWs w)
             // u >= 96 distance component (u - 96) / 5 at octave (u - 96) % 5 -- one sincosf per pair
             if (lane < 32) x0[lane] = valid ? emb[lane] : 0.f;
             if (lane < 4) x0[284 + lane] = 0.f;
-            for (int u = lane; u < 126; u += 64) {
-                float arg;
-                if (u < 96) {
-                    const int d = u / 3, f = u - 3 * d;
-                    arg = emb[d] * (float)(1 << f);
-                } else {
-                    const int q = u - 96, d = q / 5, f = q - 5 * d;
+            if (FAST_PE) {
+                // the bf16x3 mode's encodings (as the render's point_inputs / pair_inputs): one reduced-range sincos per
+                // channel, the higher octaves by double-angle steps; lane d < 32 owns embedding channel d (3 octaves),
+                // lanes 32..37 the six distance components (5 octaves)
+                if (lane < 38) {
+                    const bool is_e = lane < 32;
                     float dv = dd[0];
-                    dv = d == 1 ? dd[1] : dv;
-                    dv = d == 2 ? dd[2] : dv;
-                    dv = d == 3 ? dd[3] : dv;
-                    dv = d == 4 ? dd[4] : dv;
-                    dv = d == 5 ? dd[5] : dv;
-                    arg = dv * (float)(1 << f);
+                    dv = lane == 33 ? dd[1] : dv;
+                    dv = lane == 34 ? dd[2] : dv;
+                    dv = lane == 35 ? dd[3] : dv;
+                    dv = lane == 36 ? dd[4] : dv;
+                    dv = lane == 37 ? dd[5] : dv;
+                    const float arg = is_e ? emb[min(lane, 31)] : dv;
+                    float *dst = is_e ? x0 + 32 + 6 * lane : x0 + 224 + 10 * (lane - 32);
+                    const int nf = is_e ? 3 : 5;
+                    float sn, cs;
+                    fast_sincos(arg, sn, cs);
+#pragma unroll
+                    for (int f = 0; f < 5; ++f) {
+                        if (f < nf) *reinterpret_cast<float2 *>(dst + 2 * f) = valid ? make_float2(sn, cs) : make_float2(0.f, 0.f);
+                        const float s2 = 2.0f * sn * cs, c2 = (cs - sn) * (cs + sn);
+                        sn = s2;
+                        cs = c2;
+                    }
                 }
-                float sn, cs;
-                sincosf(arg, &sn, &cs);
-                *reinterpret_cast<float2 *>(x0 + 32 + 2 * u) = valid ? make_float2(sn, cs) : make_float2(0.f, 0.f);
+            } else {
+                for (int u = lane; u < 126; u += 64) {
+                    float arg;
+                    if (u < 96) {
+                        const int d = u / 3, f = u - 3 * d;
+                        arg = emb[d] * (float)(1 << f);
+                    } else {
+                        const int q = u - 96, d = q / 5, f = q - 5 * d;
+                        float dv = dd[0];
+                        dv = d == 1 ? dd[1] : dv;
+                        dv = d == 2 ? dd[2] : dv;
+                        dv = d == 3 ? dd[3] : dv;
+                        dv = d == 4 ? dd[4] : dv;
+                        dv = d == 5 ? dd[5] : dv;
+                        arg = dv * (float)(1 << f);
+                    }
+                    float sn, cs;
+                    sincosf(arg, &sn, &cs);
+                    *reinterpret_cast<float2 *>(x0 + 32 + 2 * u) = valid ? make_float2(sn, cs) : make_float2(0.f, 0.f);
+                }
             }
             if (lane < 8) {
                 const float4 c0 = prow[1], c1 = prow[2];
@@ -1520,7 +1548,10 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
     }
 
     // ---- forward with tape -----------------------------------------------------------------------
-    hipLaunchKernelGGL(k_train_rows, eg, eb, 0, st, P, tw);
+    if (bf)
+        hipLaunchKernelGGL(k_train_rows<true>, eg, eb, 0, st, P, tw);
+    else
+        hipLaunchKernelGGL(k_train_rows<false>, eg, eb, 0, st, P, tw);
     gemm_forward(st, bf, tw.X0, LD_X0, tw.Wp[0], 288, d_b[0], tw.H1, LD_H, 256, 288, n_rows, rows_max);
     gemm_forward(st, bf, tw.H1, LD_H, tw.Wp[1], 256, d_b[1], tw.H2, LD_H2, 256, 256, n_rows, rows_max);
     gemm_forward(st, bf, tw.H2, LD_H2, tw.Wp[2], 264, d_b[2], tw.G1, LD_H, 256, 264, n_rows, rows_max);
