@@ -138,3 +138,18 @@ def test_jitter_uniform_matches_oracle_generator(lib, oracle):
     big = oracle.jitter_uniforms(2000, 400, seed=3)[0].numpy()
     assert 0.0 <= big.min() and big.max() < 1.0 and abs(big.mean() - 0.5) < 2e-3
     assert abs(np.corrcoef(big[:, :-1].ravel(), big[:, 1:].ravel())[0, 1]) < 5e-3
+
+
+def test_backward_workspace_size_and_grads_struct(lib):
+    """Host-only entry points of the training step: the workspace size is a pure function of (cap_samples, K), grows
+    with both, and pnr_grads_t is 21 device pointers (3 point tensors + 9 weights + 9 biases)."""
+    from pointnerf2studio_amd import _lib
+    a = lib.pnr_backward_workspace_bytes(4096, 8)
+    b = lib.pnr_backward_workspace_bytes(8192, 8)
+    c = lib.pnr_backward_workspace_bytes(4096, 12)
+    assert 0 < a < b and a < c
+    # the tape is ~5.3 KB per (sample, slot) row: X0 288 + H1 256 + H2 264 + G1 256 + G2 256 floats
+    per_row = (b - a) / (4096 * 8)
+    assert 5000 < per_row < 7000, per_row
+    assert lib.pnr_backward_workspace_bytes(0, 0) == lib.pnr_backward_workspace_bytes(1, 1)   # clamped, never 0
+    assert C.sizeof(_lib.GradsC) == 21 * C.sizeof(C.c_void_p)
