@@ -54,6 +54,11 @@ struct GemmArgs {
     const float *bias;      // EPI_BIAS_LEAKY
     const float *mask;      // EPI_MASK: taped post-activation, same leading dimension as C
     int mask_cols;          // columns >= mask_cols pass unmasked
+    // LeakyReLU masks as SIGN BITS: the forward epilogue ballots (activation > 0) per stored float4 component, the masked
+    // epilogue reads the four 64-bit words of its step back (2 KiB per 128x128 tile instead of the 64-KiB tile of floats)
+    unsigned long long *sign_out;        // EPI_BIAS_LEAKY, may be null
+    const unsigned long long *sign_in;   // EPI_MASK, null = read the float mask
+    int sign_nt;                         // column tiles per row tile in the sign buffer
     float *colsum;          // TA only, may be null: colsum[z][m] = sum over split z's rows of A[k][m]  (bias gradient)
 };
 
@@ -84,9 +89,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, const f32x16 (&
                 lds_wave[((r & 3) + 8 * (r >> 2) + 4 * h) * 64 + b * 32 + j] = acc[a][b][r];
         __builtin_amdgcn_wave_barrier();
         const int row0 = m0 + wm * 64 + a * 32 + rr;
-        // the mask is the taped activation this GEMM overwrites (mask == C): all loads before the first store
+        const bool use_bits = EPI == EPI_MASK && g.sign_in != nullptr;
+        const bool tile_has_bits = n0 / 128 < g.sign_nt;   // 128 = the tile size (TM = TN, defined below)
+        // word index of step (a, i), component c: ((((row tile * sign_nt + column tile) * 4 + wave) * 2 + a) * 8 + i) * 4 + c
+        const int64_t wbase = ((((int64_t)(m0 / 128) * g.sign_nt + n0 / 128) * 4 + (wm * 2 + wn)) * 2 + a) * 32;
+        // float masks (the taped activation this GEMM overwrites, mask == C): all loads before the first store
         float4 mk[8];
-        if (EPI == EPI_MASK) {
+        if (EPI == EPI_MASK && !use_bits) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int row = row0 + 4 * i;
@@ -98,8 +107,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, const f32x16 (&
         for (int i = 0; i < 8; ++i) {
             const int row = row0 + 4 * i;
             float4 v = *reinterpret_cast<const float4 *>(lds_wave + (rr + 4 * i) * 64 + c4);
-            if (row >= M || col >= N) continue;
-            if ((PNR_GEMM_ABL & 1) && v.x != 12345.678f) continue;
+            const bool ok = row < M && col < N && !((PNR_GEMM_ABL & 1) && v.x != 12345.678f);
             if (EPI == EPI_BIAS_LEAKY) {
                 v.x += bias.x;
                 v.y += bias.y;
@@ -109,13 +117,28 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, const f32x16 (&
                 v.y = v.y > 0.f ? v.y : 0.1f * v.y;
                 v.z = v.z > 0.f ? v.z : 0.1f * v.z;
                 v.w = v.w > 0.f ? v.w : 0.1f * v.w;
+                if (g.sign_out && tile_has_bits) {   // wave-uniform
+                    const unsigned long long b0 = __ballot(ok && v.x > 0.f), b1 = __ballot(ok && v.y > 0.f);
+                    const unsigned long long b2 = __ballot(ok && v.z > 0.f), b3 = __ballot(ok && v.w > 0.f);
+                    if (lane < 4) g.sign_out[wbase + 4 * i + lane] = lane == 0 ? b0 : (lane == 1 ? b1 : (lane == 2 ? b2 : b3));
+                }
             } else if (EPI == EPI_MASK) {
-                v.x *= mk[i].x > 0.f ? 1.0f : 0.1f;
-                v.y *= mk[i].y > 0.f ? 1.0f : 0.1f;
-                v.z *= mk[i].z > 0.f ? 1.0f : 0.1f;
-                v.w *= mk[i].w > 0.f ? 1.0f : 0.1f;
+                if (use_bits) {
+                    if (tile_has_bits) {
+                        const unsigned long long *wp = g.sign_in + wbase + 4 * i;
+                        v.x *= ((wp[0] >> lane) & 1ull) ? 1.0f : 0.1f;
+                        v.y *= ((wp[1] >> lane) & 1ull) ? 1.0f : 0.1f;
+                        v.z *= ((wp[2] >> lane) & 1ull) ? 1.0f : 0.1f;
+                        v.w *= ((wp[3] >> lane) & 1ull) ? 1.0f : 0.1f;
+                    }
+                } else {
+                    v.x *= mk[i].x > 0.f ? 1.0f : 0.1f;
+                    v.y *= mk[i].y > 0.f ? 1.0f : 0.1f;
+                    v.z *= mk[i].z > 0.f ? 1.0f : 0.1f;
+                    v.w *= mk[i].w > 0.f ? 1.0f : 0.1f;
+                }
             }
-            *reinterpret_cast<float4 *>(g.C + (int64_t)row * g.ldc + col) = v;
+            if (ok) *reinterpret_cast<float4 *>(g.C + (int64_t)row * g.ldc + col) = v;
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -760,6 +783,7 @@ struct TrainWs {
     float *tmpD;     // [cap] segment length
     float *X0, *H1, *H2, *G1, *G2;  // [cap * K, ld]
     float *XC, *C1, *C2, *C3;       // [cap, ld]
+    unsigned long long *sgH1, *sgH2, *sgG1, *sgC1, *sgC2;   // LeakyReLU sign bits of the taped activations (gemm_epilogue)
     float *Wp[9], *dWp[9], *dbp[9];
     float *WT[9];                   // W^T, [W_LD (inputs, zero rows beyond in) , out]: B operand of the bf16x3 data GEMMs
     float *part;                    // partial tiles of the weight-gradient GEMM in flight: [splits, M, ld]
@@ -798,6 +822,14 @@ static TrainWs carve_train_ws(void *base, int64_t cap, int K)
     w.C1 = (float *)take(smp * LD_C * 4);
     w.C2 = (float *)take(smp * LD_C * 4);
     w.C3 = (float *)take(smp * LD_C * 4);
+    {
+        const size_t mt_rows = (rows + TM - 1) / TM, mt_smp = (smp + TM - 1) / TM;
+        w.sgH1 = (unsigned long long *)take(mt_rows * 2 * 2048);
+        w.sgH2 = (unsigned long long *)take(mt_rows * 2 * 2048);
+        w.sgG1 = (unsigned long long *)take(mt_rows * 2 * 2048);
+        w.sgC1 = (unsigned long long *)take(mt_smp * 2048);
+        w.sgC2 = (unsigned long long *)take(mt_smp * 2048);
+    }
     for (int i = 0; i < 9; ++i) w.Wp[i] = (float *)take((size_t)W_OUT[i] * W_LD[i] * 4);
     for (int i = 0; i < 9; ++i) w.WT[i] = (float *)take((size_t)W_OUT[i] * W_LD[i] * 4);
     w.part = (float *)take((size_t)(PART_FLOATS + CSUM_FLOATS) * 4);
@@ -1383,9 +1415,12 @@ static void gemm_bf(hipStream_t st, const GemmArgs &g, int m_max)
 }
 
 static void gemm_forward(hipStream_t st, bool bf, const float *A, int lda, const float *W, int ldw, const float *b,
-                         float *C, int ldc, int N, int K, const int *dev_rows, int64_t rows_max)
+                         float *C, int ldc, int N, int K, const int *dev_rows, int64_t rows_max,
+                         unsigned long long *sign_out = nullptr)
 {
     GemmArgs g{};
+    g.sign_out = sign_out;
+    g.sign_nt = (N + TN - 1) / TN;
     g.A = A; g.B = W; g.C = C; g.lda = lda; g.ldb = ldw; g.ldc = ldc; g.M = 0; g.N = N; g.K = K;
     g.dev_rows = dev_rows; g.bias = b;
     if (bf)
@@ -1397,9 +1432,12 @@ static void gemm_forward(hipStream_t st, bool bf, const float *A, int lda, const
 // C[rows, N] = (dZ[rows, K] . W[K, N]) * leaky'(C) for columns < mask_cols (in place over the taped activation)
 // (bf16x3: the B operand is WT = W^T [N, K] with leading dimension K)
 static void gemm_data(hipStream_t st, bool bf, const float *dZ, int lda, const float *W, int ldw, const float *WT,
-                      float *C, int ldc, int N, int K, int mask_cols, const int *dev_rows, int64_t rows_max)
+                      float *C, int ldc, int N, int K, int mask_cols, const int *dev_rows, int64_t rows_max,
+                      const unsigned long long *sign_in = nullptr)
 {
     GemmArgs g{};
+    g.sign_in = sign_in;
+    g.sign_nt = (mask_cols + TN - 1) / TN;
     g.A = dZ; g.B = W; g.C = C; g.lda = lda; g.ldb = ldw; g.ldc = ldc; g.M = 0; g.N = N; g.K = K;
     g.dev_rows = dev_rows; g.mask = C; g.mask_cols = mask_cols;
     if (bf) {
@@ -1552,13 +1590,13 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
         hipLaunchKernelGGL(k_train_rows<true>, eg, eb, 0, st, P, tw);
     else
         hipLaunchKernelGGL(k_train_rows<false>, eg, eb, 0, st, P, tw);
-    gemm_forward(st, bf, tw.X0, LD_X0, tw.Wp[0], 288, d_b[0], tw.H1, LD_H, 256, 288, n_rows, rows_max);
-    gemm_forward(st, bf, tw.H1, LD_H, tw.Wp[1], 256, d_b[1], tw.H2, LD_H2, 256, 256, n_rows, rows_max);
-    gemm_forward(st, bf, tw.H2, LD_H2, tw.Wp[2], 264, d_b[2], tw.G1, LD_H, 256, 264, n_rows, rows_max);
+    gemm_forward(st, bf, tw.X0, LD_X0, tw.Wp[0], 288, d_b[0], tw.H1, LD_H, 256, 288, n_rows, rows_max, tw.sgH1);
+    gemm_forward(st, bf, tw.H1, LD_H, tw.Wp[1], 256, d_b[1], tw.H2, LD_H2, 256, 256, n_rows, rows_max, tw.sgH2);
+    gemm_forward(st, bf, tw.H2, LD_H2, tw.Wp[2], 264, d_b[2], tw.G1, LD_H, 256, 264, n_rows, rows_max, tw.sgG1);
     gemm_forward(st, bf, tw.G1, LD_H, tw.Wp[3], 256, d_b[3], tw.G2, LD_H, 256, 256, n_rows, rows_max);
     hipLaunchKernelGGL(k_train_head_agg, eg, eb, 0, st, P, tw, d_w[4], d_b[4]);
-    gemm_forward(st, bf, tw.XC, LD_XC, tw.Wp[5], 288, d_b[5], tw.C1, LD_C, 128, 288, n_smp, smp_max);
-    gemm_forward(st, bf, tw.C1, LD_C, tw.Wp[6], 128, d_b[6], tw.C2, LD_C, 128, 128, n_smp, smp_max);
+    gemm_forward(st, bf, tw.XC, LD_XC, tw.Wp[5], 288, d_b[5], tw.C1, LD_C, 128, 288, n_smp, smp_max, tw.sgC1);
+    gemm_forward(st, bf, tw.C1, LD_C, tw.Wp[6], 128, d_b[6], tw.C2, LD_C, 128, 128, n_smp, smp_max, tw.sgC2);
     gemm_forward(st, bf, tw.C2, LD_C, tw.Wp[7], 128, d_b[7], tw.C3, LD_C, 128, 128, n_smp, smp_max);
     hipLaunchKernelGGL(k_train_color_head, eg, eb, 0, st, tw, d_w[8], d_b[8]);
 
@@ -1569,9 +1607,9 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
     hipLaunchKernelGGL(k_train_color_head_bwd, dim3(256), eb, 0, st, tw, d_w[8]);  // C3 <- dZ7
     hipLaunchKernelGGL(k_reduce_rows, dim3(2), eb, 0, st, tw.part, 1024, 388, 387, 384, tw.dWp[8], tw.dbp[8]);
     gemm_weight(st, bf, tw.C3, LD_C, tw.C2, LD_C, tw.dWp[7], 128, 128, 128, n_smp, smp_max, tw.dbp[7], tw.part);
-    gemm_data(st, bf, tw.C3, LD_C, tw.Wp[7], 128, tw.WT[7], tw.C2, LD_C, 128, 128, 128, n_smp, smp_max);  // C2 <- dZ6
+    gemm_data(st, bf, tw.C3, LD_C, tw.Wp[7], 128, tw.WT[7], tw.C2, LD_C, 128, 128, 128, n_smp, smp_max, tw.sgC2);  // C2 <- dZ6
     gemm_weight(st, bf, tw.C2, LD_C, tw.C1, LD_C, tw.dWp[6], 128, 128, 128, n_smp, smp_max, tw.dbp[6], tw.part);
-    gemm_data(st, bf, tw.C2, LD_C, tw.Wp[6], 128, tw.WT[6], tw.C1, LD_C, 128, 128, 128, n_smp, smp_max);  // C1 <- dZ5
+    gemm_data(st, bf, tw.C2, LD_C, tw.Wp[6], 128, tw.WT[6], tw.C1, LD_C, 128, 128, 128, n_smp, smp_max, tw.sgC1);  // C1 <- dZ5
     gemm_weight(st, bf, tw.C1, LD_C, tw.XC, LD_XC, tw.dWp[5], 288, 128, 288, n_smp, smp_max, tw.dbp[5], tw.part);
     gemm_data(st, bf, tw.C1, LD_C, tw.Wp[5], 288, tw.WT[5], tw.XC, LD_XC, 256, 128, 0, n_smp, smp_max);   // XC[:, :256] <- dAGG
     // density head + aggregation
@@ -1579,12 +1617,12 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
     hipLaunchKernelGGL(k_reduce_rows, dim3(2), eb, 0, st, tw.part, 1024, 260, 257, 256, tw.dWp[4], tw.dbp[4]);
     // mlp_head
     gemm_weight(st, bf, tw.G2, LD_H, tw.G1, LD_H, tw.dWp[3], 256, 256, 256, n_rows, rows_max, tw.dbp[3], tw.part);
-    gemm_data(st, bf, tw.G2, LD_H, tw.Wp[3], 256, tw.WT[3], tw.G1, LD_H, 256, 256, 256, n_rows, rows_max);   // G1 <- dZ3
+    gemm_data(st, bf, tw.G2, LD_H, tw.Wp[3], 256, tw.WT[3], tw.G1, LD_H, 256, 256, 256, n_rows, rows_max, tw.sgG1);   // G1 <- dZ3
     gemm_weight(st, bf, tw.G1, LD_H, tw.H2, LD_H2, tw.dWp[2], 264, 256, 264, n_rows, rows_max, tw.dbp[2], tw.part);
-    gemm_data(st, bf, tw.G1, LD_H, tw.Wp[2], 264, tw.WT[2], tw.H2, LD_H2, 264, 256, 256, n_rows, rows_max);  // H2 <- [dZ2 | d extras]
+    gemm_data(st, bf, tw.G1, LD_H, tw.Wp[2], 264, tw.WT[2], tw.H2, LD_H2, 264, 256, 256, n_rows, rows_max, tw.sgH2);  // H2 <- [dZ2 | d extras]
     // mlp_base
     gemm_weight(st, bf, tw.H2, LD_H2, tw.H1, LD_H, tw.dWp[1], 256, 256, 256, n_rows, rows_max, tw.dbp[1], tw.part);
-    gemm_data(st, bf, tw.H2, LD_H2, tw.Wp[1], 256, tw.WT[1], tw.H1, LD_H, 256, 256, 256, n_rows, rows_max);  // H1 <- dZ1
+    gemm_data(st, bf, tw.H2, LD_H2, tw.Wp[1], 256, tw.WT[1], tw.H1, LD_H, 256, 256, 256, n_rows, rows_max, tw.sgH1);  // H1 <- dZ1
     gemm_weight(st, bf, tw.H1, LD_H, tw.X0, LD_X0, tw.dWp[0], 288, 256, 288, n_rows, rows_max, tw.dbp[0], tw.part);
     gemm_data(st, bf, tw.H1, LD_H, tw.Wp[0], 288, tw.WT[0], tw.G2, LD_H, 224, 256, 0, n_rows, rows_max);     // G2 <- dX0[:, :224]
     // point tensors
