@@ -663,43 +663,47 @@ __global__ void __launch_bounds__(256, 2) k_gemm_tn_bf16x3(GemmArgs g)
     const bool col_ok = c0 < (isB ? N : M);
     const bool want_csum = g.colsum && blockIdx.y == 0 && !isB;
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 rg[8];
-    auto load_tiles = [&](int k0) {
+    // Two register stages (chunk c + 2 is requested before the MFMAs of chunk c), loads branch-free (rows clamped into
+    // the split, zeros selected when the chunk is written to LDS: a predicated load is its own basic block and hipcc then
+    // waits vmcnt(0) at every merge), LDS-only barriers, and the transpose + split + LDS store of the next chunk cut
+    // into four column pieces placed behind MFMA blocks -- the measures that paid in k_gemm_nt_bf16x3_u.
+    float4 rg[2][8];
+    const int c0c = min(c0, (isB ? N : M) - 4);            // a valid column quad for threads beyond the matrix
+    const float *srcc = src + c0c;
+    auto load_tiles = [&](int k0, auto par) {
+        constexpr int P = decltype(par)::value;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int k = k0 + kg * 8 + i;
-            rg[i] = (col_ok && k < k_end) ? *reinterpret_cast<const float4 *>(src + (int64_t)k * ld + c0)
-                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int k = min(k0 + kg * 8 + i, k_end - 1);
+            rg[P][i] = *reinterpret_cast<const float4 *>(srcc + (int64_t)k * ld);
         }
     };
-    auto store_tiles = [&](int buf) {
+    // column c of the thread's 8 x 4 block of chunk k0: 8 k values -> one hi and one lo fragment
+    auto store_piece = [&](int buf, int k0, auto par, int c) {
+        constexpr int P = decltype(par)::value;
         const int plane = isB ? 2 : 0;
-        float col[4][8];
+        bf16x8 hv, lv;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            col[0][i] = rg[i].x;
-            col[1][i] = rg[i].y;
-            col[2][i] = rg[i].z;
-            col[3][i] = rg[i].w;
+            const float4 r4 = rg[P][i];
+            float x = c == 0 ? r4.x : (c == 1 ? r4.y : (c == 2 ? r4.z : r4.w));
+            x = (col_ok && k0 + kg * 8 + i < k_end) ? x : 0.f;
+            const __bf16 hb = (__bf16)x;
+            hv[i] = hb;
+            lv[i] = (__bf16)(x - (float)hb);
             if (want_csum) {
-                csum.x += rg[i].x;
-                csum.y += rg[i].y;
-                csum.z += rg[i].z;
-                csum.w += rg[i].w;
+                if (c == 0) csum.x += x;
+                if (c == 1) csum.y += x;
+                if (c == 2) csum.z += x;
+                if (c == 3) csum.w += x;
             }
         }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            bf16x8 hv, lv;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const __bf16 hb = (__bf16)col[c][i];
-                hv[i] = hb;
-                lv[i] = (__bf16)(col[c][i] - (float)hb);
-            }
-            planes[buf][plane][kg][q4 + c] = __builtin_bit_cast(u32x4, hv);
-            planes[buf][plane + 1][kg][q4 + c] = __builtin_bit_cast(u32x4, lv);
-        }
+        planes[buf][plane][kg][q4 + c] = __builtin_bit_cast(u32x4, hv);
+        planes[buf][plane + 1][kg][q4 + c] = __builtin_bit_cast(u32x4, lv);
+    };
+    auto lds_barrier = [] {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     };
     f32x16 acc[2][2];
 #pragma unroll
@@ -708,13 +712,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_tn_bf16x3(GemmArgs g)
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    const int nchunks = (k_end - k_begin + BK - 1) / BK;
-    load_tiles(k_begin);
-    store_tiles(0);
-    __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nchunks) load_tiles(k_begin + (c + 1) * BK);
+    // MFMAs of the chunk in LDS buffer `buf`; the next chunk (first row k_next, register stage `par`) goes to buf ^ 1
+    auto mfma_chunk = [&](int buf, int k_next, auto par) {
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
             const int kgs = 2 * s + h;
@@ -730,13 +729,32 @@ __global__ void __launch_bounds__(256, 2) k_gemm_tn_bf16x3(GemmArgs g)
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
+                    __builtin_amdgcn_sched_barrier(0);
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                    if (b == 0) store_piece(buf ^ 1, k_next, par, 2 * s + a);   // four pieces per chunk
+                    __builtin_amdgcn_sched_barrier(0);
                 }
         }
-        if (c + 1 < nchunks) store_tiles(buf ^ 1);
-        __syncthreads();
+    };
+    typedef std::integral_constant<int, 0> P0;
+    typedef std::integral_constant<int, 1> P1;
+    const int nchunks = (k_end - k_begin + BK - 1) / BK;
+    load_tiles(k_begin, P0());
+    load_tiles(k_begin + BK, P1());
+#pragma unroll
+    for (int c = 0; c < 4; ++c) store_piece(0, k_begin, P0(), c);
+    lds_barrier();
+    // two chunks per iteration; chunks beyond the split are all-zero (their loads are clamped, their values selected away)
+    for (int c = 0; c < nchunks; c += 2) {
+        const int k0 = k_begin + c * BK;
+        load_tiles(k0 + 2 * BK, P0());                 // chunk c + 2 into the stage chunk c left
+        mfma_chunk(0, k0 + BK, P1());                  // chunk c; chunk c + 1 -> LDS buffer 1
+        lds_barrier();
+        load_tiles(k0 + 3 * BK, P1());
+        mfma_chunk(1, k0 + 2 * BK, P0());              // chunk c + 1; chunk c + 2 -> LDS buffer 0
+        lds_barrier();
     }
     float *ldsf = reinterpret_cast<float *>(&planes[0][0][0][0]);
     if (g.colsum && blockIdx.y == 0) {   // uniform over the workgroup
