@@ -196,66 +196,78 @@ __global__ void __launch_bounds__(256, PNR_GEMM_WGS) k_gemm(GemmArgs g)
     }
     const int wm = wave & 1, wn = wave >> 1;
 
-    float4 ra[NLD], rb[NLD];
+    // Two register stages (chunk c + 2 is requested before the MFMAs of chunk c: one 16-deep chunk is ~2 k cycles of
+    // fp32 MFMA, a memory round trip ~4.5 k), loads branch-free (indices clamped into the matrix, zeros selected when
+    // the chunk is written to LDS -- a predicated load is its own basic block and hipcc then waits vmcnt(0) at the
+    // merges), barriers that wait for LDS only.  Two chunks per loop iteration; chunks beyond k_end are all-zero.
+    float4 ra[2][NLD], rb[2][NLD];
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool want_csum = TA && g.colsum && blockIdx.y == 0;
-    auto load_tiles = [&](int k0) {
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_tiles = [&](int k0, auto par) {
+        constexpr int P = decltype(par)::value;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             if (TA) {  // natural: TK rows (k) x 128 contiguous m
                 const int kr = (tid >> 5) + 8 * i, c4 = (tid & 31) * 4;
-                const int k = k0 + kr, m = m0 + c4;
-                ra[i] = (k < k_end && m < M) ? *reinterpret_cast<const float4 *>(g.A + (int64_t)k * g.lda + m)
-                                             : make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {  // transposing: 128 rows (m) x TK contiguous k; thread = (row tid >> 3 + 32 i', float4 tid & 7)
+                const int k = min(k0 + kr, k_end - 1), m = min(m0 + c4, M - 4);
+                ra[P][i] = *reinterpret_cast<const float4 *>(g.A + (int64_t)k * g.lda + m);
+            } else {  // transposing: 128 rows (m) x TK contiguous k
                 const int mr = (tid / (TK / 4)) + (1024 / TK) * i, kq = (tid % (TK / 4)) * 4;
-                const int m = m0 + mr, k = k0 + kq;
-                ra[i] = (m < M && k < k_end) ? *reinterpret_cast<const float4 *>(g.A + (int64_t)m * g.lda + k)
-                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int m = min(m0 + mr, M - 1), k = min(k0 + kq, k_end - 4);
+                ra[P][i] = *reinterpret_cast<const float4 *>(g.A + (int64_t)m * g.lda + k);
             }
             if (!TB) {
                 const int kr = (tid >> 5) + 8 * i, c4 = (tid & 31) * 4;
-                const int k = k0 + kr, n = n0 + c4;
-                rb[i] = (k < k_end && n < N) ? *reinterpret_cast<const float4 *>(g.B + (int64_t)k * g.ldb + n)
-                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int k = min(k0 + kr, k_end - 1), n = min(n0 + c4, N - 4);
+                rb[P][i] = *reinterpret_cast<const float4 *>(g.B + (int64_t)k * g.ldb + n);
             } else {
                 const int nr = (tid / (TK / 4)) + (1024 / TK) * i, kq = (tid % (TK / 4)) * 4;
-                const int n = n0 + nr, k = k0 + kq;
-                rb[i] = (n < N && k < k_end) ? *reinterpret_cast<const float4 *>(g.B + (int64_t)n * g.ldb + k)
-                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int n = min(n0 + nr, N - 1), k = min(k0 + kq, k_end - 4);
+                rb[P][i] = *reinterpret_cast<const float4 *>(g.B + (int64_t)n * g.ldb + k);
             }
         }
     };
-    auto store_tiles = [&](int buf) {
+    // chunk starting at row / column k0 of the reduction, from register stage `par`, into LDS buffer `buf`
+    auto store_tiles = [&](int buf, int k0, auto par) {
+        constexpr int P = decltype(par)::value;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             if (TA) {
                 const int kr = (tid >> 5) + 8 * i, c4 = (tid & 31) * 4;
-                *reinterpret_cast<float4 *>(&As[buf][kr][c4]) = ra[i];
+                const float4 v = (k0 + kr < k_end && m0 + c4 < M) ? ra[P][i] : z4;
+                *reinterpret_cast<float4 *>(&As[buf][kr][c4]) = v;
                 if (want_csum) {
-                    csum.x += ra[i].x;
-                    csum.y += ra[i].y;
-                    csum.z += ra[i].z;
-                    csum.w += ra[i].w;
+                    csum.x += v.x;
+                    csum.y += v.y;
+                    csum.z += v.z;
+                    csum.w += v.w;
                 }
             } else {
                 const int mr = (tid / (TK / 4)) + (1024 / TK) * i, kq = (tid % (TK / 4)) * 4;
-                As[buf][kq + 0][mr] = ra[i].x;
-                As[buf][kq + 1][mr] = ra[i].y;
-                As[buf][kq + 2][mr] = ra[i].z;
-                As[buf][kq + 3][mr] = ra[i].w;
+                const float4 v = (m0 + mr < M && k0 + kq < k_end) ? ra[P][i] : z4;
+                As[buf][kq + 0][mr] = v.x;
+                As[buf][kq + 1][mr] = v.y;
+                As[buf][kq + 2][mr] = v.z;
+                As[buf][kq + 3][mr] = v.w;
             }
             if (!TB) {
                 const int kr = (tid >> 5) + 8 * i, c4 = (tid & 31) * 4;
-                *reinterpret_cast<float4 *>(&Bs[buf][kr][c4]) = rb[i];
+                const float4 v = (k0 + kr < k_end && n0 + c4 < N) ? rb[P][i] : z4;
+                *reinterpret_cast<float4 *>(&Bs[buf][kr][c4]) = v;
             } else {
                 const int nr = (tid / (TK / 4)) + (1024 / TK) * i, kq = (tid % (TK / 4)) * 4;
-                Bs[buf][kq + 0][nr] = rb[i].x;
-                Bs[buf][kq + 1][nr] = rb[i].y;
-                Bs[buf][kq + 2][nr] = rb[i].z;
-                Bs[buf][kq + 3][nr] = rb[i].w;
+                const float4 v = (n0 + nr < N && k0 + kq < k_end) ? rb[P][i] : z4;
+                Bs[buf][kq + 0][nr] = v.x;
+                Bs[buf][kq + 1][nr] = v.y;
+                Bs[buf][kq + 2][nr] = v.z;
+                Bs[buf][kq + 3][nr] = v.w;
             }
         }
+    };
+    auto lds_barrier = [] {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     };
 
     f32x16 acc[2][2];
@@ -265,14 +277,7 @@ __global__ void __launch_bounds__(256, PNR_GEMM_WGS) k_gemm(GemmArgs g)
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    const int nchunks = (k_end - k_begin + TK - 1) / TK;
-    load_tiles(k_begin);
-    store_tiles(0);
-    __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nchunks) load_tiles(k_begin + (c + 1) * TK);
+    auto mfma_chunk = [&](int buf) {
 #pragma unroll
         for (int kk = 0; kk < TK; kk += 2) {
             const float a0 = As[buf][kk + h][wm * 64 + j], a1 = As[buf][kk + h][wm * 64 + 32 + j];
@@ -282,9 +287,26 @@ __global__ void __launch_bounds__(256, PNR_GEMM_WGS) k_gemm(GemmArgs g)
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
-        if (c + 1 < nchunks) store_tiles(buf ^ 1);
-        __syncthreads();
+    };
+    typedef std::integral_constant<int, 0> P0;
+    typedef std::integral_constant<int, 1> P1;
+    const int nchunks = (k_end - k_begin + TK - 1) / TK;
+    load_tiles(k_begin, P0());
+    load_tiles(k_begin + TK, P1());
+    store_tiles(0, k_begin, P0());
+    lds_barrier();
+    for (int c = 0; c < nchunks; c += 2) {
+        const int k0 = k_begin + c * TK;
+        load_tiles(k0 + 2 * TK, P0());
+        mfma_chunk(0);
+        store_tiles(1, k0 + TK, P1());
+        lds_barrier();
+        load_tiles(k0 + 3 * TK, P1());
+        mfma_chunk(1);
+        store_tiles(0, k0 + 2 * TK, P0());
+        lds_barrier();
     }
+
     if (want_csum) {
         // bias gradient: every thread summed the A elements it loaded (columns m0 + 4 (tid & 31) .. + 3, eight threads
         // per column group): folded in LDS, one partial row per split (global atomics here meant 6 k adds per address)
