@@ -976,6 +976,9 @@ __global__ void __launch_bounds__(256) k_train_rows(TrainParams P, TrainWs w)
     const int lane = threadIdx.x & 63;
     const int wv = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwv = (gridDim.x * blockDim.x) >> 6;
     const int S = w.cnt[1], K = P.K;
+    // a row is assembled in wave-private LDS and leaves as 72 float4 (two store instructions of contiguous KiB) instead
+    // of five partial-line store instructions
+    __shared__ float rbuf[4][LD_X0];
     for (int v = wv; v < S; v += nwv) {
         const int s = P.vs_list[v];
         const float4 loc = P.smp_loc[s];
@@ -1013,7 +1016,8 @@ __global__ void __launch_bounds__(256) k_train_rows(TrainParams P, TrainWs w)
                 dd[4] = ppy * pcz - spy * scz;
                 dd[5] = pcz - scz;
             }
-            float *x0 = w.X0 + (int64_t)row * LD_X0;
+            float *x0 = rbuf[threadIdx.x >> 6];
+            __builtin_amdgcn_wave_barrier();
             // columns 32 + 2u, 32 + 2u + 1 = (sin, cos) pair u: u < 96 embedding channel u / 3 at octave u % 3,
             // u >= 96 distance component (u - 96) / 5 at octave (u - 96) % 5 -- one sincosf per pair
             if (lane < 32) x0[lane] = valid ? emb[lane] : 0.f;
@@ -1063,6 +1067,12 @@ __global__ void __launch_bounds__(256) k_train_rows(TrainParams P, TrainWs w)
                     sincosf(arg, &sn, &cs);
                     *reinterpret_cast<float2 *>(x0 + 32 + 2 * u) = valid ? make_float2(sn, cs) : make_float2(0.f, 0.f);
                 }
+            }
+            __builtin_amdgcn_wave_barrier();
+            {
+                float4 *gx = reinterpret_cast<float4 *>(w.X0 + (int64_t)row * LD_X0);
+                gx[lane] = reinterpret_cast<const float4 *>(x0)[lane];
+                if (lane < LD_X0 / 4 - 64) gx[64 + lane] = reinterpret_cast<const float4 *>(x0)[64 + lane];
             }
             if (lane < 8) {
                 const float4 c0 = prow[1], c1 = prow[2];
@@ -1384,12 +1394,20 @@ __global__ void __launch_bounds__(256) k_train_scatter(TrainParams P, TrainWs w,
     const int lane = threadIdx.x & 63;
     const int wv = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwv = (gridDim.x * blockDim.x) >> 6;
     const int rows = w.cnt[0], K = P.K;
+    __shared__ float sbuf[4][2][224];
     for (int row = wv; row < rows; row += nwv) {
         const int pidx = w.row_pidx[row];
         if (pidx < 0) continue;
-        const float *dx = w.G2 + (int64_t)row * LD_H;
-        const float *x0 = w.X0 + (int64_t)row * LD_X0;
         const float *dh = w.H2 + (int64_t)row * LD_H2 + 256;
+        // the row of dX0 (224 floats) and of the taped encodings (columns 0..223 of X0) through wave-private LDS: two
+        // coalesced float4 loads per lane instead of thirteen 4-byte loads at a stride of 24 bytes
+        float *dx = &sbuf[threadIdx.x >> 6][0][0], *x0 = &sbuf[threadIdx.x >> 6][1][0];
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 56) {
+            reinterpret_cast<float4 *>(dx)[lane] = reinterpret_cast<const float4 *>(w.G2 + (int64_t)row * LD_H)[lane];
+            reinterpret_cast<float4 *>(x0)[lane] = reinterpret_cast<const float4 *>(w.X0 + (int64_t)row * LD_X0)[lane];
+        }
+        __builtin_amdgcn_wave_barrier();
         if (lane < 32) {
             // d/de [e, sin(e 2^f), cos(e 2^f)] = [1, 2^f cos, -2^f sin]
             float g = dx[lane];
