@@ -26,6 +26,7 @@ from torch.nn import Parameter
 from .neural_points import NeuralPoints, PointNeRFEncoding
 from .ns_compat import (MLP, DensityFieldHead, Model, ModelConfig, MSELoss, RGBFieldHead, RGBRenderer,
                         TrainingCallback, TrainingCallbackAttributes, TrainingCallbackLocation, WHITE)
+from ._lib import MAX_CAMS
 from .renderer import MLP_TENSOR_ORDER, RendererHIP, WeightsHIP
 
 
@@ -107,12 +108,12 @@ class PointNerfConfig(ModelConfig):
 
 
 class _FusedRenderFn(torch.autograd.Function):
-    """pnr_render forwards, pnr_render_backward backwards (include/pnr.h).  Inputs after `far`: points_embeding,
+    """pnr_render_views forwards, pnr_render_backward backwards (include/pnr.h).  Inputs after `ray_cam`: points_embeding,
     points_color, points_dir and the nine (weight, bias) pairs in MLP_TENSOR_ORDER."""
 
     @staticmethod
-    def forward(ctx, rnd, dirs, pos, rot, near, far, emb, color, pdir, *mlp):
-        out = rnd.render(dirs, pos, rot, near, far)
+    def forward(ctx, rnd, dirs, cams, ray_cam, emb, color, pdir, *mlp):
+        out = rnd.render_views(dirs, cams, dirs.reshape(-1, 3).shape[0], ray_cam=ray_cam)
         rnd.last_counters = out["counters"]
         ctx.rnd = rnd
         ctx.shapes = (emb.shape, color.shape, pdir.shape)
@@ -133,7 +134,7 @@ class _FusedRenderFn(torch.autograd.Function):
         grads = [g["embedding"].view(es), g["color"].view(cs), g["dir"].view(ds)]
         for name in MLP_TENSOR_ORDER:
             grads += [g[name + ".weight"], g[name + ".bias"]]
-        return (None, None, None, None, None, None, *grads)
+        return (None, None, None, None, *grads)
 
 
 class PointNerf(Model):
@@ -276,17 +277,39 @@ class PointNerf(Model):
                                          early_stop_eps=float(getattr(c, "hip_early_stop_eps", 0.0)))
         return self._renderer
 
+    def _bundle_cameras(self, ray_bundle):
+        """The cameras of a bundle.  The reference assumes ONE per bundle and reads origins[0] / camrotc2w[0]
+        (studio_utils.py:148-155); so does this for such bundles (one cheap all-equal test).  Bundles that mix cameras
+        -- nerfstudio's usual random-pixel batches over several images -- are rendered in
+        ONE pnr_render_views call with a per-ray camera index, up to PNR_MAX_CAMS cameras.
+        Returns (cams [(pos, rot3x3, near, far)], ray_cam int32 [R] or None)."""
+        rot, pos = self.neural_points._camera(ray_bundle)
+        near, far = ray_bundle.nears[0].item(), ray_bundle.fars[0].item()
+        meta = ray_bundle.metadata["camrotc2w"]
+        o = ray_bundle.origins.reshape(-1, 3)
+        if meta.shape[0] == 3 or o.shape[0] <= 1:
+            return [(pos[0], rot[0], near, far)], None
+        key = torch.cat([o, meta.reshape(o.shape[0], 9)], dim=1).to(self._device)
+        if bool((key == key[0]).all()):
+            return [(pos[0], rot[0], near, far)], None
+        uniq, inv = torch.unique(key, dim=0, return_inverse=True)
+        if uniq.shape[0] > MAX_CAMS:
+            raise RuntimeError(f"a ray bundle may mix at most {MAX_CAMS} cameras, got {uniq.shape[0]}")
+        uniq = uniq.cpu()
+        cams = [(uniq[i, :3], uniq[i, 3:].view(3, 3), near, far) for i in range(uniq.shape[0])]
+        return cams, inv.to(torch.int32)
+
     def _get_outputs_fused(self, ray_bundle):
         """Jitter: the reference draws torch.rand jitter even at eval (studio_utils.py:166, hard-coded 0.3); the
         fused path uses the same fraction (`neural_points.jitter`) with the library's counter-based uniforms and
         a fresh seed per call.  Set `neural_points.jitter = 0` for deterministic mid-point renders."""
-        rot, pos = self.neural_points._camera(ray_bundle)
+        cams, ray_cam = self._bundle_cameras(ray_bundle)
         rnd = self._fused_renderer()
         rnd.opts.jitter = float(self.neural_points.jitter)
         rnd.opts.seed = self._render_calls & 0xFFFFFFFF
         self._render_calls += 1
-        out = rnd.render(ray_bundle.directions.to(self._device), pos[0], rot[0],
-                         ray_bundle.nears[0].item(), ray_bundle.fars[0].item())
+        dirs = ray_bundle.directions.to(self._device)
+        out = rnd.render_views(dirs, cams, dirs.reshape(-1, 3).shape[0], ray_cam=ray_cam)
         return {"coarse_raycolor": out["rgb"], "ray_mask": out["ray_mask"], "depth": out["depth"],
                 "accumulation": out["acc"]}
 
@@ -298,7 +321,7 @@ class PointNerf(Model):
         points_conf: the reference's tensor is [1,R'',SR,K] with unfilled slots reading point 0
         (studio_utils.py:193-199, clamp(pidx, 0)); the same multiset of values is returned flat, which is all the
         loss (a mean) looks at."""
-        rot, pos = self.neural_points._camera(ray_bundle)
+        cams, ray_cam = self._bundle_cameras(ray_bundle)
         rnd = self._fused_renderer(train=True)
         rnd.opts.jitter = float(self.neural_points.jitter)
         rnd.opts.seed = self._render_calls & 0xFFFFFFFF
@@ -308,8 +331,7 @@ class PointNerf(Model):
         for name in MLP_TENSOR_ORDER:
             mod = self.get_submodule(name)
             mlp += [mod.weight, mod.bias]
-        rgb, ray_mask = _FusedRenderFn.apply(rnd, ray_bundle.directions.to(self._device), pos[0], rot[0],
-                                             ray_bundle.nears[0].item(), ray_bundle.fars[0].item(),
+        rgb, ray_mask = _FusedRenderFn.apply(rnd, ray_bundle.directions.to(self._device), cams, ray_cam,
                                              npts.points_embeding, npts.points_color, npts.points_dir, *mlp)
         cnt = rnd.last_counters
         R = ray_bundle.directions.reshape(-1, 3).shape[0]

@@ -142,3 +142,56 @@ def test_dropin_query_op_signature(oracle, gpu_device):
     assert op._scene is scene                      # unchanged cloud: no rebuild
     with pytest.raises(RuntimeError, match="GPU"):
         op.woord_query_grid_point_index(raypos, *args[1:])
+
+
+def test_bundles_that_mix_cameras(oracle, gpu_device):
+    """the reference reads ONE camera per bundle (studio_utils.py:148-155); the fused path
+    renders a bundle that mixes cameras (nerfstudio's random-pixel batches) in one call with a per-ray camera index.
+    Eval: pixels equal the per-camera renders.  Training: loss and gradients equal the sum over per-camera steps."""
+    model, bundle0, _ = _model_and_bundle(oracle, gpu_device, N=40000, H=16, W=16, az=35.0)
+    model.neural_points.jitter = 0.0
+    model.config.hip_mlp_mode = "fp32"
+    dev = gpu_device
+    bundles = [bundle0]
+    for az in (150.0, 260.0):
+        campos, camrot, dirs = camera_rays(16, 16, az=az)
+        R = dirs.shape[0]
+        bundles.append(RayBundle(origins=campos[None].expand(R, 3).to(dev), directions=dirs.to(dev),
+                                 nears=torch.full((R, 1), 2.0, device=dev), fars=torch.full((R, 1), 6.0, device=dev),
+                                 metadata={"camrotc2w": camrot.reshape(1, 9).expand(R, 9).to(dev)}))
+    n = bundle0.directions.shape[0]
+    perm = torch.randperm(3 * n, generator=torch.Generator().manual_seed(1)).to(dev)
+    mixed = RayBundle(origins=torch.cat([b.origins for b in bundles])[perm],
+                      directions=torch.cat([b.directions for b in bundles])[perm],
+                      nears=torch.cat([b.nears for b in bundles])[perm], fars=torch.cat([b.fars for b in bundles])[perm],
+                      metadata={"camrotc2w": torch.cat([b.metadata["camrotc2w"] for b in bundles])[perm]})
+    model.eval()
+    with torch.no_grad():
+        singles = torch.cat([model(b)["coarse_raycolor"] for b in bundles])
+        masks = torch.cat([model(b)["ray_mask"] for b in bundles])
+        out = model(mixed)
+    assert torch.equal(out["coarse_raycolor"], singles[perm]) and torch.equal(out["ray_mask"], masks[perm])
+    assert masks.sum().item() > 50
+
+    model.train()
+    image = torch.rand(3 * n, 3, generator=torch.Generator().manual_seed(2)).to(dev)
+
+    def grads_of(bundle_list, images):
+        model.zero_grad(set_to_none=True)
+        total = 0.0
+        for b, im in zip(bundle_list, images):
+            o = model(b)
+            keep = (o["ray_mask"] > 0)[:, None].expand(-1, 3)
+            loss = ((o["coarse_raycolor"] - im) ** 2)[keep].sum()     # a sum, so that per-camera steps add up
+            loss.backward()
+            total += loss.item()
+        return total, {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    l_mix, g_mix = grads_of([mixed], [image[perm]])
+    l_sep, g_sep = grads_of(bundles, [image[i * n:(i + 1) * n] for i in range(3)])
+    assert abs(l_mix - l_sep) <= 1e-4 * max(1.0, abs(l_sep))
+    for k in g_sep:
+        if k.startswith("neural_points.points_conf"):
+            continue
+        scale = g_sep[k].abs().max().item()
+        assert (g_mix[k] - g_sep[k]).abs().max().item() <= 2e-3 * scale + 1e-12, k
