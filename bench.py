@@ -3,8 +3,9 @@
 
 Workload (BASELINE.json configs[1], the configuration the metric is quoted on): synthetic chair-bbox
 neural point cloud of ~6 M points, 800x800 image, D = 400 coarse samples, SR = 80 shading samples per ray,
-K = 8 neighbours, fp32, jitter 0; MLP weights Xavier-initialised (seed 0), density head scaled so that
-opacities are non-trivial.  Datasets / checkpoints are not reachable: data is synthetic, seeded.
+K = 8 neighbours, fp32 arithmetic, the reference's coarse-sample jitter of 0.3 (studio_utils.py:166; seeded:
+seed 7) in the timed legs and jitter 0 in the parity leg; MLP weights Xavier-initialised (seed 0), density head
+scaled so that opacities are non-trivial.  Datasets / checkpoints are not reachable: data is synthetic, seeded.
 
 One step = N views (N = number of GPUs).  Every view is cut into 16x16-pixel tiles dealt round-robin to the
 N ranks; each rank renders its tiles of all N views in ONE multi-camera call (N * 640000 / N = 640000 rays per
@@ -17,12 +18,13 @@ region; the timed region covers query + gather + MLPs + composite + all_gather f
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (the MLP chain k_shade_pairs*) against the
-dense MFMA peak of the mode that ran: bf16x3 (default: every fp32 product as 3 bf16 MFMA products on hi/lo
-splits, fp32 accumulate; RGB within 1e-5 of the exact mode) against 2.5 PFLOP/s, fp32 (exact fp32 MFMA) against
-157.3 TFLOP/s; `other_mode` holds the same workload in the other mode.  `cpu_baseline` times the CPU oracle
-(oracle/pnr_oracle.py, the PyTorch-CPU restatement of the reference path) on a bounded sample of the same
-workload on this box's host cores.
+Prints ONE JSON line (rank 0).  `value` is measured in the reference's arithmetic: --precision fp32 (default; every
+product and sum in fp32 on v_mfma_f32_32x32x2_f32), `roofline` prices the dominant kernel (the MLP chain
+k_shade_pairs) against the dense fp32 MFMA peak of 157.3 TFLOP/s.  `other_mode` holds the same workload, same
+steps and warm-up, in the opt-in bf16x3 mode (every fp32 product as 3 bf16 MFMA products on hi/lo splits: narrower
+than fp32, never `value`).  `cpu_baseline` times the CPU oracle (oracle/pnr_oracle.py, the PyTorch-CPU restatement
+of the reference path) on a bounded sample of the same workload on this box's host cores: median of 5 passes with
+the voxel grid built once, and one pass "as written" (grid rebuilt per 2304-ray chunk, studio_config.py:25).
 """
 from __future__ import annotations
 
@@ -46,7 +48,7 @@ from pointnerf2studio_amd.renderer import (RendererHIP, SceneHIP, WeightsHIP, gr
 FLOPS_PER_PAIR = 542_720       # 2 * (284*256 + 256*256 + 263*256 + 256*256 + 256)   SURVEY.md section 8d
 # mlp_base layer 0 is factorised (both modes): the pair kernels multiply the 60 pair inputs only, the 224
 # point-only inputs are contracted once per distinct neighbour point by k_point_part(_f32)
-FLOPS_PER_PAIR_BF16_KERNEL = 428_032   # 2 * (60*256 + 256*256 + 263*256 + 256*256 + 256): what the pair kernels do
+FLOPS_PER_PAIR_KERNEL = 428_032   # 2 * (60*256 + 256*256 + 263*256 + 256*256 + 256): what the pair kernels do
 FLOPS_PER_POINT_PART = 114_688         # 2 * 224*256
 MFMA_FLOPS_PER_PAIR_BF16 = 1_302_528   # executed: 1272 x v_mfma_f32_32x32x16_bf16 (32768 FLOP) per 32 pairs
 FLOPS_PER_SAMPLE = 137_984     # 2 * (280*128 + 2*128*128 + 128*3)
@@ -58,8 +60,15 @@ VSCALE = [2, 2, 2]
 KSIZE = [3, 3, 3]
 
 
-def cpu_baseline(points, weights, cfgd, n_side, view):
-    """Times the CPU oracle (a port of the reference's PyTorch path) on an n_side x n_side centre window."""
+REF_CHUNK = 2304   # eval_num_rays_per_chunk of the reference (studio_config.py:25)
+
+
+def cpu_baseline(points, weights, cfgd, n_side, view, passes=5):
+    """Times the CPU oracle (a port of the reference's PyTorch path) on an n_side x n_side centre window of the
+    workload, as BASELINE.md section 2 specifies: wall clock, median of `passes` after one warm-up, in two flavours --
+    (ii) the voxel grid built once for the sample (`value`: the stricter baseline) and (i) "as written": the sample
+    rendered in chunks of 2304 rays, the grid rebuilt for every chunk as the reference does
+    (query_worldcoords.cu:314-365), one pass."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pnr_oracle as O
     O.build_c_oracle()
@@ -70,29 +79,60 @@ def cpu_baseline(points, weights, cfgd, n_side, view):
     campos, camrot = synthetic.make_camera(view)
     y0, x0 = (H - n_side) // 2, (W - n_side) // 2
     dirs = synthetic.make_rays(H, W, campos, camrot, y0=y0, y1=y0 + n_side, x0=x0, x1=x0 + n_side)
+    n = dirs.shape[0]
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
-    # warm-up on a sliver (thread pools, oneDNN primitives), then ONE timed pass over the sample
-    O.render(points, weights, cfg, campos[None].expand(64, 3), dirs[:64].contiguous(), 2.0, 6.0, camrot)
+
+    def one(d):
+        return O.render(points, weights, cfg, campos[None].expand(d.shape[0], 3), d, 2.0, 6.0, camrot)
+    one(dirs[:64].contiguous())    # warm-up on a sliver (thread pools, oneDNN primitives)
+    times, ref = [], None
+    for _ in range(passes):
+        t0 = time.time()
+        ref = one(dirs)
+        times.append(time.time() - t0)
+    dt = sorted(times)[len(times) // 2]
     t0 = time.time()
-    ref = O.render(points, weights, cfg, campos[None].expand(dirs.shape[0], 3), dirs, 2.0, 6.0, camrot)
-    dt = time.time() - t0
-    return dict(value=dirs.shape[0] / dt, unit="rays/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{n_side}x{n_side} centre window of view az={view:g} ({dirs.shape[0]} rays) against the full "
-                       f"{points['xyz'].shape[0]}-point cloud, voxel grid rebuilt once for the chunk as the "
-                       f"reference does per chunk, {dt:.1f} s wall",
-                seconds=dt), ref, dirs, campos, camrot
-
-
-def pmc_traffic_bytes(kernel):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (bench.py cannot collect PMC
-    counters itself); None when the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_hbm_traffic.json")
+    for c0 in range(0, n, REF_CHUNK):
+        one(dirs[c0:c0 + REF_CHUNK].contiguous())
+    dt_written = time.time() - t0
+    cpu_model = ""
     try:
-        with open(path) as f:
-            return json.load(f)["kernels"][f"pnr::{kernel}<8>"]["hbm_bytes_per_launch_corrected"]
-    except (OSError, KeyError, ValueError):
-        return None
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+    except OSError:
+        pass
+    return dict(value=n / dt, unit="rays/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n_side}x{n_side} centre window of view az={view:g} ({n} rays) against the full "
+                       f"{points['xyz'].shape[0]}-point cloud, jitter 0, voxel grid built once for the sample; median of "
+                       f"{passes} passes after a warm-up ({', '.join(f'{t:.1f}' for t in times)} s)",
+                seconds=dt, passes=times, cpu_model=cpu_model,
+                as_written={"value": n / dt_written, "unit": "rays/s", "seconds": dt_written,
+                            "note": f"the same {n} rays in chunks of {REF_CHUNK}, the voxel grid rebuilt for every chunk "
+                                    f"as the reference does per eval chunk; one pass"},
+                counts={"R": n, "R_hit": ref["stats"]["rays_hit"], "S": ref["stats"]["valid_samples"],
+                        "M": ref["stats"]["valid_pairs"]}), ref, dirs, campos, camrot
+
+
+def pmc_traffic(kernel, workload_key):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC pass (bench.py cannot collect PMC
+    counters itself: they need rocprofv3 --pmc passes, tools/pmc_hbm.sh).  Returned only when that pass was collected
+    on THIS workload (config, N, K, SR, precision, jitter, world size); otherwise None."""
+    best = None
+    for rnd in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+        path = os.path.join(ROOT, "profiles", rnd, "pmc_hbm_traffic.json")
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            if d.get("workload_key") != workload_key:
+                continue
+            k = next((v for n, v in d["kernels"].items() if n.split("<")[0].endswith("::" + kernel)), None)
+            if k is not None:
+                best = (k["hbm_bytes_per_launch_corrected"], os.path.relpath(path, ROOT), d.get("collected_at", ""))
+                break
+        except (OSError, KeyError, ValueError):
+            continue
+    return best
 
 
 def main():
@@ -103,13 +143,19 @@ def main():
     ap.add_argument("--config", default="cfg1_chair_6m", choices=sorted(synthetic.SCENE_CONFIGS))
     ap.add_argument("--points", type=int, default=None, help="override the number of points")
     ap.add_argument("--cpu-rays-side", type=int, default=64, help="side of the CPU-baseline window (0 = skip)")
+    ap.add_argument("--cpu-passes", type=int, default=5, help="timed passes of the CPU baseline (median is reported)")
     ap.add_argument("--sigma-scale", type=float, default=300.0)
-    ap.add_argument("--no-other-mode", action="store_true", help="skip the 2-step run of the other arithmetic mode")
+    ap.add_argument("--no-other-mode", action="store_true", help="skip the side legs (other arithmetic mode, early "
+                    "termination, training step)")
+    ap.add_argument("--jitter", type=float, default=0.3, help="coarse-sample jitter of the timed legs (the reference "
+                    "renders with 0.3, studio_utils.py:166); the parity leg always runs at 0")
+    ap.add_argument("--jitter-seed", type=int, default=7)
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="diagnostic, single process: shard as rank --emulate-rank of this many ranks, no collectives")
     ap.add_argument("--emulate-rank", type=int, default=0)
-    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3"],
-                    help="MLP arithmetic: exact fp32 MFMA, or 3 bf16 MFMAs per fp32 product (hi/lo split)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
+                    help="MLP arithmetic of `value`: fp32 MFMA (the reference's arithmetic), or the opt-in 3 bf16 MFMAs "
+                         "per fp32 product (hi/lo split)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -156,7 +202,9 @@ def main():
     wh = WeightsHIP()
     wh.pack(weights, points["Rw2c"], dev)
     rnd = RendererHIP(scene, wh, SR=SR, K=K, D=400, radius_limit=4 * max(VSIZE[0], VSIZE[1]), vsize_z=VSIZE[2],
-                      precision=args.precision)
+                      precision=args.precision, jitter=args.jitter, seed=args.jitter_seed)
+    workload_key = (f"{args.config}:N={cfgd['N']}:K={K}:SR={SR}:{args.precision}:jitter={args.jitter:g}:"
+                    f"world={world}")
 
     # ---- rays: `world` views per step, this rank's tiles of each ----------------------------------------
     azimuths = [45.0 * i + 20.0 for i in range(8)]
@@ -246,71 +294,76 @@ def main():
         return float(t.item()), acc, cnt, max(recorded - lo, 1)
 
     def roofline(mode, acc_ms, cnt, n_launch):
+        """Dominant kernel = the per-pair MLP chain.  achieved = valid pairs x the fp32 FLOPs THIS kernel computes per
+        pair / its device time (HIP events on the render stream, pnr_profile_*); invalid neighbour slots and tile
+        padding are computed but not counted."""
         pairs, samples, upoints = cnt[4], cnt[3], cnt[7]
         t_pairs = acc_ms[2] / 1e3
         bf = mode == "bf16x3"
-        per_pair = FLOPS_PER_PAIR_BF16_KERNEL   # both modes run the factorised first layer
+        per_pair = FLOPS_PER_PAIR_KERNEL   # both modes run the factorised first layer
         achieved = pairs * per_pair / t_pairs / 1e12 if t_pairs > 0 else 0.0
         peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
         kernel = "k_shade_pairs_bf16" if bf else "k_shade_pairs"
-        if bf:
-            executed = pairs * MFMA_FLOPS_PER_PAIR_BF16 / t_pairs / 1e12 if t_pairs > 0 else 0.0
-            alg_bytes = pairs * 8 + upoints * 1072 + samples * 1064
-            bytes_note = "pairs*8 + distinct points*1072 + samples*1064"
-        else:
-            executed = achieved
-            alg_bytes = pairs * 8 + upoints * 1072 + samples * 1064
-            bytes_note = "pairs*8 + distinct points*1072 + samples*1064"
-        r = {
+        executed = pairs * MFMA_FLOPS_PER_PAIR_BF16 / t_pairs / 1e12 if (bf and t_pairs > 0) else achieved
+        alg_bytes = pairs * 8 + upoints * 1072 + samples * 1064
+        key = workload_key.replace(f":{args.precision}:", f":{mode}:")
+        traffic = pmc_traffic(kernel, key)
+        t_both = (acc_ms[2] + acc_ms[5]) / 1e3
+        return {
             "bound": "mfma", "kernel": kernel, "mode": mode,
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "peak_note": ("dense bf16 MFMA peak.  achieved = algorithmic fp32 FLOPs of THIS kernel (mlp_base layer 0 is "
                           "factorised: its 224 point-only inputs are contracted once per distinct neighbour point by "
                           "k_point_part, stage point_part) / its launch time; the kernel executes 3 bf16 MFMA products "
                           "per algorithmic product on padded tiles: executed_mfma_frac prices those"
-                          if bf else "dense fp32 MFMA peak; achieved = algorithmic fp32 FLOPs of THIS kernel (mlp_base layer 0 "
-                          "factorised as in the bf16x3 mode, point part in k_point_part_f32) / its launch time"),
+                          if bf else "dense fp32 MFMA peak; achieved = algorithmic fp32 FLOPs of THIS kernel (mlp_base "
+                          "layer 0 is factorised: its 224 point-only inputs are contracted once per distinct neighbour "
+                          "point by k_point_part_f32, stage point_part) / its launch time"),
             "executed_mfma_frac": executed / peak,
-            "traffic": pmc_traffic_bytes(kernel),
-            "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
-                            f"profiles/r01/pmc_hbm_traffic.json; algorithmic bytes = {bytes_note})",
+            "traffic": traffic[0] if traffic else None,
+            "traffic_source": (f"{traffic[1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this workload, collected "
+                               f"at {traffic[2]})" if traffic else
+                               "no committed PMC pass matches this workload (config / N / K / SR / mode / jitter / world)"),
             "algorithmic_bytes_per_launch": alg_bytes / n_launch,
+            "algorithmic_bytes_formula": "pairs*8 + distinct points*1072 + samples*1064",
             "avg_launch_ms": acc_ms[2] / n_launch,
             "valid_pairs_per_launch": pairs / n_launch,
             "flops_per_pair": per_pair,
-        }
-        if True:
-            t_both = (acc_ms[2] + acc_ms[5]) / 1e3
-            r["distinct_points_per_launch"] = upoints / n_launch
-            r["point_part_ms"] = acc_ms[5] / n_launch
-            r["reference_flops_per_pair"] = FLOPS_PER_PAIR
+            "distinct_points_per_launch": upoints / n_launch,
+            "point_part_ms": acc_ms[5] / n_launch,
+            "reference_flops_per_pair": FLOPS_PER_PAIR,
             # the reference's per-pair arithmetic (542,720 FLOP) over the time of both kernels that replace it
-            r["reference_equivalent_tflops"] = pairs * FLOPS_PER_PAIR / t_both / 1e12 if t_both > 0 else 0.0
-        return r
+            "reference_equivalent_tflops": pairs * FLOPS_PER_PAIR / t_both / 1e12 if t_both > 0 else 0.0,
+        }
 
     run_steps(rnd, 0, args.warmup)
     elapsed, acc_ms, acc_cnt, n_launch = timed(rnd, args.steps, args.warmup)
     rays_per_step = world * H * W
     value = rays_per_step * args.steps / elapsed
 
-    # the other arithmetic mode, for the record (same workload, 2 steps, not part of `value`)
+    # the other arithmetic mode, for the record: same workload, same steps and warm-up, never part of `value`
     alt = None
     if world == 1 and not emulate and not args.no_other_mode:
         alt_mode = "fp32" if args.precision == "bf16x3" else "bf16x3"
         rnd_alt = RendererHIP(scene, wh, SR=SR, K=K, D=400, radius_limit=4 * max(VSIZE[0], VSIZE[1]),
-                              vsize_z=VSIZE[2], precision=alt_mode)
+                              vsize_z=VSIZE[2], precision=alt_mode, jitter=args.jitter, seed=args.jitter_seed)
         rnd_alt._ws, rnd_alt._ws_key, rnd_alt.cap_samples = rnd._ws, rnd._ws_key, rnd.cap_samples
-        run_steps(rnd_alt, 0, 1)
-        a_el, a_ms, a_cnt, a_n = timed(rnd_alt, 2, 1)
-        alt = {"mode": alt_mode, "value": rays_per_step * 2 / a_el, "unit": "rays/s", "ms_per_step": a_el / 2 * 1e3,
-               "roofline": roofline(alt_mode, a_ms, a_cnt, a_n)}
+        run_steps(rnd_alt, 0, args.warmup)
+        a_el, a_ms, a_cnt, a_n = timed(rnd_alt, args.steps, args.warmup)
+        alt = {"mode": alt_mode, "dtype": "f32" if alt_mode == "fp32" else "bf16x3 products, f32 accumulate",
+               "value": rays_per_step * args.steps / a_el, "unit": "rays/s", "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": a_el / args.steps * 1e3,
+               "roofline": roofline(alt_mode, a_ms, a_cnt, a_n),
+               "note": "opt-in fast mode: 16-bit-significand operand splits, narrower than the reference's fp32" if
+                       alt_mode == "bf16x3" else "the reference's arithmetic"}
 
     # opt-in early ray termination (pnr_render_opts_t.early_stop_eps), for the record: NOT part of `value`, which
     # keeps the reference's sample set (every sample with a neighbour is shaded)
     early = None
     if world == 1 and not emulate and not args.no_other_mode:
         rnd_es = RendererHIP(scene, wh, SR=SR, K=K, D=400, radius_limit=4 * max(VSIZE[0], VSIZE[1]),
-                             vsize_z=VSIZE[2], precision=args.precision, early_stop_eps=1e-5)
+                             vsize_z=VSIZE[2], precision=args.precision, early_stop_eps=1e-5, jitter=args.jitter,
+                             seed=args.jitter_seed)
         rnd_es._ws, rnd_es._ws_key, rnd_es.cap_samples = rnd._ws, rnd._ws_key, rnd.cap_samples
         run_steps(rnd_es, 0, 1)
         e_rgb = outs["rgb"].clone()
@@ -376,7 +429,9 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{args.config}: chair-bbox synthetic cloud N={cfgd['N']}, {H}x{W} image, D=400, "
-                            f"SR={SR}, K={K}, P={cfgd['P']}, jitter=0, {world} view(s)/step",
+                            f"SR={SR}, K={K}, P={cfgd['P']}, jitter={args.jitter:g} (seed {args.jitter_seed}), {world} "
+                            f"view(s)/step",
+                "workload_key": workload_key,
                 "rays_per_step": rays_per_step, "global_batch": rays_per_step, "mlp_mode": args.precision,
                 "rays_per_rank_per_step": n_local,
                 "parallelism": f"ray-tile shard x{world} (16x16 tiles round-robin), one multi-camera render + one "
@@ -396,12 +451,14 @@ def main():
         if train is not None:
             result["training_step"] = train
         if world == 1 and not emulate and args.cpu_rays_side > 0:
-            cb, ref, dirs, campos, camrot = cpu_baseline(points, weights, cfgd, args.cpu_rays_side, azimuths[0])
+            cb, ref, dirs, campos, camrot = cpu_baseline(points, weights, cfgd, args.cpu_rays_side, azimuths[0], args.cpu_passes)
             # parity on the very same rays: HIP render vs the oracle that was just timed
             out = RendererHIP(scene, wh, SR=SR, K=K, D=400, radius_limit=4 * max(VSIZE[0], VSIZE[1]),
                               vsize_z=VSIZE[2], precision=args.precision).render(dirs.to(dev), campos, camrot, 2.0, 6.0)
+            # (jitter 0 on both sides: the oracle pass that was timed and this render see the same sample positions)
             err = (out["rgb"].cpu() - ref["coarse_raycolor"]).abs().max().item()
-            result["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample")}
+            result["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "seconds",
+                                                         "cpu_model", "as_written", "counts")}
             result["parity_on_cpu_sample"] = {
                 "max_abs_rgb_err": err, "ray_mask_equal": bool(torch.equal(out["ray_mask"].cpu(), ref["ray_mask"])),
                 "psnr_vs_oracle_db": float(-10 * torch.log10(((out["rgb"].cpu() - ref["coarse_raycolor"]) ** 2).mean()

@@ -93,7 +93,9 @@ class PointNerfConfig(ModelConfig):
     zero_one_loss_weights: float = 0.0001
 
     # additions of this build (not in the reference): arithmetic of the fused HIP MLP, see include/pnr.h
-    hip_mlp_mode: str = "bf16x3"   # "bf16x3" (3 bf16 MFMA products per fp32 product) or "fp32" (exact)
+    # "fp32" (default: every product and sum in fp32, the reference's arithmetic) or the opt-in fast mode "bf16x3"
+    # (3 bf16 MFMA products per fp32 product: image within ~2e-5 of fp32, gradients with ~1e-2 relative noise)
+    hip_mlp_mode: str = "fp32"
     hip_early_stop_eps: float = 0.0  # eval only: > 0 stops shading a ray once its transmittance is below eps
     hip_fused_training: bool = True  # training: fused HIP render + pnr_render_backward instead of torch autograd
     # opt-in (a behaviour change: the reference discards them, studio_utils.py:84-90): initialise the plugin MLPs from
@@ -266,14 +268,14 @@ class PointNerf(Model):
                                                    radius_limit=float(self.neural_points.radius_limit_np),
                                                    vsize_z=c.vsize[2], eval_clamp=False,
                                                    bg=self._background_color.tolist(),
-                                                   precision=getattr(c, "hip_mlp_mode", "bf16x3"))
+                                                   precision=getattr(c, "hip_mlp_mode", "fp32"))
             self._renderer_train.mlp_state = sd
             return self._renderer_train
         if self._renderer is None or self._renderer.scene is not scene:
             self._renderer = RendererHIP(scene, self._weights, SR=c.SR, K=c.K, D=c.z_depth_dim,
                                          radius_limit=float(self.neural_points.radius_limit_np),
                                          vsize_z=c.vsize[2], eval_clamp=True, bg=self._background_color.tolist(),
-                                         precision=getattr(c, "hip_mlp_mode", "bf16x3"),
+                                         precision=getattr(c, "hip_mlp_mode", "fp32"),
                                          early_stop_eps=float(getattr(c, "hip_early_stop_eps", 0.0)))
         return self._renderer
 
@@ -438,10 +440,12 @@ class PointNerf(Model):
 
     def get_training_callbacks(self, training_callback_attributes: TrainingCallbackAttributes) -> List[TrainingCallback]:
         """The reference inherits nerfstudio's empty list.  Here one callback runs after every optimiser step:
-        point features and MLP weights changed, so the packed HIP copies used by the fused eval path are
-        invalidated (they are re-packed lazily, on the next eval render)."""
+        point features and MLP weights changed, so the PACKED copies (point rows, MFMA-ordered weights) are marked
+        stale and re-packed lazily by the next render.  The voxel structure, the SceneHIP / RendererHIP objects and
+        their workspaces stay: points_xyz is frozen (studio_utils.py:84), and a real change of it is caught by the
+        (data_ptr, _version) key of NeuralPoints.fused_scene."""
         def _invalidate(step: int = 0):
-            self.neural_points.invalidate()
+            self.neural_points.invalidate_packed()
             self._weights_key = None
         return [TrainingCallback(where_to_run=[TrainingCallbackLocation.AFTER_TRAIN_ITERATION], func=_invalidate)]
 

@@ -227,6 +227,10 @@ class NeuralPoints(nn.Module):
         return self._fused_scene
 
     def invalidate(self) -> None:
-        """Forces a rebuild + repack at the next fused render (training callback hook)."""
+        """Forces a rebuild of the voxel structure + repack at the next fused render (the cloud itself changed)."""
         self._fused_key = None
+        self._packed_key = None
+
+    def invalidate_packed(self) -> None:
+        """Forces a repack of the point rows only (features changed, positions did not): the training callback."""
         self._packed_key = None

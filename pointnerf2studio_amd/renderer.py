@@ -153,7 +153,8 @@ class SceneHIP:
         with torch.cuda.device(dev):
             _lib.check(self.lib.pnr_points_pack(self.handle, _ptr(x), _ptr(e), _ptr(c), _ptr(d), _ptr(col), N,
                                                 _stream_ptr(dev)), "pnr_points_pack")
-            torch.cuda.current_stream(dev).synchronize()  # inputs above may be temporaries
+        # no synchronisation: converted temporaries return to torch's caching allocator, which hands a block out
+        # again only to work queued behind this launch on the same stream
 
 
 class WeightsHIP:
@@ -216,12 +217,13 @@ def query_raypos(scene: SceneHIP, raypos: torch.Tensor, SR: int, K: int, radius_
 
 class RendererHIP:
     """Fused render of one ray bundle.  Owns a growable workspace; `cap_samples` (selected shading samples
-    the workspace can hold) grows automatically when a frame overflows it.  precision: "bf16x3" (default: three bf16
-    MFMA products per fp32 product, image within ~1e-5 of fp32) or "fp32" (every product in fp32)."""
+    the workspace can hold) grows automatically when a frame overflows it.  precision: "fp32" (default: every product
+    and sum in fp32 on v_mfma_f32_32x32x2_f32, the reference's arithmetic) or the opt-in "bf16x3" (three bf16 MFMA
+    products per fp32 product, image within ~2e-5 of fp32)."""
 
     def __init__(self, scene: SceneHIP, weights: WeightsHIP, SR: int = 80, K: int = 8, D: int = 400,
                  radius_limit: float = 0.016, vsize_z: float = 0.004, eval_clamp: bool = True,
-                 bg=(1.0, 1.0, 1.0), precision: str = "bf16x3", jitter: float = 0.0, seed: int = 0,
+                 bg=(1.0, 1.0, 1.0), precision: str = "fp32", jitter: float = 0.0, seed: int = 0,
                  early_stop_eps: float = 0.0):
         self.lib = _lib.load()
         self.scene, self.weights = scene, weights
@@ -377,7 +379,7 @@ class RendererHIP:
                 self.scene.handle, self.weights.handle, C.byref(wp), C.byref(bp), _ptr(d), R, arr, n, _ptr(rc),
                 rays_per_cam, C.byref(self.opts), _ptr(g), _ptr(ws), ws.numel(), cap, _ptr(self._tws),
                 self._tws.numel(), C.byref(grads), _ptr(out["rgb"]), _stream_ptr(dev)), "pnr_render_backward")
-            torch.cuda.current_stream(dev).synchronize()  # the converted inputs above may be temporaries
+        # no synchronisation (see pack_points): everything is queued on torch's current stream
         return out
 
     def touched_points(self) -> torch.Tensor:

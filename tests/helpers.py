@@ -6,6 +6,25 @@ from pointnerf2studio_amd import synthetic
 from pointnerf2studio_amd.renderer import (RendererHIP, SceneHIP, WeightsHIP, grid_hyperparameters)
 
 
+# ---- tolerances, in ONE place ------------------------------------------------------------------------------
+# The bar of BASELINE.json's north_star, which the DEFAULT arithmetic mode ("fp32": PointNerfConfig.hip_mlp_mode,
+# RendererHIP(precision=...), bench.py --precision) meets everywhere: RGB / depth / accumulation within 1e-4 abs of
+# the CPU oracle, per-sample sigma within 1e-4 relative, neighbour lists / sample positions / ray mask bit-exact,
+# every gradient tensor within 2e-3 of its own largest magnitude.
+DEFAULT_MODE = "fp32"
+NORTH_STAR = dict(rgb=1e-4, depth=1e-4, acc=1e-4, sigma_rel=1e-4, grad_rel=2e-3)
+# The opt-in fast mode "bf16x3" (3 bf16 MFMA products per fp32 product) is narrower than fp32 by construction
+# (2^-16 relative per product).  What it is held to is its own documented accuracy, NOT the north_star bar: the
+# image within 1e-4, depth within 3e-4 (blend weights x ray parameters up to far = 6), sigma within 1e-4 of the
+# largest sigma, gradients within 2e-2 relative L2 / 1e-1 of the largest entry (LeakyReLU units within ~1e-5 of
+# zero fall on the other side of the kink than in the fp32 oracle).  Index lists do not depend on the mode.
+OPT_IN_BF16X3 = dict(rgb=1e-4, depth=3e-4, acc=1e-4, sigma_of_max=1e-4, grad_l2=2e-2, grad_max=1e-1)
+
+
+def tol(mode, key):
+    return (NORTH_STAR if mode == DEFAULT_MODE else OPT_IN_BF16X3)[key]
+
+
 def small_scene(N=60000, seed=1234, shrink=1.0):
     pts = synthetic.make_points(N, seed=seed)
     if shrink != 1.0:

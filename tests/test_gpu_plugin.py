@@ -116,6 +116,41 @@ def test_fused_training_step_equals_autograd_path(oracle, gpu_device):
     assert "neural_points.points_conf" in g_fus and g_fus["neural_points.points_conf"].abs().sum().item() > 0
 
 
+def test_consecutive_fused_training_steps_reuse_scene_and_workspace(oracle, gpu_device):
+    """The AFTER_TRAIN_ITERATION callback marks the packed point rows / weights stale and nothing else: the voxel
+    structure (SceneHIP handle), the training renderer and its workspaces survive an optimiser step (points_xyz is
+    frozen, studio_utils.py:84), and the next step renders with the UPDATED features."""
+    model, bundle, _ = _model_and_bundle(oracle, gpu_device, N=40000, H=24, W=24)
+    model.train()
+    model.neural_points.jitter = 0.0
+    opt = torch.optim.SGD([{"params": g} for g in model.get_param_groups().values()], lr=1e-2)
+    image = torch.rand(bundle.directions.shape[0], 3, device=gpu_device)
+    seen = []
+    for it in range(3):
+        opt.zero_grad(set_to_none=True)
+        out = model(bundle)
+        sum(model.get_loss_dict(out, {"image": image}).values()).backward()
+        opt.step()
+        for cb in model.get_training_callbacks(None):
+            cb.run_callback(step=it)
+        rnd = model._renderer_train
+        seen.append((model.neural_points._fused_scene, model.neural_points._fused_scene.handle.value, rnd,
+                     rnd._ws.data_ptr(), rnd._tws.data_ptr(), rnd.cap_samples, out["coarse_raycolor"].detach().clone()))
+    for a, b in zip(seen, seen[1:]):
+        assert a[0] is b[0] and a[1] == b[1], "the voxel structure was rebuilt between two training steps"
+        assert a[2] is b[2] and a[3] == b[3] and a[4] == b[4] and a[5] == b[5], "workspaces were reallocated"
+        assert not torch.equal(a[6], b[6]), "the second step did not see the optimiser's update"
+    # ... and the eval renderer picks the trained features up as well, on the same scene
+    model.eval()
+    with torch.no_grad():
+        ev = model(bundle)
+    assert model.neural_points._fused_scene is seen[0][0]
+    inside = (ev["coarse_raycolor"] > 0) & (ev["coarse_raycolor"] < 1)
+    model.train()
+    tr = model(bundle)["coarse_raycolor"].detach()
+    assert (ev["coarse_raycolor"] - tr)[inside].abs().max().item() <= 1e-5
+
+
 def test_dropin_query_op_signature(oracle, gpu_device):
     """The 17-argument call of studio_utils.py:172-188, verbatim."""
     from pointnerf2studio_amd.neural_points import QueryWorldcoordsHIP

@@ -5,14 +5,14 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import build_hip, camera_rays, oracle_cfg, small_scene
+from helpers import NORTH_STAR, OPT_IN_BF16X3, build_hip, camera_rays, oracle_cfg, small_scene
 from pointnerf2studio_amd import synthetic
 from pointnerf2studio_amd.renderer import RendererHIP
 
 pytestmark = pytest.mark.gpu
 
-RGB_TOL = 1e-4
-DEPTH_TOL = 1e-4
+RGB_TOL = NORTH_STAR["rgb"]
+DEPTH_TOL = NORTH_STAR["depth"]
 
 
 def _render_both(oracle, device, N, SR, K, P, H, W, az, sigma_scale=300.0, shrink=1.0, window=None, Rw2c=None,
@@ -94,8 +94,10 @@ def test_render_bf16x3_rotated_frame_and_sigma(oracle, gpu_device):
         d, rd = dec[off[r]:off[r] + cnt[r]], ref_dec[row, :cnt[r]]
         worst = max(worst, float(np.max(np.abs(d[:, 0] - rd[:, 0]))))
     smax = float(ref_dec[..., 0].max())
-    # hi/lo-split products carry ~2^-16 relative error on |w||x| sums: sigma is good to ~1e-4 of its scale
-    assert worst <= 1e-4 * smax, f"sigma abs error {worst:.3e} vs scale {smax:.1f} in bf16x3 mode"
+    # hi/lo-split products carry ~2^-16 relative error on |w||x| sums: sigma is good to ~1e-4 of its scale (the
+    # opt-in mode's documented accuracy; the default fp32 mode is held to 1e-4 RELATIVE per sample in
+    # test_render_decoded_features_and_neighbours)
+    assert worst <= OPT_IN_BF16X3["sigma_of_max"] * smax, f"sigma abs error {worst:.3e} vs scale {smax:.1f} in bf16x3 mode"
 
 
 def test_render_decoded_features_and_neighbours(oracle, gpu_device):
@@ -123,8 +125,8 @@ def test_render_decoded_features_and_neighbours(oracle, gpu_device):
         d, rd = dec[o:o + c], ref_dec[row, :c]
         worst_sigma = max(worst_sigma, float(np.max(np.abs(d[:, 0] - rd[:, 0]) / (1.0 + np.abs(rd[:, 0])))))
         worst_rgb = max(worst_rgb, float(np.max(np.abs(d[:, 1:] - rd[:, 1:]))))
-    assert worst_sigma <= 1e-4, f"sigma relative error {worst_sigma:.3e}"
-    assert worst_rgb <= 1e-4, f"per-sample rgb error {worst_rgb:.3e}"
+    assert worst_sigma <= NORTH_STAR["sigma_rel"], f"sigma relative error {worst_sigma:.3e}"
+    assert worst_rgb <= NORTH_STAR["rgb"], f"per-sample rgb error {worst_rgb:.3e}"
 
 
 def test_render_rotated_point_frame(oracle, gpu_device):

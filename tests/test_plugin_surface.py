@@ -54,6 +54,20 @@ def test_config_fields_and_defaults_match_reference():
     assert set(expect) <= names
 
 
+def test_default_arithmetic_is_the_references_fp32():
+    """The product computes in the reference's arithmetic unless asked otherwise: fp32 is the default of the plugin
+    config, of RendererHIP and of bench.py's headline; bf16x3 (narrower) is opt-in everywhere."""
+    import inspect
+    import re
+    from pathlib import Path
+    from pointnerf2studio_amd.renderer import RendererHIP
+    assert PointNerfConfig().hip_mlp_mode == "fp32"
+    assert inspect.signature(RendererHIP.__init__).parameters["precision"].default == "fp32"
+    bench = (Path(__file__).resolve().parent.parent / "bench.py").read_text()
+    m = re.search(r'add_argument\("--precision", default="(\w+)"', bench)
+    assert m and m.group(1) == "fp32"
+
+
 def test_missing_point_cloud_raises_like_reference(tmp_path):
     with pytest.raises(RuntimeError, match="does not exist"):
         PointNerfConfig(path_point_cloud=tmp_path / "nope")
@@ -90,7 +104,11 @@ def test_training_callbacks_invalidate_packed_copies():
     assert len(cbs) == 1
     m.neural_points._fused_key, m.neural_points._packed_key, m._weights_key = "a", "b", "c"
     cbs[0].run_callback(step=3)
-    assert m.neural_points._fused_key is None and m.neural_points._packed_key is None and m._weights_key is None
+    # the packed copies (point rows, MFMA-ordered weights) go stale; the voxel structure stays (points_xyz is frozen)
+    assert m.neural_points._packed_key is None and m._weights_key is None
+    assert m.neural_points._fused_key == "a"
+    m.neural_points.invalidate()          # a real change of the cloud (grow / prune) drops the structure too
+    assert m.neural_points._fused_key is None
 
 
 def test_loss_dict_keys_and_values():

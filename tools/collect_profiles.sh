@@ -1,25 +1,39 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (gpurun -- 'bash tools/collect_profiles.sh'): the bench line, the rocprofv3 kernel trace of the
-# same command and the two HBM-traffic PMC passes, into gpurun_out/prof_final/.  Summaries are then copied to
-# profiles/<round>/ by hand (tools/summarize_profiles.py makes the JSON / trimmed CSV).
+# Runs ON THE GPU BOX (gpurun -- 'bash tools/collect_profiles.sh [what]'): the bench line, the rocprofv3 kernel trace of
+# the same command, the HBM-traffic PMC passes and the MFMA-busy PMC pass, into gpurun_out/prof_rNN/.
+# tools/summarize_profiles.py then condenses them into profiles/<round>/ (run on the host).
+#   what = all (default) | bench | trace | pmc
 set -e -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/prof_final
-rm -rf $O
+WHAT=${1:-all}
+O=gpurun_out/prof_r02
 mkdir -p $O
-echo "[1/5] bench (default flags)"; python bench.py > $O/bench_default.json 2> $O/bench_default.err
-echo "[2/5] bench fp32"; python bench.py --precision fp32 --cpu-rays-side 0 > $O/bench_fp32.json 2> $O/bench_fp32.err
-# the profiled runs skip the side legs (other arithmetic mode, early termination): the last launches of every kernel
-# are then the timed ones
-echo "[3/7] kernel trace"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python bench.py --steps 4 --warmup 1 --cpu-rays-side 0 \
-    --no-other-mode > $O/bench_under_rocprof.json 2> $O/trace.err
-for mode in bf16x3 fp32; do
-  echo "[PMC] FETCH_SIZE $mode"
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$mode -- python bench.py --steps 2 --warmup 1 \
-      --cpu-rays-side 0 --no-other-mode --precision $mode > $O/bench_pmc_fetch_$mode.json 2> $O/pmc_fetch_$mode.err
-  echo "[PMC] WRITE_SIZE $mode"
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$mode -- python bench.py --steps 2 --warmup 1 \
-      --cpu-rays-side 0 --no-other-mode --precision $mode > $O/bench_pmc_write_$mode.json 2> $O/pmc_write_$mode.err
-done
-echo done; ls -R $O | head -40
+if [ "$WHAT" = all ] || [ "$WHAT" = bench ]; then
+  echo "[bench] default flags (fp32 headline, all side legs, CPU baseline)"
+  python bench.py > $O/bench_default.json 2> $O/bench_default.err
+fi
+# the profiled runs skip the side legs (other arithmetic mode, early termination, training step, CPU baseline): the
+# last launches of every kernel are then the timed ones
+if [ "$WHAT" = all ] || [ "$WHAT" = trace ]; then
+  for mode in fp32 bf16x3; do
+    echo "[trace] kernel trace $mode"
+    rm -rf $O/trace_$mode
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$mode -- python bench.py --steps 4 --warmup 1 \
+        --cpu-rays-side 0 --no-other-mode --precision $mode > $O/bench_under_rocprof_$mode.json 2> $O/trace_$mode.err
+  done
+fi
+if [ "$WHAT" = all ] || [ "$WHAT" = pmc ]; then
+  for mode in fp32 bf16x3; do
+    for counter in FETCH_SIZE WRITE_SIZE; do
+      echo "[pmc] $counter $mode"
+      rm -rf $O/pmc_${counter}_$mode
+      rocprofv3 --pmc $counter --output-format csv -d $O/pmc_${counter}_$mode -- python bench.py --steps 2 --warmup 1 \
+          --cpu-rays-side 0 --no-other-mode --precision $mode > $O/bench_pmc_${counter}_$mode.json 2> $O/pmc_${counter}_$mode.err
+    done
+    echo "[pmc] MFMA busy / clock $mode"
+    rm -rf $O/pmc_mfma_$mode
+    rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/pmc_mfma_$mode -- python bench.py \
+        --steps 3 --warmup 1 --cpu-rays-side 0 --no-other-mode --precision $mode > $O/bench_pmc_mfma_$mode.json 2> $O/pmc_mfma_$mode.err
+  done
+fi
+echo done; ls $O

@@ -1,72 +1,130 @@
-"""Host side of tools/collect_profiles.sh: turns gpurun_out/prof_final/ into the files kept under profiles/<round>/.
-Usage: python tools/summarize_profiles.py gpurun_out/prof_final profiles/r01"""
+"""Host side of tools/collect_profiles.sh: condenses gpurun_out/prof_rNN/ into the files kept under profiles/<round>/.
+Usage: python tools/summarize_profiles.py gpurun_out/prof_r02 profiles/r02 [git-sha]"""
 import csv
 import glob
 import json
 import os
 import shutil
+import subprocess
 import sys
 from collections import defaultdict
 
 src, dst = sys.argv[1], sys.argv[2]
+sha = sys.argv[3] if len(sys.argv) > 3 else subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True,
+                                                           text=True).stdout.strip()
 os.makedirs(dst, exist_ok=True)
+MODES = ("fp32", "bf16x3")
 
 
 def one(pattern):
     hits = glob.glob(os.path.join(src, pattern), recursive=True)
-    if not hits:
-        raise SystemExit(f"missing {pattern} under {src}")
-    return max(hits, key=os.path.getmtime)  # the newest run if the directory holds several
+    return max(hits, key=os.path.getmtime) if hits else None  # the newest run if the directory holds several
 
 
-for name, out in (("bench_default.json", "bench_cfg1_n1_bf16x3.json"), ("bench_fp32.json", "bench_cfg1_n1_fp32.json"),
-                  ("bench_under_rocprof.json", "bench_cfg1_n1_bf16x3_under_rocprof.json")):
-    shutil.copy(os.path.join(src, name), os.path.join(dst, out))
+def bench_line(path):
+    with open(path) as f:
+        lines = [ln for ln in f if ln.startswith("{")]
+    return json.loads(lines[-1])
 
-# kernel stats: keep our kernels (pnr::) and the few largest others
-rows = list(csv.DictReader(open(one("trace/**/*kernel_stats.csv"))))
-keep = [r for r in rows if "pnr::" in r["Name"]] + [r for r in rows if "pnr::" not in r["Name"]][:8]
-with open(os.path.join(dst, "kernel_stats_bench_cfg1_bf16x3.csv"), "w", newline="") as f:
-    w = csv.DictWriter(f, fieldnames=rows[0].keys())
-    w.writeheader()
-    w.writerows(keep)
-# per-dispatch durations of the two dominant kernels (to compare with the HIP-event figure of the same run)
-trace = list(csv.DictReader(open(one("trace/**/*kernel_trace.csv"))))
-disp = defaultdict(list)
-for r in trace:
-    n = r["Kernel_Name"]
-    if "k_shade_pairs" in n or "k_point_part" in n or "k_shade_color" in n:
-        disp[n.split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
-json.dump({k: v for k, v in disp.items()}, open(os.path.join(dst, "dispatch_ms_bench_cfg1_bf16x3.json"), "w"), indent=1)
 
-# PMC passes
-out = {"command": "rocprofv3 --pmc <COUNTER> --output-format csv -- python bench.py --steps 2 --warmup 1 --cpu-rays-side 0 "
-                  "--no-other-mode --precision <MODE> (one pass per counter and mode)",
-       "units": "FETCH_SIZE / WRITE_SIZE are reported in KiB; bytes = value * 1024",
-       "gfx950_correction": "FETCH_SIZE reads 1/2 of the bytes of a wide 16-B/lane read (MI355X_MICROARCH.md, HBM): "
-                            "hbm_read_bytes = 2 * FETCH_SIZE * 1024 for the kernels below marked corrected",
-       "kernels": {}}
-for counter, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
-    acc = defaultdict(list)
-    for mode in ("bf16x3", "fp32"):
-        for r in csv.DictReader(open(one(f"{d}_{mode}/**/*counter_collection.csv"))):
-            name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-            # each mode's run contributes its own MLP kernels; the mode-independent kernels come from the first run
-            mlp = "k_shade" in name or "k_point_part" in name
-            if r["Counter_Name"] == counter and "pnr::" in name and (mlp or mode == "bf16x3"):
-                acc[name].append(float(r["Counter_Value"]))
-    for k, v in acc.items():
-        e = out["kernels"].setdefault(k, {})
-        e[f"{counter}_KiB_avg_per_launch"] = sum(v) / len(v)
-        e[f"launches_{counter}"] = len(v)
-        if "k_shade" in k or "k_point_part" in k:
-            # the timed launches are the last ones; warm-up / sizing launches render smaller windows
-            last = v[-2:]
-            e[f"{counter}_KiB_timed_launches"] = last
-for k, e in out["kernels"].items():
-    if "FETCH_SIZE_KiB_timed_launches" in e and "WRITE_SIZE_KiB_timed_launches" in e:
-        f = sum(e["FETCH_SIZE_KiB_timed_launches"]) / len(e["FETCH_SIZE_KiB_timed_launches"])
-        w = sum(e["WRITE_SIZE_KiB_timed_launches"]) / len(e["WRITE_SIZE_KiB_timed_launches"])
-        e["hbm_bytes_per_launch_corrected"] = (2 * f + w) * 1024
-json.dump(out, open(os.path.join(dst, "pmc_hbm_traffic.json"), "w"), indent=1)
+if os.path.exists(os.path.join(src, "bench_default.json")):
+    shutil.copy(os.path.join(src, "bench_default.json"), os.path.join(dst, "bench_cfg1_n1_default.json"))
+
+for mode in MODES:
+    stats = one(f"trace_{mode}/**/*kernel_stats.csv")
+    if not stats:
+        continue
+    shutil.copy(os.path.join(src, f"bench_under_rocprof_{mode}.json"),
+                os.path.join(dst, f"bench_cfg1_n1_{mode}_under_rocprof.json"))
+    # kernel stats: keep our kernels (pnr::) and the few largest others
+    rows = list(csv.DictReader(open(stats)))
+    keep = [r for r in rows if "pnr::" in r["Name"]] + [r for r in rows if "pnr::" not in r["Name"]][:8]
+    with open(os.path.join(dst, f"kernel_stats_bench_cfg1_{mode}.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=rows[0].keys())
+        w.writeheader()
+        w.writerows(keep)
+    # per-dispatch durations of the MLP kernels (to compare with the HIP-event figure of the same run)
+    trace = list(csv.DictReader(open(one(f"trace_{mode}/**/*kernel_trace.csv"))))
+    disp = defaultdict(list)
+    for r in trace:
+        n = r["Kernel_Name"]
+        if "k_shade_pairs" in n or "k_point_part" in n or "k_shade_color" in n:
+            disp[n.split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    b = bench_line(os.path.join(src, f"bench_under_rocprof_{mode}.json"))
+    json.dump({"command": f"rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 4 --warmup 1 "
+                          f"--cpu-rays-side 0 --no-other-mode --precision {mode}",
+               "collected_at": sha, "workload_key": b["config"]["workload_key"],
+               "hip_event_avg_launch_ms_of_the_same_run": b["roofline"]["avg_launch_ms"],
+               "timed_dispatches": 4, "dispatch_ms": dict(disp)},
+              open(os.path.join(dst, f"dispatch_ms_bench_cfg1_{mode}.json"), "w"), indent=1)
+
+# HBM traffic PMC passes
+keys = {}
+for mode in MODES:
+    p = os.path.join(src, f"bench_pmc_FETCH_SIZE_{mode}.json")
+    if os.path.exists(p):
+        keys[mode] = bench_line(p)["config"]["workload_key"]
+if keys:
+    out = {"command": "rocprofv3 --pmc <COUNTER> --output-format csv -- python bench.py --steps 2 --warmup 1 --cpu-rays-side 0 "
+                      "--no-other-mode --precision <MODE> (one pass per counter and mode)",
+           "collected_at": sha,
+           # bench.py quotes a kernel's traffic only when its own workload_key equals the one recorded here
+           "workload_key": keys.get("fp32") or next(iter(keys.values())), "workload_keys": keys,
+           "units": "FETCH_SIZE / WRITE_SIZE are reported in KiB; bytes = value * 1024",
+           "gfx950_correction": "FETCH_SIZE reads 1/2 of the bytes of a wide 16-B/lane read (MI355X_MICROARCH.md, HBM): "
+                                "hbm_read_bytes = 2 * FETCH_SIZE * 1024 for the kernels below marked corrected",
+           "kernels": {}}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        acc = defaultdict(list)
+        for i, mode in enumerate(MODES):
+            f = one(f"pmc_{counter}_{mode}/**/*counter_collection.csv")
+            if not f:
+                continue
+            for r in csv.DictReader(open(f)):
+                name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+                # each mode's run contributes its own MLP kernels; the mode-independent kernels come from the first run
+                mlp = "k_shade" in name or "k_point_part" in name
+                if r["Counter_Name"] == counter and "pnr::" in name and (mlp or i == 0):
+                    acc[name].append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            e = out["kernels"].setdefault(k, {})
+            e[f"{counter}_KiB_avg_per_launch"] = sum(v) / len(v)
+            e[f"launches_{counter}"] = len(v)
+            # the timed launches are the last ones; warm-up / sizing launches render other views
+            e[f"{counter}_KiB_timed_launches"] = v[-2:]
+    for k, e in out["kernels"].items():
+        if "FETCH_SIZE_KiB_timed_launches" in e and "WRITE_SIZE_KiB_timed_launches" in e:
+            f = sum(e["FETCH_SIZE_KiB_timed_launches"]) / len(e["FETCH_SIZE_KiB_timed_launches"])
+            w = sum(e["WRITE_SIZE_KiB_timed_launches"]) / len(e["WRITE_SIZE_KiB_timed_launches"])
+            e["hbm_bytes_per_launch_corrected"] = (2 * f + w) * 1024
+    json.dump(out, open(os.path.join(dst, "pmc_hbm_traffic.json"), "w"), indent=1)
+
+# MFMA busy / effective clock
+busy = {"command": "rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -- python bench.py --steps 3 "
+                   "--warmup 1 --cpu-rays-side 0 --no-other-mode --precision <MODE>", "collected_at": sha,
+        "definitions": {"clock_ghz": "GRBM_GUI_ACTIVE / 8 XCDs / dispatch ns",
+                        "mfma_busy": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 4 SIMDs * 256 CUs)"}, "kernels": {}}
+for mode in MODES:
+    f = one(f"pmc_mfma_{mode}/**/*counter_collection.csv")
+    if not f:
+        continue
+    rows = defaultdict(dict)
+    for r in csv.DictReader(open(f)):
+        n = r["Kernel_Name"].split("(")[0]
+        if "pnr::" in n and ("shade" in n or "point_part" in n):
+            k = (int(r["Dispatch_Id"]), n)
+            rows[k][r["Counter_Name"]] = float(r["Counter_Value"])
+            rows[k]["ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    per = defaultdict(list)
+    for (d, n), v in sorted(rows.items()):
+        per[n].append(v)
+    for n, vs in per.items():
+        vs = vs[-3:]   # the timed launches
+        gui = [v.get("GRBM_GUI_ACTIVE", 0) / 8 for v in vs]
+        busy["kernels"][mode + " " + n] = {
+            "launches": len(vs), "ms": [round(v["ns"] / 1e6, 3) for v in vs],
+            "clock_ghz": [round(g / v["ns"], 3) for g, v in zip(gui, vs)],
+            "mfma_busy": [round(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (g * 1024 + 1e-9), 3) for g, v in zip(gui, vs)]}
+if busy["kernels"]:
+    json.dump(busy, open(os.path.join(dst, "pmc_mfma_busy.json"), "w"), indent=1)
 print("wrote", sorted(os.listdir(dst)))
