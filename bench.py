@@ -63,7 +63,7 @@ KSIZE = [3, 3, 3]
 REF_CHUNK = 2304   # eval_num_rays_per_chunk of the reference (studio_config.py:25)
 
 
-def cpu_baseline(points, weights, cfgd, n_side, view, passes=5):
+def cpu_baseline(points, weights, cfgd, n_side, view, passes=5, budget_s=270.0):
     """Times the CPU oracle (a port of the reference's PyTorch path) on an n_side x n_side centre window of the
     workload, as BASELINE.md section 2 specifies: wall clock, median of `passes` after one warm-up, in two flavours --
     (ii) the voxel grid built once for the sample (`value`: the stricter baseline) and (i) "as written": the sample
@@ -86,16 +86,22 @@ def cpu_baseline(points, weights, cfgd, n_side, view, passes=5):
     def one(d):
         return O.render(points, weights, cfg, campos[None].expand(d.shape[0], 3), d, 2.0, 6.0, camrot)
     one(dirs[:64].contiguous())    # warm-up on a sliver (thread pools, oneDNN primitives)
-    times, ref = [], None
-    for _ in range(passes):
+    t_leg = time.time()
+    times, ref, dt_written = [], None, None
+    for i in range(passes):
+        # time-boxed: the default bench run must finish within minutes on whatever host the box has; every pass after
+        # the first is taken only while the leg's budget allows one more
+        if times and time.time() - t_leg + max(times) > budget_s:
+            break
         t0 = time.time()
         ref = one(dirs)
         times.append(time.time() - t0)
+        if i == 0:
+            t0 = time.time()
+            for c0 in range(0, n, REF_CHUNK):
+                one(dirs[c0:c0 + REF_CHUNK].contiguous())
+            dt_written = time.time() - t0
     dt = sorted(times)[len(times) // 2]
-    t0 = time.time()
-    for c0 in range(0, n, REF_CHUNK):
-        one(dirs[c0:c0 + REF_CHUNK].contiguous())
-    dt_written = time.time() - t0
     cpu_model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -105,7 +111,7 @@ def cpu_baseline(points, weights, cfgd, n_side, view, passes=5):
     return dict(value=n / dt, unit="rays/s", cores=torch.get_num_threads(), kind="port",
                 sample=f"{n_side}x{n_side} centre window of view az={view:g} ({n} rays) against the full "
                        f"{points['xyz'].shape[0]}-point cloud, jitter 0, voxel grid built once for the sample; median of "
-                       f"{passes} passes after a warm-up ({', '.join(f'{t:.1f}' for t in times)} s)",
+                       f"{len(times)} passes after a warm-up ({', '.join(f'{t:.1f}' for t in times)} s)",
                 seconds=dt, passes=times, cpu_model=cpu_model,
                 as_written={"value": n / dt_written, "unit": "rays/s", "seconds": dt_written,
                             "note": f"the same {n} rays in chunks of {REF_CHUNK}, the voxel grid rebuilt for every chunk "
@@ -144,6 +150,8 @@ def main():
     ap.add_argument("--points", type=int, default=None, help="override the number of points")
     ap.add_argument("--cpu-rays-side", type=int, default=64, help="side of the CPU-baseline window (0 = skip)")
     ap.add_argument("--cpu-passes", type=int, default=5, help="timed passes of the CPU baseline (median is reported)")
+    ap.add_argument("--cpu-budget-s", type=float, default=270.0, help="wall-clock budget of the CPU-baseline leg: no "
+                    "further pass is started once one more would exceed it")
     ap.add_argument("--sigma-scale", type=float, default=300.0)
     ap.add_argument("--no-other-mode", action="store_true", help="skip the side legs (other arithmetic mode, early "
                     "termination, training step)")
@@ -451,7 +459,8 @@ def main():
         if train is not None:
             result["training_step"] = train
         if world == 1 and not emulate and args.cpu_rays_side > 0:
-            cb, ref, dirs, campos, camrot = cpu_baseline(points, weights, cfgd, args.cpu_rays_side, azimuths[0], args.cpu_passes)
+            cb, ref, dirs, campos, camrot = cpu_baseline(points, weights, cfgd, args.cpu_rays_side, azimuths[0], args.cpu_passes,
+                                                         args.cpu_budget_s)
             # parity on the very same rays: HIP render vs the oracle that was just timed
             out = RendererHIP(scene, wh, SR=SR, K=K, D=400, radius_limit=4 * max(VSIZE[0], VSIZE[1]),
                               vsize_z=VSIZE[2], precision=args.precision).render(dirs.to(dev), campos, camrot, 2.0, 6.0)

@@ -17,12 +17,13 @@ import glob
 import os
 from dataclasses import dataclass
 from pathlib import Path
-from typing import Any, Dict, List, Optional
+from typing import Any, Dict, List, Optional, Tuple
 
 import torch
 from torch import nn
 from torch.nn import Parameter
 
+from . import metrics
 from .neural_points import NeuralPoints, PointNeRFEncoding
 from .ns_compat import (MLP, DensityFieldHead, Model, ModelConfig, MSELoss, RGBFieldHead, RGBRenderer,
                         TrainingCallback, TrainingCallbackAttributes, TrainingCallbackLocation, WHITE)
@@ -210,7 +211,7 @@ class PointNerf(Model):
         return len(todo)
 
     def populate_modules(self):
-        """studio_model.py:169-237 (metrics modules are outside the hot path and omitted)."""
+        """studio_model.py:169-237."""
         super().populate_modules()
         cfg = self.config
         self.direction_encoding = PointNeRFEncoding(in_dim=2, num_frequencies=cfg.num_viewdir_freqs, ori=True)
@@ -234,6 +235,30 @@ class PointNerf(Model):
         self.rgb_renderer = RGBRenderer(background_color=self._background_color)
         self.mask_loss = MSELoss()
         self.rgb_loss = MSELoss()
+        # metrics (studio_model.py:230-237), same attribute names; see metrics.py for what stands behind each
+        self.psnr = metrics.psnr
+        self.torchmetrics_ssim = metrics.ssim_gaussian
+        self.skimage_ssim = metrics.ssim_uniform
+        self.skimage_rmse = metrics.rmse
+        self.lpips = metrics.Lpips("alex")
+        self.lpips_vgg = metrics.Lpips("vgg")
+
+    # Just to allow for size reduction of the checkpoint (studio_model.py:240-255): the LPIPS networks are never
+    # saved, and a checkpoint without them loads under strict=True
+    def load_state_dict(self, state_dict, strict: bool = True):
+        state_dict = dict(state_dict)
+        for name in ("lpips", "lpips_vgg"):
+            if hasattr(self, name):
+                for k, v in getattr(self, name).state_dict().items():
+                    state_dict[f"{name}.{k}"] = v
+        return super().load_state_dict(state_dict, strict)
+
+    def state_dict(self, *args, prefix="", **kwargs):
+        state_dict = super().state_dict(*args, prefix=prefix, **kwargs)
+        for k in list(state_dict.keys()):
+            if k.startswith(f"{prefix}lpips.") or k.startswith(f"{prefix}lpips_vgg."):
+                state_dict.pop(k)
+        return state_dict
 
     # ---- fused HIP path ---------------------------------------------------------------------------------
     def _fusable(self) -> bool:
@@ -463,6 +488,28 @@ class PointNerf(Model):
                 torch.mean(torch.log(val) + torch.log(1 - val)) * self.config.zero_one_loss_weights
         coeff = getattr(self.config, "loss_coefficients", None) or {}
         return {k: v * coeff.get(k, 1.0) for k, v in loss_dict.items()}
+
+    def get_image_metrics_and_images(self, outputs: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor]
+                                     ) -> Tuple[Dict[str, float], Dict[str, torch.Tensor]]:
+        """studio_model.py:433-464, same metric and image keys.  The reference reshapes to a hard-coded 800 x 800
+        (:437); here the extent comes from the batch image, so other resolutions work."""
+        image = batch["image"].to(outputs["coarse_raycolor"].device)
+        H, W = image.shape[0], image.shape[1]
+        outputs["ray_masked_coarse_raycolor"] = outputs["coarse_raycolor"].reshape(H, W, 3)
+        rgb = outputs["ray_masked_coarse_raycolor"]
+        combined_rgb = torch.cat([image, rgb], dim=1)
+        # [H, W, C] -> [1, C, H, W] for the metrics
+        image = torch.moveaxis(image, -1, 0)[None, ...]
+        rgb = torch.moveaxis(rgb, -1, 0)[None, ...]
+        metrics_dict = {
+            "psnr": float(self.psnr(image, rgb)),
+            "skimage_ssim": float(self.skimage_ssim(image, rgb)),
+            "torchmetrics_ssim": float(self.torchmetrics_ssim(image, rgb)),
+            "lpips": float(self.lpips(image, rgb)),
+            "lpips_vgg": float(self.lpips_vgg(image, rgb)),
+            "rmse": float(self.skimage_rmse(image, rgb)),
+        }
+        return metrics_dict, {"img": combined_rgb}
 
     def linear(self, dists, pnt_mask, axis_weight=None):
         """studio_model.py:467-475."""

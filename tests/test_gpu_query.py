@@ -94,3 +94,45 @@ def test_scene_build_is_deterministic(oracle, gpu_device):
         outs.append((pidx.cpu(), mask.cpu()))
     for o in outs[1:]:
         assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
+
+
+def _hip_query(args, device):
+    """The HIP op on the argument tuple of oracle.query: (raypos, xyz, ks, qs, SR, K, vdim, max_o, P, radius, ranges,
+    vsize, compat)."""
+    from pointnerf2studio_amd.renderer import SceneHIP
+    raypos, xyz, ks, qs, SR, K, vdim, max_o, P, radius, ranges, vsize, compat = args
+    scene = SceneHIP()
+    info = scene.build(xyz.reshape(-1, 3).to(device), np.asarray(ranges, dtype=np.float32), vsize, vdim, ks, qs, P,
+                       max_o, compat)
+    pidx, loc, mask, cnt = query_raypos(scene, raypos.to(device), SR, K, float(radius))
+    return pidx.cpu(), loc.cpu(), mask.cpu(), cnt, info
+
+
+def test_query_matches_stored_fixtures(oracle, gpu_device):
+    """pnr_query_raypos against the int32 lists frozen in tests/golden/query_stage.npz (SR in {8, 80}, K in {8, 12},
+    compat on / off): the HIP kernels, the C oracle and the Python statement are all held to the same stored lists
+    (the CPU half is tests/test_query_fixtures.py)."""
+    from query_cases import stored_case_args, stored_cases
+    g, names = stored_cases()
+    for name in names:
+        args, want, stats = stored_case_args(oracle, g, name)
+        pidx, loc, mask, cnt, info = _hip_query(args, gpu_device)
+        assert torch.equal(mask, want[2]), name
+        assert torch.equal(pidx, want[0]), f"{name}: neighbour lists differ from the stored fixture"
+        assert torch.equal(loc, want[1]), name
+        assert [info["occupied_voxels"], cnt["rays_hit"], cnt["rays_kept"]] == stats[:3].tolist()
+        assert cnt["samples_selected"] == stats[5]
+
+
+@pytest.mark.parametrize("compat", [True, False])
+def test_query_hand_derived_case(gpu_device, compat):
+    """Expected lists derived by hand from query_worldcoords.cu (tests/query_cases.py): more than P points in a voxel,
+    a replace-the-farthest step with a tie, the voxel-0 drop, a hit ray without neighbours, a partial list."""
+    from query_cases import hand_case
+    args, want, stats = hand_case(compat)
+    pidx, loc, mask, cnt, info = _hip_query(args, gpu_device)
+    assert torch.equal(mask, want[2])
+    assert torch.equal(pidx, want[0]), pidx
+    assert torch.equal(loc, want[1])
+    assert cnt["rays_hit"] == stats["rays_hit"] and cnt["rays_kept"] == stats["rays_kept"]
+    assert info["occupied_voxels"] == stats["occupied_voxels"]

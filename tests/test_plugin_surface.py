@@ -204,3 +204,34 @@ def test_optional_aggregator_warm_start(tmp_path, monkeypatch):
     with pytest.raises(RuntimeError, match="shape"):
         plain.load_aggregator_weights(bad)
     assert all(torch.equal(v, plain.state_dict()[k]) for k, v in before.items())
+
+
+def test_aggregator_map_against_the_shipped_checkpoints():
+    """tests/golden/shipped_checkpoint_keys.json lists key -> shape of the reference's own
+    mvsnet_checkpoints/init/*/best_net_ray_marching.pth (generated in the build container by
+    oracle/gen_checkpoint_listing.py).  The warm-start name map must name tensors that exist there with the plugin's
+    shapes for the 32-feature `agg2_32_dirclr20` variant (the one the reference's scripts train from); the other
+    shipped variant (501-input first layer: 63-dim positional features) must be refused by shape."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "shipped_checkpoint_keys.json")) as f:
+        listing = json.load(f)["checkpoints"]
+    good = listing["dtu_dgt_d012_img0123_conf_agg2_32_dirclr20"]
+    by_dst = dict(zip(MLP_TENSOR_ORDER, MLP_SHAPES))
+    for src, dst in PointNerf.AGGREGATOR_MAP.items():
+        assert good[src + ".weight"]["shape"] == list(by_dst[dst]), (src, dst)
+        assert good[src + ".bias"]["shape"] == [by_dst[dst][0]]
+        assert good[src + ".weight"]["dtype"] == "float32"
+    assert set(PointNerf.AGGREGATOR_MAP.values()) == set(MLP_TENSOR_ORDER)
+    assert {k.rsplit(".", 1)[0] for k in good if k.startswith("aggregator.")} == set(PointNerf.AGGREGATOR_MAP)
+    # the shipped initialisation checkpoints carry no point cloud (it comes from the per-scene training checkpoint)
+    assert not [k for k in good if k.startswith("neural_points.")]
+    other = listing["dtu_dgt_d012_img0123_conf_color_dir_agg2"]
+    assert other["aggregator.block1.0.weight"]["shape"] == [256, 501]
+    m = _cpu_model()
+    sd = {k: torch.zeros(v["shape"]) for k, v in other.items()}
+    with pytest.raises(RuntimeError, match="shape"):
+        m.load_aggregator_weights(sd)
+    # ... while the listed good variant is accepted tensor for tensor
+    assert m.load_aggregator_weights({k: torch.full(v["shape"], 0.5) for k, v in good.items()}) == 18
+    assert float(m.mlp_head.layers[0].weight.detach().mean()) == 0.5
