@@ -55,7 +55,6 @@ FLOPS_PER_SAMPLE = 137_984     # 2 * (280*128 + 2*128*128 + 128*3)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X dense bf16 matrix peak (no 2:1 sparsity)
 
-VSIZE = [0.004, 0.004, 0.004]
 VSCALE = [2, 2, 2]
 KSIZE = [3, 3, 3]
 
@@ -75,16 +74,18 @@ def cpu_baseline(points, weights, cfgd, n_side, view, passes=5, budget_s=270.0):
     cfg = O.OracleConfig()
     cfg.SR, cfg.K, cfg.P, cfg.max_o = cfgd["SR"], cfgd["K"], cfgd["P"], cfgd["max_o"]
     cfg.ranges = list(cfgd["ranges"])
+    cfg.vsize = [cfgd["vsize"]] * 3
     H, W = cfgd["H"], cfgd["W"]
-    campos, camrot = synthetic.make_camera(view)
+    near, far = cfgd["near"], cfgd["far"]
+    campos, camrot = synthetic.make_scene_camera(cfgd, view)
     y0, x0 = (H - n_side) // 2, (W - n_side) // 2
-    dirs = synthetic.make_rays(H, W, campos, camrot, y0=y0, y1=y0 + n_side, x0=x0, x1=x0 + n_side)
+    dirs = synthetic.make_rays(H, W, campos, camrot, cfgd["angle_x"], y0=y0, y1=y0 + n_side, x0=x0, x1=x0 + n_side)
     n = dirs.shape[0]
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
 
     def one(d):
-        return O.render(points, weights, cfg, campos[None].expand(d.shape[0], 3), d, 2.0, 6.0, camrot)
+        return O.render(points, weights, cfg, campos[None].expand(d.shape[0], 3), d, near, far, camrot)
     one(dirs[:64].contiguous())    # warm-up on a sliver (thread pools, oneDNN primitives)
     t_leg = time.time()
     times, ref, dt_written = [], None, None
@@ -109,7 +110,7 @@ def cpu_baseline(points, weights, cfgd, n_side, view, passes=5, budget_s=270.0):
     except OSError:
         pass
     return dict(value=n / dt, unit="rays/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{n_side}x{n_side} centre window of view az={view:g} ({n} rays) against the full "
+                sample=f"{n_side}x{n_side} centre window of view {view} ({n} rays) against the full "
                        f"{points['xyz'].shape[0]}-point cloud, jitter 0, voxel grid built once for the sample; median of "
                        f"{len(times)} passes after a warm-up ({', '.join(f'{t:.1f}' for t in times)} s)",
                 seconds=dt, passes=times, cpu_model=cpu_model,
@@ -196,7 +197,9 @@ def main():
     H, W, SR, K = cfgd["H"], cfgd["W"], cfgd["SR"], cfgd["K"]
 
     # ---- scene resident in HBM (replicated on every rank) ----------------------------------------------
-    points = synthetic.make_points(cfgd["N"], seed=1234, ranges=cfgd["ranges"])
+    VSIZE = [cfgd["vsize"]] * 3
+    near, far = cfgd["near"], cfgd["far"]
+    points = synthetic.make_scene_points(cfgd, seed=1234)
     weights = synthetic.make_weights(0, sigma_scale=args.sigma_scale, bias_scale=0.1)
     xyz = points["xyz"].to(dev)
     hyp = grid_hyperparameters(xyz, VSIZE, VSCALE, KSIZE, cfgd["ranges"])
@@ -215,12 +218,12 @@ def main():
                     f"world={world}")
 
     # ---- rays: `world` views per step, this rank's tiles of each ----------------------------------------
-    azimuths = [45.0 * i + 20.0 for i in range(8)]
+    azimuths = list(range(8))   # the eight views of the configuration
     shard = make_shard(H, W, world, rank).to(dev)
     view_dirs, cams = [], []
     for az in azimuths:
-        campos, camrot = synthetic.make_camera(az)
-        d = synthetic.make_rays(H, W, campos, camrot).to(dev)
+        campos, camrot = synthetic.make_scene_camera(cfgd, az)
+        d = synthetic.make_rays(H, W, campos, camrot, cfgd["angle_x"]).to(dev)
         view_dirs.append(d.index_select(0, shard.pixels).contiguous())
         cams.append((campos, camrot))
     n_local = shard.n_pad * world          # this rank's rays of one step: its tiles of `world` views
@@ -230,7 +233,7 @@ def main():
         vs = tuple((s0 * world + i) % len(azimuths) for i in range(world))
         if vs not in step_sets:
             step_sets[vs] = (torch.cat([view_dirs[v] for v in vs]).contiguous(),
-                             [(cams[v][0], cams[v][1], 2.0, 6.0) for v in vs])
+                             [(cams[v][0], cams[v][1], near, far) for v in vs])
     outs = {
         "rgb": torch.empty((n_local, 3), dtype=torch.float32, device=dev),
         "depth": torch.empty((n_local,), dtype=torch.float32, device=dev),
@@ -392,7 +395,7 @@ def main():
     train = None
     if world == 1 and not emulate and not args.no_other_mode:
         train = []
-        full = synthetic.make_rays(H, W, cams[0][0], cams[0][1]).to(dev)
+        full = synthetic.make_rays(H, W, cams[0][0], cams[0][1], cfgd["angle_x"]).to(dev)
         w_dev = {k: v.to(dev) for k, v in weights.items()}   # the trainer's parameters live on the GPU
         gen = torch.Generator().manual_seed(11)
         for n_rays in (4096, 65536):
@@ -405,7 +408,7 @@ def main():
             for it in range(5):
                 ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
                 ev[0].record()
-                o = rnd_t.render(dirs_t, cams[0][0], cams[0][1], 2.0, 6.0)
+                o = rnd_t.render(dirs_t, cams[0][0], cams[0][1], near, far)
                 ev[1].record()
                 rnd_t.backward(g_rgb, w_dev, cfgd["N"])
                 ev[2].record()
@@ -436,7 +439,7 @@ def main():
             "dtype": "bf16x3 products, f32 accumulate" if args.precision == "bf16x3" else "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.config}: chair-bbox synthetic cloud N={cfgd['N']}, {H}x{W} image, D=400, "
+                "workload": f"{args.config}: synthetic {cfgd['points']} cloud N={cfgd['N']}, {H}x{W} (HxW) image, D=400, "
                             f"SR={SR}, K={K}, P={cfgd['P']}, jitter={args.jitter:g} (seed {args.jitter_seed}), {world} "
                             f"view(s)/step",
                 "workload_key": workload_key,
@@ -463,7 +466,7 @@ def main():
                                                          args.cpu_budget_s)
             # parity on the very same rays: HIP render vs the oracle that was just timed
             out = RendererHIP(scene, wh, SR=SR, K=K, D=400, radius_limit=4 * max(VSIZE[0], VSIZE[1]),
-                              vsize_z=VSIZE[2], precision=args.precision).render(dirs.to(dev), campos, camrot, 2.0, 6.0)
+                              vsize_z=VSIZE[2], precision=args.precision).render(dirs.to(dev), campos, camrot, near, far)
             # (jitter 0 on both sides: the oracle pass that was timed and this render see the same sample positions)
             err = (out["rgb"].cpu() - ref["coarse_raycolor"]).abs().max().item()
             result["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "seconds",

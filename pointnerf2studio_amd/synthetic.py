@@ -161,9 +161,48 @@ def make_rays(H: int, W: int, campos: torch.Tensor, camrot: torch.Tensor, camera
     return torch.nn.functional.normalize(d_world, dim=-1).contiguous()
 
 
+# The configurations BASELINE.json names, as seeded synthetic stand-ins (datasets are not reachable).  `points`
+# names the cloud generator, `camera` the camera family (orbit: nerf-synthetic sphere of radius 4; inside: a camera
+# inside the cloud), `angle_x` the horizontal field of view (focal = 0.5 W / tan(0.5 angle_x)), `vsize` the voxel
+# edge (the grid uses vsize * vscale, vscale = 2), near / far the clip planes of the datamanager.
 SCENE_CONFIGS = {
-    # BASELINE.json configs[0]: 50k points, 64x64 image, 32 samples/ray, K = 8
-    "cfg0_chair_50k": dict(N=50_000, H=64, W=64, SR=32, K=8, ranges=CHAIR_RANGES, max_o=410000, P=12),
-    # BASELINE.json configs[1]: ~6M points, 800x800, 80 samples/ray, K = 8 (the metric's configuration)
-    "cfg1_chair_6m": dict(N=6_000_000, H=800, W=800, SR=80, K=8, ranges=CHAIR_RANGES, max_o=410000, P=12),
+    # configs[0]: 50k points, 64x64 image, 32 samples/ray, K = 8 (the reference's CPU-runnable case)
+    "cfg0_chair_50k": dict(N=50_000, H=64, W=64, SR=32, K=8, ranges=CHAIR_RANGES, max_o=410000, P=12, vsize=0.004,
+                           near=2.0, far=6.0, points="chair", camera="orbit", angle_x=0.6911112070083618),
+    # configs[1]: ~6M points, 800x800, 80 samples/ray, K = 8 (the metric's configuration)
+    "cfg1_chair_6m": dict(N=6_000_000, H=800, W=800, SR=80, K=8, ranges=CHAIR_RANGES, max_o=410000, P=12, vsize=0.004,
+                          near=2.0, far=6.0, points="chair", camera="orbit", angle_x=0.6911112070083618),
+    # configs[2]: lego-like, ~6M points, 800x800, K = 8 (lego bbox and P = 9 of dev_scripts/w_n360/lego_points.sh:59)
+    "cfg2_lego_6m": dict(N=6_000_000, H=800, W=800, SR=80, K=8, ranges=LEGO_RANGES, max_o=410000, P=9, vsize=0.004,
+                         near=2.0, far=6.0, points="lego", camera="orbit", angle_x=0.6911112070083618),
+    # configs[3]: DTU-like dense MVSNet cloud, ~10M points, 1600x1200 (W x H: a 4:3 frame), K = 8
+    "cfg3_dtu_10m": dict(N=10_000_000, H=1200, W=1600, SR=80, K=8, ranges=CHAIR_RANGES, max_o=410000, P=12, vsize=0.004,
+                         near=2.0, far=6.0, points="chair", camera="orbit", angle_x=0.9),
+    # configs[4]: ScanNet-like indoor scene, ~20M points, 1296x968, K = 12, SR = 24, P = 26, vsize 0.008, the camera
+    # inside the cloud (dev_scripts/w_scannet_etf/scene241_points.sh:53-60,91-92): the HBM-bound neighbour-gather stress
+    "cfg4_scannet_20m": dict(N=20_000_000, H=968, W=1296, SR=24, K=12, ranges=[-0.5, -0.5, -0.5, 8.5, 6.5, 3.5],
+                             max_o=1000000, P=26, vsize=0.008, near=0.1, far=8.0, points="room", camera="inside",
+                             angle_x=1.0),
 }
+
+
+def make_scene_points(cfgd: dict, N: int = None, seed: int = 1234) -> Dict[str, torch.Tensor]:
+    """The cloud of a SCENE_CONFIGS entry (optionally at a reduced point count)."""
+    n = int(N or cfgd["N"])
+    if cfgd["points"] == "room":
+        return make_room_points(n, seed=seed)
+    if cfgd["points"] == "lego":
+        # the chair-shaped surfaces squeezed into the lego box (flatter in x, longer in y)
+        pts = make_points(n, seed=seed, ranges=CHAIR_RANGES)
+        lo_c, hi_c = torch.tensor(CHAIR_RANGES[:3]), torch.tensor(CHAIR_RANGES[3:])
+        lo_l, hi_l = torch.tensor(LEGO_RANGES[:3]), torch.tensor(LEGO_RANGES[3:])
+        pts["xyz"] = ((pts["xyz"] - lo_c) / (hi_c - lo_c) * (hi_l - lo_l - 0.04) + lo_l + 0.02).float().contiguous()
+        return pts
+    return make_points(n, seed=seed, ranges=cfgd["ranges"])
+
+
+def make_scene_camera(cfgd: dict, view: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Camera `view` (0..7) of a SCENE_CONFIGS entry: (campos [3], camrotc2w [3,3])."""
+    if cfgd["camera"] == "inside":
+        return make_inside_camera([4.0, 3.0, 1.5], yaw_deg=35.0 + 45.0 * view, pitch_deg=-10.0)
+    return make_camera(45.0 * view + 20.0)

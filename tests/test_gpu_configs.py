@@ -1,0 +1,165 @@
+"""Every configuration BASELINE.json names, on the GPU, in pytest (synthetic stand-ins: pointnerf2studio_amd/synthetic.py
+SCENE_CONFIGS; datasets are not reachable):
+
+  * at REDUCED point counts against the CPU oracle, both arithmetic modes: cfg[2] lego-like (lego box, P = 9),
+    cfg[3] DTU-like (1600 x 1200 frame: W != H, off-centre windows), cfg[4] ScanNet-like (room shell, camera inside the
+    cloud, K = 12, SR = 24, P = 26, vsize 0.008, near 0.1 / far 8);
+  * at FULL size (cfg[1] 6 M / 800 x 800, cfg[3] 10 M / 1600 x 1200, cfg[4] 20 M / 1296 x 968) through size-independent
+    properties: bitwise-equal re-render, tiling invariance (the frame rendered in two halves), background rays exactly
+    the background colour, accumulated opacity in [0, 1], counter consistency, no capacity overflow, the opt-in bf16x3
+    mode within 1e-4 of the default fp32 mode -- and, for cfg[1] and cfg[3], a window of the full-size frame against the
+    CPU oracle run on the full-size cloud.
+cfg[0] (50 k points, 64 x 64, SR 32) is in test_gpu_render.py; the 8-GPU form of cfg[2]-[4] is the same per-rank code on
+a tile shard (tests/test_distributed_gloo.py)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import NORTH_STAR, OPT_IN_BF16X3, build_hip
+from pointnerf2studio_amd import synthetic
+from pointnerf2studio_amd.renderer import RendererHIP
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_cfg(oracle, c):
+    cfg = oracle.OracleConfig()
+    cfg.SR, cfg.K, cfg.P, cfg.max_o = c["SR"], c["K"], c["P"], c["max_o"]
+    cfg.ranges = list(c["ranges"])
+    cfg.vsize = [c["vsize"]] * 3
+    return cfg
+
+
+def _renderer(scene, wh, c, oracle_mod, cfg, precision):
+    return RendererHIP(scene, wh, SR=c["SR"], K=c["K"], D=cfg.z_depth_dim, radius_limit=float(oracle_mod.radius_limit(cfg)),
+                       vsize_z=cfg.vsize[2], precision=precision)
+
+
+def _window_rays(c, view, window):
+    campos, camrot = synthetic.make_scene_camera(c, view)
+    y0, y1, x0, x1 = window
+    dirs = synthetic.make_rays(c["H"], c["W"], campos, camrot, c["angle_x"], y0=y0, y1=y1, x0=x0, x1=x1)
+    return campos, camrot, dirs
+
+
+def _against_oracle(oracle, device, c, pts, scene, wh, cfg, view, window, min_kept=20):
+    campos, camrot, dirs = _window_rays(c, view, window)
+    ref = oracle.render(pts, _against_oracle.w, cfg, campos[None].expand(dirs.shape[0], 3), dirs, c["near"], c["far"],
+                        camrot)
+    assert ref["stats"]["rays_kept"] >= min_kept, ref["stats"]
+    lists = {}
+    for mode, tol in (("fp32", NORTH_STAR), ("bf16x3", OPT_IN_BF16X3)):
+        rnd = _renderer(scene, wh, c, oracle, cfg, mode)
+        out = rnd.render(dirs.to(device), campos, camrot, c["near"], c["far"])
+        assert out["counters"]["overflow"] == 0
+        assert out["counters"]["rays_hit"] == ref["stats"]["rays_hit"]
+        assert out["counters"]["rays_kept"] == ref["stats"]["rays_kept"]
+        assert torch.equal(out["ray_mask"].cpu(), ref["ray_mask"]), mode
+        for key, name in (("rgb", "coarse_raycolor"), ("depth", "depth"), ("acc", "acc")):
+            err = (out[key].cpu() - ref[name]).abs().max().item()
+            assert err <= tol[key], f"{mode}: max abs {key} error {err:.3e} (window {window}, view {view})"
+        S = int(out["counters"]["samples_selected"])
+        lists[mode] = rnd.taps(dirs.shape[0])["smp_pidx"][:S].clone()
+    assert torch.equal(lists["fp32"], lists["bf16x3"])
+    return ref
+
+
+_against_oracle.w = synthetic.make_weights(0, sigma_scale=300.0, bias_scale=0.1)
+
+
+@pytest.mark.parametrize("name,N,windows", [
+    # DTU-like 4:3 frame: a centre window, one across the upper silhouette (hit and missed rays mixed, hit rays that
+    # find no neighbour), one in the lower right (principal point
+    # off the window's centre, different horizontal and vertical extents)
+    ("cfg3_dtu_10m", 250_000, [(0, (584, 616, 776, 824)), (2, (330, 370, 700, 748)), (5, (700, 732, 900, 980))]),
+    ("cfg2_lego_6m", 200_000, [(0, (380, 420, 380, 420)), (3, (300, 332, 420, 468))]),
+    ("cfg4_scannet_20m", 400_000, [(0, (460, 492, 620, 668)), (4, (200, 232, 300, 348))]),
+])
+def test_reduced_config_matches_oracle(oracle, gpu_device, name, N, windows):
+    c = dict(synthetic.SCENE_CONFIGS[name])
+    pts = synthetic.make_scene_points(c, N=N)
+    cfg = _oracle_cfg(oracle, c)
+    scene, wh, hyp, info = build_hip(pts, cfg, gpu_device, weights=_against_oracle.w)
+    assert info["max_o_overflow"] == 0
+    kept = 0
+    for view, window in windows:
+        ref = _against_oracle(oracle, gpu_device, c, pts, scene, wh, cfg, view, window)
+        kept += ref["stats"]["rays_kept"]
+        assert ref["acc"].max().item() > 0.3          # not a trivially transparent image
+    assert kept > 200
+
+
+# ---- full size ------------------------------------------------------------------------------------------------------
+def _properties(device, c, scene, wh, cfg, oracle_mod, view=0):
+    campos, camrot = synthetic.make_scene_camera(c, view)
+    d = synthetic.make_rays(c["H"], c["W"], campos, camrot, c["angle_x"]).to(device)
+    R = d.shape[0]
+    res = {}
+    for mode in ("fp32", "bf16x3"):
+        rnd = _renderer(scene, wh, c, oracle_mod, cfg, mode)
+        a = rnd.render(d, campos, camrot, c["near"], c["far"])
+        rgb, depth, mask, acc = a["rgb"].clone(), a["depth"].clone(), a["ray_mask"].clone(), a["acc"].clone()
+        cnt = a["counters"]
+        assert cnt["overflow"] == 0
+        # counters: R >= hit >= kept; selected <= R * SR; valid <= selected; valid <= pairs <= valid * K; U <= pairs
+        assert R >= cnt["rays_hit"] >= cnt["rays_kept"] > 1000
+        assert cnt["rays_kept"] == int(mask.sum().item())
+        assert cnt["samples_valid"] <= cnt["samples_selected"] <= R * c["SR"]
+        assert cnt["samples_valid"] <= cnt["pairs_valid"] <= cnt["samples_valid"] * c["K"]
+        assert 0 < cnt["points_unique"] <= min(cnt["pairs_valid"], c["N"])
+        b = rnd.render(d, campos, camrot, c["near"], c["far"])                       # determinism
+        assert torch.equal(b["rgb"], rgb) and torch.equal(b["depth"], depth) and torch.equal(b["ray_mask"], mask)
+        if mode == "fp32":                                                           # tiling invariance
+            half = (R // 2 // 64) * 64 + 17                                          # a cut that is not tile aligned
+            top = rnd.render(d[:half].contiguous(), campos, camrot, c["near"], c["far"])
+            top_rgb, top_mask = top["rgb"].clone(), top["ray_mask"].clone()
+            bot = rnd.render(d[half:].contiguous(), campos, camrot, c["near"], c["far"])
+            assert torch.equal(torch.cat([top_rgb, bot["rgb"]]), rgb)
+            assert torch.equal(torch.cat([top_mask, bot["ray_mask"]]), mask)
+        assert torch.all(rgb[mask == 0] == 1.0)                                      # white background, exactly
+        assert float(acc.min()) >= 0.0 and float(acc.max()) <= 1.0 + 1e-5
+        assert torch.all(acc[mask == 0] == 0) and torch.all(depth[mask == 0] == 0)
+        assert float(rgb.min()) >= 0.0 and float(rgb.max()) <= 1.0 and bool(torch.isfinite(depth).all())
+        assert float(depth[mask > 0].min()) >= 0.0 and float(depth.max()) <= c["far"] * (1 + 1e-5)
+        assert float(acc.max()) > 0.5                                                # some rays are opaque
+        res[mode] = (rgb, depth, cnt)
+    assert res["fp32"][2] == res["bf16x3"][2]                                        # counters do not depend on the mode
+    assert (res["fp32"][0] - res["bf16x3"][0]).abs().max().item() <= OPT_IN_BF16X3["rgb"]
+    return res["fp32"][2]
+
+
+def _full_scene(oracle, device, name):
+    c = dict(synthetic.SCENE_CONFIGS[name])
+    pts = synthetic.make_scene_points(c)
+    cfg = _oracle_cfg(oracle, c)
+    scene, wh, hyp, info = build_hip(pts, cfg, device, weights=_against_oracle.w)
+    return c, pts, cfg, scene, wh, info
+
+
+def test_cfg1_full_size(oracle, gpu_device):
+    """BASELINE cfg[1]: 6 M points, 800 x 800, SR 80, K 8 -- the metric's configuration, at full size."""
+    c, pts, cfg, scene, wh, info = _full_scene(oracle, gpu_device, "cfg1_chair_6m")
+    assert info["N"] == 6_000_000 and info["max_o_overflow"] == 0
+    cnt = _properties(gpu_device, c, scene, wh, cfg, oracle)
+    assert cnt["pairs_valid"] > 5_000_000
+    # a 16 x 16 window of the frame against the oracle run on the full 6 M-point cloud
+    _against_oracle(oracle, gpu_device, c, pts, scene, wh, cfg, 0, (392, 408, 392, 408), min_kept=100)
+
+
+def test_cfg3_dtu_full_size(oracle, gpu_device):
+    """BASELINE cfg[3]: DTU-like, 10 M points, 1600 x 1200, K 8 (one GPU's view of the 8-GPU configuration)."""
+    c, pts, cfg, scene, wh, info = _full_scene(oracle, gpu_device, "cfg3_dtu_10m")
+    assert info["N"] == 10_000_000
+    cnt = _properties(gpu_device, c, scene, wh, cfg, oracle)
+    assert cnt["pairs_valid"] > 5_000_000
+    _against_oracle(oracle, gpu_device, c, pts, scene, wh, cfg, 0, (592, 608, 792, 808), min_kept=100)
+
+
+def test_cfg4_scannet_full_size(oracle, gpu_device):
+    """BASELINE cfg[4]: ScanNet-like, 20 M points, 1296 x 968, K 12, SR 24, P 26, camera inside the cloud: every ray
+    hits, the neighbour gather is the stress (properties only: the oracle does not finish in seconds at 20 M)."""
+    c, pts, cfg, scene, wh, info = _full_scene(oracle, gpu_device, "cfg4_scannet_20m")
+    assert info["N"] == 20_000_000
+    del pts
+    cnt = _properties(gpu_device, c, scene, wh, cfg, oracle)
+    assert cnt["rays_kept"] > 0.9 * c["H"] * c["W"] and cnt["pairs_valid"] > 50_000_000
