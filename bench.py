@@ -43,7 +43,7 @@ sys.path.insert(0, ROOT)
 
 from pointnerf2studio_amd import _lib, synthetic  # noqa: E402
 from pointnerf2studio_amd.distributed import ViewGatherPipe, make_shard  # noqa: E402
-from pointnerf2studio_amd.renderer import (RendererHIP, SceneHIP, WeightsHIP, grid_hyperparameters)  # noqa: E402
+from pointnerf2studio_amd.renderer import (RendererHIP, SceneHIP, View, WeightsHIP, grid_hyperparameters)  # noqa: E402
 
 FLOPS_PER_PAIR = 542_720       # 2 * (284*256 + 256*256 + 263*256 + 256*256 + 256)   SURVEY.md section 8d
 # mlp_base layer 0 is factorised (both modes): the pair kernels multiply the 60 pair inputs only, the 224
@@ -159,6 +159,8 @@ def main():
     ap.add_argument("--jitter", type=float, default=0.3, help="coarse-sample jitter of the timed legs (the reference "
                     "renders with 0.3, studio_utils.py:166); the parity leg always runs at 0")
     ap.add_argument("--jitter-seed", type=int, default=7)
+    ap.add_argument("--rays-from-tensor", action="store_true", help="render from a resident [R,3] direction tensor "
+                    "(pnr_render_views) instead of generating the rays in the kernels (pnr_render_camera)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="diagnostic, single process: shard as rank --emulate-rank of this many ranks, no collectives")
     ap.add_argument("--emulate-rank", type=int, default=0)
@@ -220,20 +222,33 @@ def main():
     # ---- rays: `world` views per step, this rank's tiles of each ----------------------------------------
     azimuths = list(range(8))   # the eight views of the configuration
     shard = make_shard(H, W, world, rank).to(dev)
-    view_dirs, cams = [], []
+    # A view is pose + intrinsics; its rays are generated inside the kernels from the pixel ids this rank owns
+    # (pnr_render_camera): no direction tensor exists.  --rays-from-tensor renders from a resident [R,3] tensor instead
+    # (pnr_render_views, the plugin's ray-bundle contract).
+    shard_px = shard.pixels.to(torch.int32).contiguous()
+    view_dirs, cams, views = [], [], []
     for az in azimuths:
         campos, camrot = synthetic.make_scene_camera(cfgd, az)
-        d = synthetic.make_rays(H, W, campos, camrot, cfgd["angle_x"]).to(dev)
-        view_dirs.append(d.index_select(0, shard.pixels).contiguous())
         cams.append((campos, camrot))
+        views.append(View.from_angle(campos, camrot, H, W, cfgd["angle_x"], near, far))
+        if args.rays_from_tensor:
+            d = synthetic.make_rays(H, W, campos, camrot, cfgd["angle_x"]).to(dev)
+            view_dirs.append(d.index_select(0, shard.pixels).contiguous())
     n_local = shard.n_pad * world          # this rank's rays of one step: its tiles of `world` views
     # the view sets a step can consist of: views (s*world + i) % 8, i < world -- concatenated once, resident in HBM
     step_sets = {}
     for s0 in range(len(azimuths)):
         vs = tuple((s0 * world + i) % len(azimuths) for i in range(world))
         if vs not in step_sets:
-            step_sets[vs] = (torch.cat([view_dirs[v] for v in vs]).contiguous(),
-                             [(cams[v][0], cams[v][1], near, far) for v in vs])
+            step_sets[vs] = (torch.cat([view_dirs[v] for v in vs]).contiguous() if args.rays_from_tensor else None,
+                             [(cams[v][0], cams[v][1], near, far) for v in vs], [views[v] for v in vs])
+
+    def render_step(renderer, vs, **kw):
+        dirs_s, cams_s, views_s = step_sets[vs]
+        if args.rays_from_tensor:
+            return renderer.render_views(dirs_s, cams_s, shard.n_pad, **kw)
+        return renderer.render_camera(views_s, H, W, pixels=shard_px, **kw)
+
     outs = {
         "rgb": torch.empty((n_local, 3), dtype=torch.float32, device=dev),
         "depth": torch.empty((n_local,), dtype=torch.float32, device=dev),
@@ -247,12 +262,11 @@ def main():
 
     # capacity: size the workspace once from the heaviest step (untimed)
     cap = 0
-    for dirs_s, cams_s in step_sets.values():
-        o = rnd.render_views(dirs_s, cams_s, shard.n_pad, out=outs)
+    for vs in step_sets:
+        o = render_step(rnd, vs, out=outs)
         cap = max(cap, o["counters"]["samples_selected"])
     cap = int(cap * 1.05) + 4096
-    d0, c0 = next(iter(step_sets.values()))
-    rnd.render_views(d0, c0, shard.n_pad, cap_samples=cap, out=outs)
+    render_step(rnd, next(iter(step_sets)), cap_samples=cap, out=outs)
 
     lib = _lib.load()
     n_calls_max = max(args.steps, 4)  # the side legs (other mode, early termination) time up to 3 steps
@@ -264,10 +278,9 @@ def main():
         call = 0
         for s in range(first, first + count):
             vs = tuple((s * world + i) % len(azimuths) for i in range(world))
-            dirs_s, cams_s = step_sets[vs]
             if counters is not None:
                 outs["counters_dev"] = counters[call]
-            renderer.render_views(dirs_s, cams_s, shard.n_pad, cap_samples=cap, sync_counters=False, out=outs)
+            render_step(renderer, vs, cap_samples=cap, sync_counters=False, out=outs)
             local4 = pipe.stage()
             local4[:, :3].copy_(outs["rgb"])
             local4[:, 3].copy_(outs["depth"])
@@ -447,6 +460,8 @@ def main():
                 "rays_per_rank_per_step": n_local,
                 "parallelism": f"ray-tile shard x{world} (16x16 tiles round-robin), one multi-camera render + one "
                                f"all_gather per step",
+                "rays": "directions resident in HBM (pnr_render_views)" if args.rays_from_tensor else
+                        "generated in the kernels from pose + intrinsics + pixel ids (pnr_render_camera)",
             },
             "roofline": roofline(args.precision, acc_ms, acc_cnt, n_launch),
             "stages_ms_per_launch": {n: acc_ms[i] / n_launch for i, n in enumerate(_lib.STAGE_NAMES)},

@@ -194,6 +194,42 @@ int pnr_render_views(const pnr_scene_t *scene, const pnr_weights_t *weights, con
                      int8_t *d_ray_mask, int64_t *d_counters, void *d_workspace, size_t workspace_bytes,
                      int64_t cap_samples, void *stream);
 
+/* ---- rays from cameras: pose + intrinsics in, no direction tensor ----------------------------------------
+ * Replaces the ray generator in front of the model (studio_datamanager.py:62-110 -> nerfstudio RayGenerator /
+ * Cameras.generate_rays, which materialises origins [R,3] + directions [R,3] in HBM for every bundle, plus the
+ * per-ray copy of the camera rotation at studio_datamanager.py:108).  A view is a pinhole camera as nerfstudio's
+ * Cameras holds it; the ray of pixel (x, y) is, in fp32 and in exactly this order (no fused multiply-add):
+ *     cxn = ((float)x + 0.5f - cx) / fx;   cyn = -(((float)y + 0.5f - cy) / fy);   czn = -1
+ *     w_i = R[i][0] * cxn + R[i][1] * cyn + R[i][2] * czn          (i = 0..2, left to right)
+ *     dir = w / sqrtf(w_0 * w_0 + w_1 * w_1 + w_2 * w_2)            (unit length, as nerfstudio's bundles)
+ * with origin campos.  pnr_pinhole_ray is the host statement of the same arithmetic (bit-identical to what the
+ * kernels compute), so a caller or a test can reproduce any ray without the device. */
+typedef struct {
+    float campos[3];      /* camera_to_worlds[:3, 3]                                             */
+    float camrotc2w[9];   /* camera_to_worlds[:3, :3], row-major (= metadata["camrotc2w"])       */
+    float near_plane, far_plane;
+    float fx, fy, cx, cy; /* intrinsics in pixels                                                */
+} pnr_view_t;
+
+void pnr_pinhole_ray(const pnr_view_t *view, int32_t x, int32_t y, float dir[3]);
+
+/* The fused render of n_views views of an H x W frame with the rays generated INSIDE the kernels: ray r of the call
+ * is pixel d_pixels[r % n_pixels] (flat row-major id y * W + x; d_pixels NULL = pixel r % n_pixels, n_pixels = H * W)
+ * of view r / n_pixels, so the call renders R = n_views * n_pixels rays and the outputs have R rows, view-major in
+ * d_pixels order.  d_pixels is what a tile shard owns (pointnerf2studio_amd.distributed.make_shard).  The sample
+ * selection probes every ray from its pixel id alone; only the rays that hit the occupancy (about one in five on the
+ * metric's configuration) get their direction written to a compact scratch row inside the workspace for the shading
+ * stage.  d_tmid holds n_views tables [2, D] as for pnr_render_views.  Everything else as pnr_render_views. */
+int pnr_render_camera(const pnr_scene_t *scene, const pnr_weights_t *weights, const pnr_view_t *views, int32_t n_views,
+                      int32_t H, int32_t W, const int32_t *d_pixels, int64_t n_pixels, const float *d_tmid,
+                      const pnr_render_opts_t *opts, float *d_rgb, float *d_depth, float *d_acc, int8_t *d_ray_mask,
+                      int64_t *d_counters, void *d_workspace, size_t workspace_bytes, int64_t cap_samples, void *stream);
+
+/* The same rays written out as a direction tensor d_dirs [n_views * n_pixels, 3] (for callers that need one: the
+ * training step's pnr_render_backward, tests). */
+int pnr_camera_rays(const pnr_view_t *views, int32_t n_views, int32_t H, int32_t W, const int32_t *d_pixels,
+                    int64_t n_pixels, float *d_dirs, void *stream);
+
 /* Debug/test taps into the last pnr_render workspace (device pointers, valid until the workspace is
  * reused): per selected sample s: loc+t float4, ray id, neighbour list [K], decoded (sigma,r,g,b). */
 typedef struct {
@@ -203,6 +239,8 @@ typedef struct {
     const float *smp_out;      /* [S_sel,4] sigma r g b (zero where no neighbour) */
     const int32_t *ray_cnt;    /* [R] selected samples per ray */
     const int32_t *ray_off;    /* [R] first sample of ray      */
+    const float *ray_dirs;     /* [R,3] after pnr_render_camera: directions of the rays with samples (other rows are
+                                  not written); what pnr_render_backward takes as d_dirs after such a render */
 } pnr_render_taps_t;
 int pnr_render_taps(void *d_workspace, size_t workspace_bytes, int64_t R, int64_t cap_samples, int32_t K,
                     pnr_render_taps_t *taps);

@@ -27,6 +27,7 @@ EXPORTED_SYMBOLS = [
     "pnr_weights_create", "pnr_weights_destroy", "pnr_weights_pack",
     "pnr_query_workspace_bytes", "pnr_query_raypos",
     "pnr_render_workspace_bytes", "pnr_render_workspace_bytes_for", "pnr_render", "pnr_render_views",
+    "pnr_render_camera", "pnr_camera_rays", "pnr_pinhole_ray",
     "pnr_render_taps",
     "pnr_backward_workspace_bytes", "pnr_render_backward",
     "pnr_profile_enable", "pnr_profile_calls", "pnr_profile_read",
@@ -46,6 +47,12 @@ class CameraC(C.Structure):
                 ("far_plane", C.c_float)]
 
 
+class ViewC(C.Structure):
+    """pnr_view_t: pose + pinhole intrinsics of one view (nerfstudio Cameras)."""
+    _fields_ = [("campos", C.c_float * 3), ("camrotc2w", C.c_float * 9), ("near_plane", C.c_float),
+                ("far_plane", C.c_float), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float)]
+
+
 class RenderOpts(C.Structure):
     _fields_ = [("SR", C.c_int32), ("K", C.c_int32), ("D", C.c_int32), ("radius_limit", C.c_float),
                 ("vsize_z", C.c_float), ("eval_clamp", C.c_int32), ("bg", C.c_float * 3), ("precision", C.c_int32), ("jitter", C.c_float), ("seed", C.c_uint32),
@@ -57,7 +64,7 @@ PRECISION = {"fp32": 0, "bf16x3": 1}
 
 class RenderTaps(C.Structure):
     _fields_ = [("smp_loc", C.c_void_p), ("smp_ray", C.c_void_p), ("smp_pidx", C.c_void_p),
-                ("smp_out", C.c_void_p), ("ray_cnt", C.c_void_p), ("ray_off", C.c_void_p)]
+                ("smp_out", C.c_void_p), ("ray_cnt", C.c_void_p), ("ray_off", C.c_void_p), ("ray_dirs", C.c_void_p)]
 
 
 class GradsC(C.Structure):
@@ -103,6 +110,11 @@ def load() -> C.CDLL:
                                vp, sz, i64, vp]
     lib.pnr_render_views.argtypes = [vp, vp, vp, i64, C.POINTER(CameraC), i32, vp, i64, vp, C.POINTER(RenderOpts), vp, vp,
                                      vp, vp, vp, vp, sz, i64, vp]
+    lib.pnr_render_camera.argtypes = [vp, vp, C.POINTER(ViewC), i32, i32, i32, vp, i64, vp, C.POINTER(RenderOpts), vp, vp, vp,
+                                      vp, vp, vp, sz, i64, vp]
+    lib.pnr_camera_rays.argtypes = [C.POINTER(ViewC), i32, i32, i32, vp, i64, vp, vp]
+    lib.pnr_pinhole_ray.restype = None
+    lib.pnr_pinhole_ray.argtypes = [C.POINTER(ViewC), i32, i32, C.POINTER(C.c_float * 3)]
     lib.pnr_render_taps.argtypes = [vp, sz, i64, i64, i32, C.POINTER(RenderTaps)]
     lib.pnr_backward_workspace_bytes.restype = sz
     lib.pnr_backward_workspace_bytes.argtypes = [i64, i32]
@@ -117,7 +129,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         if name not in ("pnr_last_error", "pnr_query_workspace_bytes", "pnr_render_workspace_bytes",
                         "pnr_render_workspace_bytes_for", "pnr_profile_calls", "pnr_jitter_uniform",
-                        "pnr_backward_workspace_bytes"):
+                        "pnr_backward_workspace_bytes", "pnr_pinhole_ray"):
             fn.restype = C.c_int
     _lib = lib
     return lib

@@ -82,6 +82,7 @@ __device__ __forceinline__ void brick_of(const GridView &g, int cx, int cy, int 
 struct Camera {
     float o[3];
     float R[9];  // camrotc2w row-major
+    float fx, fy, cx, cy;  // pinhole intrinsics (pnr_render_camera only; 0 otherwise).  64 bytes per camera
 };
 
 // The cameras of one render call live in a small device array; ray r belongs to camera ray_cam[r] or, when
@@ -97,7 +98,30 @@ struct CamRef {
     float jitter;
     unsigned seed;
     float nears[PNR_MAX_CAMS];
+    // rays from cameras (pnr_render_camera): ray r = pixel pixels[r % n_pixels] (or r % n_pixels) of view r / n_pixels
+    // of a frame W pixels wide; rays_per_cam == n_pixels then
+    int gen_rays;
+    int W;
+    const int *pixels;
+    long long n_pixels;
 };
+
+// Direction of pixel (x, y) of a pinhole view: the arithmetic include/pnr.h states for pnr_view_t, fp32, unfused (the
+// library is built with -ffp-contract=off; the host build of pnr_pinhole_ray uses the same flags, IEEE divide and sqrt
+// on both sides), so host and device agree bit for bit.
+__host__ __device__ __forceinline__ void pinhole_dir(const Camera &c, int x, int y, float &dx, float &dy, float &dz)
+{
+    const float cxn = ((float)x + 0.5f - c.cx) / c.fx;
+    const float cyn = -(((float)y + 0.5f - c.cy) / c.fy);
+    const float czn = -1.0f;
+    const float w0 = c.R[0] * cxn + c.R[1] * cyn + c.R[2] * czn;
+    const float w1 = c.R[3] * cxn + c.R[4] * cyn + c.R[5] * czn;
+    const float w2 = c.R[6] * cxn + c.R[7] * cyn + c.R[8] * czn;
+    const float n = sqrtf(w0 * w0 + w1 * w1 + w2 * w2);
+    dx = w0 / n;
+    dy = w1 / n;
+    dz = w2 / n;
+}
 
 // counter-based uniform in [0, 1) with 24 random bits: two rounds of a 32-bit mix over (seed, ray, sample);
 // exported as pnr_jitter_uniform so hosts (and the test suite) can reproduce the stream
@@ -127,7 +151,34 @@ __device__ __forceinline__ Camera load_cam(const CamRef &cr, int cid)
     for (int i = 0; i < 3; ++i) c.o[i] = p[i];
 #pragma unroll
     for (int i = 0; i < 9; ++i) c.R[i] = p[3 + i];
+    c.fx = c.fy = c.cx = c.cy = 0.f;   // the intrinsics are read by ray_dir only (load_cam_full)
     return c;
+}
+__device__ __forceinline__ Camera load_cam_full(const CamRef &cr, int cid)
+{
+    Camera c = load_cam(cr, cid);
+    const float *p = reinterpret_cast<const float *>(cr.cams + cid);
+    c.fx = p[12];
+    c.fy = p[13];
+    c.cx = p[14];
+    c.cy = p[15];
+    return c;
+}
+// direction of ray r (of camera `cam`, loaded with load_cam_full when cr.gen_rays): from the caller's tensor, or
+// generated from the pixel id
+__device__ __forceinline__ void ray_dir(const CamRef &cr, const Camera &cam, const float *__restrict__ dirs,
+                                        long long r, float &dx, float &dy, float &dz)
+{
+    if (!cr.gen_rays) {
+        dx = dirs[3 * r];
+        dy = dirs[3 * r + 1];
+        dz = dirs[3 * r + 2];
+        return;
+    }
+    const unsigned i = (unsigned)((unsigned long long)r % (unsigned long long)cr.n_pixels);
+    const unsigned p = cr.pixels ? (unsigned)cr.pixels[i] : i;
+    const unsigned y = p / (unsigned)cr.W, x = p - y * (unsigned)cr.W;
+    pinhole_dir(cam, (int)x, (int)y, dx, dy, dz);
 }
 // camera of a per-lane ray: rays are ordered by camera, so a wavefront almost always sees ONE camera and can
 // fetch it with wave-uniform (scalar) loads; only a wavefront straddling two bundles loads per lane
@@ -220,6 +271,7 @@ struct RenderWs {
     float *ray_T;      // [R] transmittance after the chunks shaded so far
     float *ray_cm;     // [R] running maximum of the camera-space depth (ray_dist state of the composite)
     int *ray_alive;    // [R]
+    float *ray_dirs;   // [R,3] pnr_render_camera: directions of the rays that have samples (written by k_expand)
     int *n_sel;        // device ints: [0]=S_sel (clamped to cap), [1]=S_valid, [2]=R, [3]=U unique neighbour points,
                        // [4],[5] = first / one-past-last position of the current shading pass in vs_all, [6] = 0
     unsigned long long *shards;  // statistics counters, SHARDS x 128-byte lines per counter (see shard_add)
@@ -255,6 +307,7 @@ __device__ __forceinline__ unsigned long long shard_sum(const unsigned long long
     return s;
 }
 
+// d_dirs: the caller's directions; with cr.gen_rays they are null and k_expand writes ws.ray_dirs instead
 int launch_select_expand(const GridView &g, const CamRef &cr, const float *d_dirs, const float *d_raypos,
                          int64_t R, int D, int SR, int64_t cap, RenderWs &ws, int64_t *d_counters,
                          hipStream_t stream);

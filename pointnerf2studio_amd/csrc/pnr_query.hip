@@ -53,6 +53,7 @@ RenderWs carve_render_ws(void *base, int64_t R, int64_t cap, int K, int64_t N, i
     ws.ray_T = (float *)take((size_t)R * sizeof(float));
     ws.ray_cm = (float *)take((size_t)R * sizeof(float));
     ws.ray_alive = (int *)take((size_t)R * sizeof(int));
+    ws.ray_dirs = (float *)take((size_t)R * 3 * sizeof(float));
     ws.total = off;
     if (N > 0) {
         ws.u_cap = std::max<int64_t>(1, std::min<int64_t>(n_list, cap * (int64_t)K));
@@ -155,11 +156,9 @@ __global__ void __launch_bounds__(TPB) k_select(GridView g, CamRef cr, const flo
         w_hi = nwords - 1;
         if (!raypos) {
             cid = cam_id(cr, rl);
-            const Camera cam = load_cam(cr, cid);
+            const Camera cam = load_cam_full(cr, cid);
             const float *tmid = cr.tmid + (size_t)cid * 2 * D;
-            dx = dirs[3 * rl];
-            dy = dirs[3 * rl + 1];
-            dz = dirs[3 * rl + 2];
+            ray_dir(cr, cam, dirs, rl, dx, dy, dz);
             // Conservative ray / grid-box clip: a coarse sample outside the voxel grid can never be occupied
             // (cu:182-187), so whole 64-sample words whose parameter range misses the box -- grown by two voxels
             // against rounding -- are skipped without probing.  Every probed sample still takes the exact test.
@@ -267,7 +266,8 @@ __global__ void __launch_bounds__(TPB) k_expand(CamRef cr, const float *__restri
                                                  int64_t R, int D, int SR, const int *__restrict__ ray_off,
                                                  const unsigned long long *__restrict__ ray_bits, int64_t cap,
                                                  float4 *__restrict__ smp_loc, int *__restrict__ smp_ray,
-                                                 int *__restrict__ n_sel, int64_t *__restrict__ counters)
+                                                 int *__restrict__ n_sel, int64_t *__restrict__ counters,
+                                                 float *__restrict__ ray_dirs)
 {
     const int lane = threadIdx.x & 63;
     const int64_t r0 = ((int64_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6)) * RPW;
@@ -287,9 +287,18 @@ __global__ void __launch_bounds__(TPB) k_expand(CamRef cr, const float *__restri
         my_n = ray_off[rl + 1] - my_off;
         if (my_n > 0 && !raypos) {
             cid = cam_id(cr, rl);
-            dx = dirs[3 * rl];
-            dy = dirs[3 * rl + 1];
-            dz = dirs[3 * rl + 2];
+            if (cr.gen_rays) {
+                // rays from cameras: the direction is generated here, and kept for the shading stage -- for the rays
+                // that have samples only (the rest of [R,3] is never written or read)
+                ray_dir(cr, load_cam_full(cr, cid), nullptr, rl, dx, dy, dz);
+                ray_dirs[3 * rl] = dx;
+                ray_dirs[3 * rl + 1] = dy;
+                ray_dirs[3 * rl + 2] = dz;
+            } else {
+                dx = dirs[3 * rl];
+                dy = dirs[3 * rl + 1];
+                dz = dirs[3 * rl + 2];
+            }
         }
     }
     unsigned long long todo = __ballot(my_n > 0);
@@ -652,7 +661,7 @@ int launch_select_expand(const GridView &g, const CamRef &cr, const float *d_dir
     int rc = scan_exclusive_i32(ws.ray_cnt, ws.ray_off, R, nullptr, nullptr, ws.scan_temp, stream);
     if (rc != PNR_OK) return rc;
     hipLaunchKernelGGL(k_expand, dim3(nblk((R + RPW - 1) / RPW, TPB / 64)), dim3(TPB), 0, stream, cr, d_dirs, d_raypos, R, D, SR,
-                       ws.ray_off, ws.ray_bits, cap, ws.smp_loc, ws.smp_ray, ws.n_sel, d_counters);
+                       ws.ray_off, ws.ray_bits, cap, ws.smp_loc, ws.smp_ray, ws.n_sel, d_counters, ws.ray_dirs);
     PNR_HIP_CHECK(hipGetLastError());
     return PNR_OK;
 }

@@ -162,13 +162,21 @@ extern "C" size_t pnr_render_workspace_bytes_for(const pnr_scene_t *scene, const
     return carve_render_ws(nullptr, R, cap_samples, opts->K, scene->N, scene->info[2]).total_pt;
 }
 
+// rays from cameras (pnr_render_camera): frame width, pixel list, pixels per view
+struct RayGen {
+    int W = 0;
+    const int *pixels = nullptr;
+    int64_t n_pixels = 0;
+};
+
 static int render_views(const pnr_scene_t *scene, const pnr_weights_t *weights, const float *d_dirs, int64_t R,
-                        const pnr_camera_t *cams, int32_t n_cams, const int32_t *d_ray_cam, int64_t rays_per_cam,
-                        const float *d_tmid, const pnr_render_opts_t *opts, float *d_rgb, float *d_depth, float *d_acc,
-                        int8_t *d_ray_mask, int64_t *d_counters, void *d_workspace, size_t workspace_bytes,
-                        int64_t cap_samples, hipStream_t stream, const char *who)
+                        const CamSet &set, const float *nears, int32_t n_cams, const int32_t *d_ray_cam,
+                        int64_t rays_per_cam, const RayGen *gen, const float *d_tmid, const pnr_render_opts_t *opts,
+                        float *d_rgb, float *d_depth, float *d_acc, int8_t *d_ray_mask, int64_t *d_counters,
+                        void *d_workspace, size_t workspace_bytes, int64_t cap_samples, hipStream_t stream,
+                        const char *who)
 {
-    PNR_REQUIRE(scene && weights && d_dirs && cams && d_tmid && opts && d_rgb && d_ray_mask && d_counters &&
+    PNR_REQUIRE(scene && weights && (d_dirs || gen) && d_tmid && opts && d_rgb && d_ray_mask && d_counters &&
                     d_workspace,
                 "%s: null argument", who);
     if (!scene->built || !scene->packed) {
@@ -202,11 +210,6 @@ static int render_views(const pnr_scene_t *scene, const pnr_weights_t *weights, 
     }
     const bool factored = true;  // both arithmetic modes start mlp_base layer 0 from the per-point table
     RenderWs ws = carve_render_ws(d_workspace, R, cap_samples, opts->K, scene->N, scene->info[2]);
-    CamSet set{};
-    for (int c = 0; c < n_cams; ++c) {
-        for (int i = 0; i < 3; ++i) set.c[c].o[i] = cams[c].campos[i];
-        for (int i = 0; i < 9; ++i) set.c[c].R[i] = cams[c].camrotc2w[i];
-    }
     hipLaunchKernelGGL(k_set_cams, dim3(1), dim3(64), 0, stream, set, n_cams, ws.cams);
     CamRef cr{};
     cr.cams = ws.cams;
@@ -217,7 +220,15 @@ static int render_views(const pnr_scene_t *scene, const pnr_weights_t *weights, 
     cr.n_cams = n_cams;
     cr.jitter = opts->jitter;
     cr.seed = opts->seed;
-    for (int c = 0; c < n_cams; ++c) cr.nears[c] = cams[c].near_plane;
+    for (int c = 0; c < n_cams; ++c) cr.nears[c] = nears[c];
+    if (gen) {
+        cr.gen_rays = 1;
+        cr.W = gen->W;
+        cr.pixels = gen->pixels;
+        cr.n_pixels = gen->n_pixels;
+    }
+    // the shading stage reads directions per hit ray: the caller's tensor, or the rows k_expand generated
+    const float *shade_dirs = gen ? ws.ray_dirs : d_dirs;
     const bool prof = g_prof;
     hipEvent_t *g_ev = g_evs[g_prof_calls % PNR_PROFILE_SLOTS];
     if (prof) PNR_HIP_CHECK(hipEventRecord(g_ev[0], stream));
@@ -230,7 +241,7 @@ static int render_views(const pnr_scene_t *scene, const pnr_weights_t *weights, 
     if (rc != PNR_OK) return rc;
     if (prof) PNR_HIP_CHECK(hipEventRecord(g_ev[2], stream));
     // events in time order: 0 select 1 knn 2 point-part 6 shade-pairs 3 shade-colour 4 composite 5
-    rc = launch_shade(scene, weights, cr, d_dirs, *opts, R, ws, cap_samples, d_counters, stream,
+    rc = launch_shade(scene, weights, cr, shade_dirs, *opts, R, ws, cap_samples, d_counters, stream,
                       prof ? g_ev[6] : nullptr, prof ? g_ev[3] : nullptr);
     if (rc != PNR_OK) return rc;
     if (prof) PNR_HIP_CHECK(hipEventRecord(g_ev[4], stream));
@@ -243,13 +254,39 @@ static int render_views(const pnr_scene_t *scene, const pnr_weights_t *weights, 
     return PNR_OK;
 }
 
+static void camset_of(const pnr_camera_t *cams, int n_cams, CamSet &set, float *nears)
+{
+    for (int c = 0; c < n_cams && c < PNR_MAX_CAMS; ++c) {
+        for (int i = 0; i < 3; ++i) set.c[c].o[i] = cams[c].campos[i];
+        for (int i = 0; i < 9; ++i) set.c[c].R[i] = cams[c].camrotc2w[i];
+        nears[c] = cams[c].near_plane;
+    }
+}
+
+static Camera camera_of(const pnr_view_t &v)
+{
+    Camera c{};
+    for (int i = 0; i < 3; ++i) c.o[i] = v.campos[i];
+    for (int i = 0; i < 9; ++i) c.R[i] = v.camrotc2w[i];
+    c.fx = v.fx;
+    c.fy = v.fy;
+    c.cx = v.cx;
+    c.cy = v.cy;
+    return c;
+}
+
 extern "C" int pnr_render(const pnr_scene_t *scene, const pnr_weights_t *weights, const float *d_dirs, int64_t R,
                           const pnr_camera_t *cam, const float *d_tmid, const pnr_render_opts_t *opts, float *d_rgb,
                           float *d_depth, float *d_acc, int8_t *d_ray_mask, int64_t *d_counters, void *d_workspace,
                           size_t workspace_bytes, int64_t cap_samples, void *stream)
 {
-    return render_views(scene, weights, d_dirs, R, cam, 1, nullptr, R, d_tmid, opts, d_rgb, d_depth, d_acc, d_ray_mask,
-                        d_counters, d_workspace, workspace_bytes, cap_samples, (hipStream_t)stream, "pnr_render");
+    PNR_REQUIRE(cam && d_dirs, "pnr_render: null argument");
+    CamSet set{};
+    float nears[PNR_MAX_CAMS] = {0};
+    camset_of(cam, 1, set, nears);
+    return render_views(scene, weights, d_dirs, R, set, nears, 1, nullptr, R, nullptr, d_tmid, opts, d_rgb, d_depth, d_acc,
+                        d_ray_mask, d_counters, d_workspace, workspace_bytes, cap_samples, (hipStream_t)stream,
+                        "pnr_render");
 }
 
 extern "C" int pnr_render_views(const pnr_scene_t *scene, const pnr_weights_t *weights, const float *d_dirs, int64_t R,
@@ -258,9 +295,93 @@ extern "C" int pnr_render_views(const pnr_scene_t *scene, const pnr_weights_t *w
                                 float *d_depth, float *d_acc, int8_t *d_ray_mask, int64_t *d_counters,
                                 void *d_workspace, size_t workspace_bytes, int64_t cap_samples, void *stream)
 {
-    return render_views(scene, weights, d_dirs, R, cams, n_cams, d_ray_cam, rays_per_cam, d_tmid, opts, d_rgb, d_depth,
-                        d_acc, d_ray_mask, d_counters, d_workspace, workspace_bytes, cap_samples, (hipStream_t)stream,
-                        "pnr_render_views");
+    PNR_REQUIRE(cams && d_dirs, "pnr_render_views: null argument");
+    PNR_REQUIRE(n_cams >= 1 && n_cams <= PNR_MAX_CAMS, "pnr_render_views: n_cams=%d not in [1,%d]", n_cams,
+                PNR_MAX_CAMS);
+    CamSet set{};
+    float nears[PNR_MAX_CAMS] = {0};
+    camset_of(cams, n_cams, set, nears);
+    return render_views(scene, weights, d_dirs, R, set, nears, n_cams, d_ray_cam, rays_per_cam, nullptr, d_tmid, opts,
+                        d_rgb, d_depth, d_acc, d_ray_mask, d_counters, d_workspace, workspace_bytes, cap_samples,
+                        (hipStream_t)stream, "pnr_render_views");
+}
+
+static int check_views(const pnr_view_t *views, int32_t n_views, int32_t H, int32_t W, const int32_t *d_pixels,
+                       int64_t n_pixels, const char *who)
+{
+    PNR_REQUIRE(views != nullptr, "%s: null argument", who);
+    PNR_REQUIRE(n_views >= 1 && n_views <= PNR_MAX_CAMS, "%s: n_views=%d not in [1,%d]", who, n_views, PNR_MAX_CAMS);
+    PNR_REQUIRE(H >= 1 && W >= 1 && (int64_t)H * W < (int64_t)0x7FFFFFF0, "%s: frame %d x %d out of range", who, H, W);
+    PNR_REQUIRE(n_pixels >= 1 && (d_pixels != nullptr || n_pixels <= (int64_t)H * W),
+                "%s: n_pixels=%lld does not fit the %d x %d frame", who, (long long)n_pixels, H, W);
+    for (int v = 0; v < n_views; ++v)
+        PNR_REQUIRE(views[v].fx > 0.f && views[v].fy > 0.f, "%s: view %d has focal lengths %g, %g", who, v, views[v].fx,
+                    views[v].fy);
+    return PNR_OK;
+}
+
+extern "C" int pnr_render_camera(const pnr_scene_t *scene, const pnr_weights_t *weights, const pnr_view_t *views,
+                                 int32_t n_views, int32_t H, int32_t W, const int32_t *d_pixels, int64_t n_pixels,
+                                 const float *d_tmid, const pnr_render_opts_t *opts, float *d_rgb, float *d_depth,
+                                 float *d_acc, int8_t *d_ray_mask, int64_t *d_counters, void *d_workspace,
+                                 size_t workspace_bytes, int64_t cap_samples, void *stream)
+{
+    int rc = check_views(views, n_views, H, W, d_pixels, n_pixels, "pnr_render_camera");
+    if (rc != PNR_OK) return rc;
+    CamSet set{};
+    float nears[PNR_MAX_CAMS] = {0};
+    for (int v = 0; v < n_views; ++v) {
+        set.c[v] = camera_of(views[v]);
+        nears[v] = views[v].near_plane;
+    }
+    RayGen gen;
+    gen.W = W;
+    gen.pixels = d_pixels;
+    gen.n_pixels = n_pixels;
+    return render_views(scene, weights, nullptr, (int64_t)n_views * n_pixels, set, nears, n_views, nullptr, n_pixels, &gen,
+                        d_tmid, opts, d_rgb, d_depth, d_acc, d_ray_mask, d_counters, d_workspace, workspace_bytes,
+                        cap_samples, (hipStream_t)stream, "pnr_render_camera");
+}
+
+extern "C" void pnr_pinhole_ray(const pnr_view_t *view, int32_t x, int32_t y, float dir[3])
+{
+    const Camera c = camera_of(*view);
+    pinhole_dir(c, x, y, dir[0], dir[1], dir[2]);
+}
+
+namespace pnr {
+__global__ void __launch_bounds__(TPB) k_camera_rays(CamSet set, CamRef cr, int64_t R, float *__restrict__ dirs)
+{
+    const int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (r >= R) return;
+    float dx, dy, dz;
+    ray_dir(cr, set.c[cam_id(cr, r)], nullptr, r, dx, dy, dz);
+    dirs[3 * r] = dx;
+    dirs[3 * r + 1] = dy;
+    dirs[3 * r + 2] = dz;
+}
+}  // namespace pnr
+
+extern "C" int pnr_camera_rays(const pnr_view_t *views, int32_t n_views, int32_t H, int32_t W, const int32_t *d_pixels,
+                               int64_t n_pixels, float *d_dirs, void *stream)
+{
+    int rc = check_views(views, n_views, H, W, d_pixels, n_pixels, "pnr_camera_rays");
+    if (rc != PNR_OK) return rc;
+    PNR_REQUIRE(d_dirs != nullptr, "pnr_camera_rays: null argument");
+    CamSet set{};
+    for (int v = 0; v < n_views; ++v) set.c[v] = camera_of(views[v]);
+    CamRef cr{};
+    cr.n_cams = n_views;
+    cr.rays_per_cam = n_pixels;
+    cr.gen_rays = 1;
+    cr.W = W;
+    cr.pixels = d_pixels;
+    cr.n_pixels = n_pixels;
+    const int64_t R = (int64_t)n_views * n_pixels;
+    hipLaunchKernelGGL(k_camera_rays, dim3((unsigned)((R + TPB - 1) / TPB)), dim3(TPB), 0, (hipStream_t)stream, set, cr, R,
+                       d_dirs);
+    PNR_HIP_CHECK(hipGetLastError());
+    return PNR_OK;
 }
 
 extern "C" int pnr_profile_enable(int enable)
@@ -306,5 +427,6 @@ extern "C" int pnr_render_taps(void *d_workspace, size_t workspace_bytes, int64_
     taps->smp_out = reinterpret_cast<const float *>(ws.smp_out);
     taps->ray_cnt = ws.ray_cnt;
     taps->ray_off = ws.ray_off;
+    taps->ray_dirs = ws.ray_dirs;
     return PNR_OK;
 }

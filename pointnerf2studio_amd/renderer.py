@@ -87,6 +87,56 @@ def grid_hyperparameters(xyz: torch.Tensor, vsize: Sequence[float], vscale: Sequ
     return GridHyper(rng, scaled_vsize_np, scaled_vdim)
 
 
+@dataclass
+class View:
+    """One pinhole view as nerfstudio's Cameras holds it: camera_to_worlds = [camrotc2w | campos], intrinsics in pixels."""
+    campos: Sequence[float]
+    camrotc2w: Sequence[float]     # 3x3, row-major
+    fx: float
+    fy: float
+    cx: float
+    cy: float
+    near: float = 2.0
+    far: float = 6.0
+
+    @staticmethod
+    def from_angle(campos, camrotc2w, H: int, W: int, camera_angle_x: float, near: float = 2.0, far: float = 6.0) -> "View":
+        """nerf-synthetic convention: focal = 0.5 W / tan(0.5 camera_angle_x), principal point at the frame centre."""
+        import math
+        f = 0.5 * W / math.tan(0.5 * camera_angle_x)
+        return View(campos, camrotc2w, f, f, 0.5 * W, 0.5 * H, near, far)
+
+
+def _views_c(views: Sequence[View]):
+    arr = (_lib.ViewC * len(views))()
+    for i, v in enumerate(views):
+        arr[i].campos[:] = [float(x) for x in torch.as_tensor(v.campos).reshape(3).tolist()]
+        arr[i].camrotc2w[:] = [float(x) for x in torch.as_tensor(v.camrotc2w).reshape(9).tolist()]
+        arr[i].near_plane, arr[i].far_plane = float(v.near), float(v.far)
+        arr[i].fx, arr[i].fy, arr[i].cx, arr[i].cy = float(v.fx), float(v.fy), float(v.cx), float(v.cy)
+    return arr
+
+
+def pinhole_ray(view: View, x: int, y: int) -> np.ndarray:
+    """Host statement of the direction the kernels generate for pixel (x, y) (pnr_pinhole_ray): float32 [3]."""
+    out = (C.c_float * 3)()
+    _lib.load().pnr_pinhole_ray(_views_c([view]), int(x), int(y), C.byref(out))
+    return np.array(list(out), dtype=np.float32)
+
+
+def camera_rays(views: Sequence[View], H: int, W: int, device, pixels: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """pnr_camera_rays: the directions pnr_render_camera generates in its kernels, written out as [n_views * n_pixels, 3]
+    (view-major; `pixels` int32 flat ids on the device, None = every pixel of the frame row-major)."""
+    lib = _lib.load()
+    px = None if pixels is None else pixels.to(device=device, dtype=torch.int32).contiguous()
+    n = H * W if px is None else px.numel()
+    out = torch.empty((len(views) * n, 3), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        _lib.check(lib.pnr_camera_rays(_views_c(views), len(views), H, W, _ptr(px), n, _ptr(out), _stream_ptr(device)),
+                   "pnr_camera_rays")
+    return out
+
+
 class SceneHIP:
     """Owns a pnr_scene_t.  Built once per point-cloud version; the reference rebuilds the equivalent
     structure for every ray chunk (query_worldcoords.cu:314-365)."""
@@ -331,6 +381,62 @@ class RendererHIP:
             # overflow: grow to what the frame actually needs (+12 %) and render again
             cap = int(cnt[2] * 1.125) + 1024
 
+    def render_camera(self, views: Sequence[View], H: int, W: int, pixels: Optional[torch.Tensor] = None,
+                      cap_samples: Optional[int] = None, sync_counters: bool = True, out: Optional[dict] = None):
+        """pnr_render_camera: the views' rays are generated inside the kernels from pose + intrinsics; no direction
+        tensor is handed over.  `pixels` (int32 flat ids y * W + x on the device: what a tile shard owns) or None for
+        the whole frame; the outputs have len(views) * n_pixels rows, view-major in `pixels` order."""
+        dev = self.scene.device
+        n = len(views)
+        if not 1 <= n <= _lib.MAX_CAMS:
+            raise ValueError(f"1..{_lib.MAX_CAMS} views per call, got {n}")
+        px = None if pixels is None else pixels.to(device=dev, dtype=torch.int32).contiguous()
+        n_px = H * W if px is None else int(px.numel())
+        R = n * n_px
+        key = ("views",) + tuple(id(v) for v in views)
+        cached = self._cam_cache.get(key)
+        sig = [(v.fx, v.fy, v.cx, v.cy, v.near, v.far) for v in views]   # (a View is a value: not mutated in place)
+        if cached is None or cached[3] != sig:
+            arr = _views_c(views)
+            tm = torch.stack([self.tmid(v.near, v.far, dev) for v in views]).contiguous()
+            cams = (_lib.CameraC * n)()     # the same cameras without intrinsics: what a backward call takes
+            for i in range(n):
+                cams[i].campos[:] = list(arr[i].campos)
+                cams[i].camrotc2w[:] = list(arr[i].camrotc2w)
+                cams[i].near_plane, cams[i].far_plane = arr[i].near_plane, arr[i].far_plane
+            if len(self._cam_cache) > 64:
+                self._cam_cache.clear()
+            # (the View objects are kept alive by the entry, so their ids stay theirs)
+            cached = self._cam_cache[key] = (arr, tm, cams, sig, list(views))
+        arr, tm, cams = cached[0], cached[1], cached[2]
+        cap = int(cap_samples or self.cap_samples or max(4096, min(R * self.opts.SR, R * 16)))
+        if out is None:
+            out = {
+                "rgb": torch.empty((R, 3), dtype=torch.float32, device=dev),
+                "depth": torch.empty((R,), dtype=torch.float32, device=dev),
+                "acc": torch.empty((R,), dtype=torch.float32, device=dev),
+                "ray_mask": torch.empty((R,), dtype=torch.int8, device=dev),
+                "counters_dev": torch.zeros(_lib.NUM_COUNTERS, dtype=torch.int64, device=dev),
+            }
+        while True:
+            ws = self._workspace(R, cap, dev)
+            # a backward after this render reads the directions k_expand wrote into the workspace (taps.ray_dirs)
+            self._last = ("camera", R, cams, n, None, n_px, cap)
+            self.calls += 1
+            with torch.cuda.device(dev):
+                _lib.check(self.lib.pnr_render_camera(
+                    self.scene.handle, self.weights.handle, arr, n, int(H), int(W), _ptr(px), n_px, _ptr(tm),
+                    C.byref(self.opts), _ptr(out["rgb"]), _ptr(out["depth"]), _ptr(out["acc"]), _ptr(out["ray_mask"]),
+                    _ptr(out["counters_dev"]), _ptr(ws), ws.numel(), cap, _stream_ptr(dev)), "pnr_render_camera")
+            if not sync_counters:
+                return out
+            cnt = out["counters_dev"].cpu().tolist()
+            out["counters"] = dict(zip(_lib.COUNTER_NAMES, cnt))
+            self.last_counters = out["counters"]
+            if cnt[6] == 0:
+                return out
+            cap = int(cnt[2] * 1.125) + 1024
+
     def backward(self, grad_rgb: torch.Tensor, state: Dict[str, torch.Tensor], num_points: int,
                  point_grads: bool = True, weight_grads: bool = True) -> Dict[str, torch.Tensor]:
         """Gradients of the LAST render / render_views call (pnr_render_backward): d loss / d {embedding [N,32],
@@ -341,6 +447,8 @@ class RendererHIP:
         if getattr(self, "_last", None) is None:
             raise RuntimeError("RendererHIP.backward: no render call to differentiate")
         d, R, arr, n, rc, rays_per_cam, cap = self._last
+        if isinstance(d, str):   # after render_camera: the per-hit-ray directions live in the render workspace
+            d = self.taps(R)["ray_dirs"]
         dev = d.device
         g = _f32c(grad_rgb.reshape(R, 3), dev)
         ws_t, bs_t = [], []
@@ -412,4 +520,5 @@ class RendererHIP:
             "smp_out": view(t.smp_out, cap * 16, torch.float32, (cap, 4)),
             "ray_cnt": view(t.ray_cnt, R * 4, torch.int32, (R,)),
             "ray_off": view(t.ray_off, R * 4, torch.int32, (R,)),
+            "ray_dirs": view(t.ray_dirs, R * 12, torch.float32, (R, 3)),
         }

@@ -35,6 +35,30 @@ def test_struct_layouts_match_header(lib):
     assert C.sizeof(_lib.GridParams) == 6 * 4 + 3 * 4 + 3 * 4 + 3 * 4 + 3 * 4 + 3 * 4
     assert C.sizeof(_lib.CameraC) == (3 + 9 + 2) * 4
     assert C.sizeof(_lib.RenderOpts) == 13 * 4
+    assert C.sizeof(_lib.ViewC) == (3 + 9 + 2 + 4) * 4
+
+
+def test_pinhole_ray_host_statement(lib):
+    """pnr_pinhole_ray is the host statement of the ray arithmetic pnr_render_camera runs in its kernels (nerfstudio's
+    pinhole convention: pixel centres, camera looking down -z, unit directions; studio_datamanager.py:62-110 hands
+    such bundles to the model).  Against the numpy formula in float64 and against synthetic.make_rays (torch)."""
+    from pointnerf2studio_amd import synthetic
+    from pointnerf2studio_amd.renderer import View, pinhole_ray
+    campos, camrot = synthetic.make_camera(35.0, 20.0)
+    H, W = 1200, 1600
+    v = View(campos, camrot, fx=1650.0, fy=1660.5, cx=790.25, cy=611.5)
+    R = camrot.double().numpy()
+    for (x, y) in [(0, 0), (1599, 1199), (800, 600), (13, 977), (1234, 5)]:
+        dc = np.array([(x + 0.5 - 790.25) / 1650.0, -(y + 0.5 - 611.5) / 1660.5, -1.0])
+        want = R @ dc
+        want /= np.linalg.norm(want)
+        got = pinhole_ray(v, x, y)
+        assert got.dtype == np.float32 and abs(np.linalg.norm(got.astype(np.float64)) - 1.0) < 1e-6
+        assert np.abs(got - want).max() < 2e-7
+    v2 = View.from_angle(campos, camrot, H, W, 0.9)
+    d = synthetic.make_rays(H, W, campos, camrot, 0.9, y0=300, y1=302, x0=40, x1=43).numpy()
+    for i, (y, x) in enumerate([(300, 40), (300, 41), (300, 42), (301, 40), (301, 41), (301, 42)]):
+        assert np.abs(pinhole_ray(v2, x, y) - d[i]).max() < 2e-7
 
 
 def test_argument_validation_fails_loudly(lib):
@@ -45,6 +69,13 @@ def test_argument_validation_fails_loudly(lib):
         _lib.check(rc, "pnr_scene_build")
     assert lib.pnr_render(None, None, None, 1, None, None, None, None, None, None, None, None, None, 0, 1, None) == -1
     assert lib.pnr_query_raypos(None, None, 1, 400, 80, 8, 0.016, None, None, None, None, None, 0, None) == -1
+    assert lib.pnr_render_camera(None, None, None, 1, 8, 8, None, 64, None, None, None, None, None, None, None, None, 0, 1,
+                                 None) == -1
+    view = (_lib.ViewC * 1)()
+    assert lib.pnr_camera_rays(view, 1, 8, 8, None, 64, None, None) == -1 and b"focal" in lib.pnr_last_error()
+    view[0].fx = view[0].fy = 10.0
+    assert lib.pnr_camera_rays(view, 1, 8, 8, None, 65, None, None) == -1 and b"n_pixels" in lib.pnr_last_error()
+    assert lib.pnr_camera_rays(view, 17, 8, 8, None, 64, None, None) == -1 and b"n_views" in lib.pnr_last_error()
 
 
 def test_workspace_sizes_are_monotonic(lib):
