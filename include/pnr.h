@@ -128,6 +128,16 @@ int pnr_scene_destroy(pnr_scene_t *scene);
  * are in ascending point index, first P kept. */
 int pnr_scene_build(pnr_scene_t *scene, const float *d_xyz, int64_t N, const pnr_grid_params_t *params,
                     void *stream);
+/* The cloud changed (points pruned and / or grown: neural_points.py:341-393 of the reference, driven by
+ * run/train_studio.py:676-735): rebuilds the structure over the NEW cloud d_xyz [N,3] inside the memory the scene
+ * already holds (no allocation unless it outgrew its buffers).  d_old_index [N] int32: the index point i had in the
+ * previous cloud, -1 for an added point.  When the grid (ranges[0:3], vox, dims) is unchanged, surviving points reuse
+ * their cell code and only the added points are binned.  The result is the structure pnr_scene_build produces on
+ * the same cloud, bit for bit (same order-independent steps).  The packed rows are invalidated: call pnr_points_pack. */
+int pnr_scene_update(pnr_scene_t *scene, const float *d_xyz, int64_t N, const pnr_grid_params_t *params,
+                     const int32_t *d_old_index, void *stream);
+/* info[0]=full builds, [1]=updates, [2]=cell codes reused by the last update, [3]=bytes of build scratch kept */
+int pnr_scene_update_info(const pnr_scene_t *scene, int64_t info[4]);
 /* info[0]=occupied voxels, [1]=(occupied > max_o), [2]=points kept in voxel lists, [3]=bricks,
  * [4]=device bytes held, [5]=N, [6]=points inside the grid, [7]=voxel dropped by compat (-1 none) */
 int pnr_scene_info(const pnr_scene_t *scene, int64_t info[8]);
@@ -253,13 +263,23 @@ int pnr_render_taps(void *d_workspace, size_t workspace_bytes, int64_t R, int64_
  * reference (studio_utils.py:84-90) and points_conf does not enter the render (studio_model.py:285-292: it feeds
  * the loss directly), so none of them gets a gradient here.
  * Every pointer may be null (that gradient is skipped); gradients are ACCUMULATED (+=) as torch does with .grad:
- * zero the buffers first for plain gradients.  Shapes are those of pnr_points_pack / pnr_weights_pack inputs. */
+ * zero the buffers first for plain gradients.  Shapes are those of pnr_points_pack / pnr_weights_pack inputs.
+ * The point gradients are summed per point in a FIXED order (rows grouped by point, ascending row index: a segmented
+ * sum, no float atomics): two calls on the same inputs return the same bits. */
 typedef struct {
     float *d_embedding; /* [N,32] */
     float *d_color;     /* [N,3]  */
     float *d_dir;       /* [N,3]  */
     float *d_w[9];      /* nn.Linear weights, [out,in] row-major, order of pnr_weights_pack */
     float *d_b[9];      /* [out] */
+    /* Sparse emission of the point gradients (instead of the three dense tensors above, which are then ignored): row u
+     * of d_point_grads [point_cap, 40] = [d embedding (32) | d color (3) | d dir (3) | 0 0] of the u-th distinct
+     * neighbour point of the render (ascending point index, U = d_counters[PNR_CNT_POINTS_UNIQUE] rows; rows are
+     * WRITTEN, not accumulated) and d_point_index [point_cap] its point index.  A 4096-ray batch touches ~60 k of 6 M
+     * points: 10 MB instead of a zero-filled 768-MB tensor. */
+    float *d_point_grads;
+    int32_t *d_point_index;
+    int64_t point_cap;
 } pnr_grads_t;
 
 size_t pnr_backward_workspace_bytes(int64_t cap_samples, int32_t K);
@@ -278,6 +298,29 @@ int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t *weights, 
                         size_t render_workspace_bytes, int64_t cap_samples, void *d_train_workspace,
                         size_t train_workspace_bytes, const pnr_grads_t *grads, float *d_rgb_recomputed,
                         void *stream);
+
+/* ---- probing outputs (point growing) ------------------------------------------------------------------
+ * What the reference's legacy model returns with `opt.prob == 1` (models/neural_points_volumetric_model.py:331-352)
+ * and run/train_studio.py:335-444 turns into new points: per ray, the shading sample of largest opacity
+ * 1 - exp(-sigma * ray_dist) (the first one on ties), its world position, the distance of its nearest neighbour, and
+ * the K-averages of its neighbours' colour / dir / conf / embedding under the weights the legacy aggregator returns in
+ * probe mode: normalised inverse-distance weight x clamp(conf, 1e-4, 1) (point_aggregators.py:816-830).
+ * Call after pnr_render / pnr_render_views / pnr_render_camera with the same cameras, options, cap_samples and
+ * render workspace (sample lists, neighbour lists and densities are read from it).  Rays that are not kept get zeros
+ * and index -1.  Any output pointer may be null.  No host synchronisation. */
+typedef struct {
+    float *d_max_opacity;    /* [R]     ray_max_shading_opacity                                   */
+    float *d_max_loc;        /* [R,3]   ray_max_sample_loc_w                                      */
+    float *d_far_dist;       /* [R]     ray_max_far_dist: min over the FILLED neighbour slots (1e10 if none) */
+    float *d_avg_color;      /* [R,3]   shading_avg_color                                         */
+    float *d_avg_dir;        /* [R,3]   shading_avg_dir                                           */
+    float *d_avg_conf;       /* [R]     shading_avg_conf                                          */
+    float *d_avg_embedding;  /* [R,32]  shading_avg_embedding                                     */
+    int32_t *d_max_index;    /* [R]     index of that sample among the ray's selected samples      */
+} pnr_probe_t;
+int pnr_render_probe(const pnr_scene_t *scene, const pnr_camera_t *cams, int32_t n_cams, const int32_t *d_ray_cam,
+                     int64_t rays_per_cam, const pnr_render_opts_t *opts, int64_t R, void *d_render_workspace,
+                     size_t render_workspace_bytes, int64_t cap_samples, const pnr_probe_t *out, void *stream);
 
 /* ---- per-stage device timing (bench / roofline) ------------------------------------------------- */
 /* When enabled, pnr_render records hipEvents on `stream` between its stages into a ring of

@@ -510,7 +510,7 @@ def fill_invalid(rgb_hit, ray_mask):
 
 
 def render(points, w, cfg: OracleConfig, origins, directions, near, far, camrotc2w,
-           jitter: float = 0.0, u=None, training: bool = False, compat_drop0: bool = True):
+           jitter: float = 0.0, u=None, training: bool = False, compat_drop0: bool = True, probe: bool = False):
     """NeuralPoints.forward + PointNerf.get_outputs for one ray bundle.  Returns a dict with
     the plugin's outputs (coarse_raycolor [R,3], ray_mask [R] int8) plus the build's extra
     outputs (depth [R], acc [R]) and intermediate tensors used by the parity tests."""
@@ -536,7 +536,73 @@ def render(points, w, cfg: OracleConfig, origins, directions, near, far, camrotc
     acc[keep] = acc_hit[0]
     out.update(depth=depth, acc=acc, decoded=decoded, sample_valid=sample_valid, sample_pidx=None,
                sample_loc_w=loc_w, blend_weight=bw, pnt_mask=pnt_mask, agg_weight=weight)
+    if probe:
+        out["probe"] = probe_outputs(decoded, sample_valid, loc, loc_w, vsize, weight, s_conf, s_xyz, s_color, s_dir,
+                                     s_emb, pnt_mask, ray_mask, R)
     return out
+
+
+# --------------------------------------------------------------------------------------
+# probing outputs + point grow / prune
+# --------------------------------------------------------------------------------------
+def probe_outputs(decoded, sample_valid, loc, loc_w, vsize, weight, s_conf, s_xyz, s_color, s_dir, s_emb, pnt_mask,
+                  ray_mask, R):
+    """models/neural_points_volumetric_model.py:331-352 (`opt.prob == 1`): per ray, the shading sample of largest
+    opacity (`coarse_point_opacity` = 1 - exp(-sigma * ray_dist), first maximum), its world position, the distance of
+    its nearest neighbour and the K-averages of its neighbours' colour / dir / conf / embedding with the weights the
+    legacy aggregator returns in probe mode: normalised inverse-distance weight x clamp(conf, 1e-4, 1)
+    (models/aggregators/point_aggregators.py:816-830).  Opacity uses this build's ray_dist (the plugin's,
+    studio_model.py:368-375).  One stated deviation: `ray_max_far_dist` takes the minimum over the FILLED neighbour
+    slots (the legacy gather reads point 0 through unfilled slots, neural_points.py clamp(pidx, 0)); 1e10 if none.
+    Rays that are not kept: all zeros, max_index -1.  Returns tensors over ALL R rays."""
+    ray_dist = compute_ray_dist(loc, sample_valid, vsize)
+    _, opacity, _, _, _ = alpha_composite(decoded, sample_valid, ray_dist)          # [1,R'',SR]
+    max_op, ind = torch.max(opacity, dim=-1, keepdim=True)
+    # torch.max does not promise WHICH maximum on ties; the canonical choice is the first
+    first = (opacity == max_op).float().argmax(dim=-1, keepdim=True)
+    ind = first
+    g3 = lambda t: torch.gather(t, 2, ind[..., None].expand(-1, -1, -1, t.shape[-1])).squeeze(2)
+    g4 = lambda t: torch.gather(t, 2, ind[..., None, None].expand(-1, -1, -1, t.shape[-2], t.shape[-1])).squeeze(2)
+    max_loc = g3(loc_w)                                                                  # [1,R'',3]
+    conf_c = torch.clamp(s_conf[..., 0], min=0.0001, max=1)
+    wk = g3(weight * conf_c)[..., None]                                                  # [1,R'',K,1]
+    nb_xyz, nb_mask = g4(s_xyz), g3(pnt_mask.float()) > 0
+    d = torch.norm(nb_xyz - max_loc[..., None, :], dim=-1)
+    d = torch.where(nb_mask, d, torch.full_like(d, 1e10))
+    far = torch.min(d, dim=-1)[0]
+    vals = dict(max_opacity=max_op[0, :, 0], max_loc=max_loc[0], far_dist=far[0],
+                avg_color=torch.sum(g4(s_color) * wk, dim=-2)[0], avg_dir=torch.sum(g4(s_dir) * wk, dim=-2)[0],
+                avg_conf=torch.sum(g4(s_conf) * wk, dim=-2)[0, :, 0], avg_embedding=torch.sum(g4(s_emb) * wk, dim=-2)[0],
+                max_index=ind[0, :, 0].to(torch.int32))
+    keep = ray_mask[0] > 0
+    full = {}
+    for k, v in vals.items():
+        t = torch.full((R,) + tuple(v.shape[1:]), -1 if k == "max_index" else 0, dtype=v.dtype)
+        t[keep] = v
+        full[k] = t
+    return full
+
+
+def prune_points(points: Dict[str, torch.Tensor], thresh: float):
+    """models/neural_points/neural_points.py:341-364: keep the points whose confidence is >= thresh.  Returns the new
+    tensors and old_index [N'] (the index each kept point had)."""
+    mask = points["conf"][0, ..., 0] >= thresh
+    out = {"xyz": points["xyz"][mask, :], "embedding": points["embedding"][:, mask, :],
+           "conf": points["conf"][:, mask, :], "dir": points["dir"][:, mask, :], "color": points["color"][:, mask, :],
+           "Rw2c": points["Rw2c"]}
+    return out, torch.nonzero(mask).reshape(-1).to(torch.int32)
+
+
+def grow_points(points: Dict[str, torch.Tensor], add_xyz, add_embedding, add_color, add_dir, add_conf):
+    """models/neural_points/neural_points.py:367-393: the added points are appended behind the existing ones."""
+    N = points["xyz"].shape[0]
+    out = {"xyz": torch.cat([points["xyz"], add_xyz], dim=0),
+           "embedding": torch.cat([points["embedding"], add_embedding[None, ...]], dim=1),
+           "conf": torch.cat([points["conf"], add_conf[None, ...]], dim=1),
+           "dir": torch.cat([points["dir"], add_dir[None, ...]], dim=1),
+           "color": torch.cat([points["color"], add_color[None, ...]], dim=1), "Rw2c": points["Rw2c"]}
+    old = torch.cat([torch.arange(N, dtype=torch.int32), torch.full((add_xyz.shape[0],), -1, dtype=torch.int32)])
+    return out, old
 
 
 # --------------------------------------------------------------------------------------

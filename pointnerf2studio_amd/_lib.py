@@ -24,6 +24,7 @@ MAX_CAMS = 16
 EXPORTED_SYMBOLS = [
     "pnr_last_error", "pnr_version", "pnr_jitter_uniform",
     "pnr_scene_create", "pnr_scene_destroy", "pnr_scene_build", "pnr_scene_info", "pnr_points_pack",
+    "pnr_scene_update", "pnr_scene_update_info", "pnr_render_probe",
     "pnr_weights_create", "pnr_weights_destroy", "pnr_weights_pack",
     "pnr_query_workspace_bytes", "pnr_query_raypos",
     "pnr_render_workspace_bytes", "pnr_render_workspace_bytes_for", "pnr_render", "pnr_render_views",
@@ -67,9 +68,17 @@ class RenderTaps(C.Structure):
                 ("smp_out", C.c_void_p), ("ray_cnt", C.c_void_p), ("ray_off", C.c_void_p), ("ray_dirs", C.c_void_p)]
 
 
+class ProbeC(C.Structure):
+    """pnr_probe_t"""
+    _fields_ = [("d_max_opacity", C.c_void_p), ("d_max_loc", C.c_void_p), ("d_far_dist", C.c_void_p),
+                ("d_avg_color", C.c_void_p), ("d_avg_dir", C.c_void_p), ("d_avg_conf", C.c_void_p),
+                ("d_avg_embedding", C.c_void_p), ("d_max_index", C.c_void_p)]
+
+
 class GradsC(C.Structure):
     _fields_ = [("d_embedding", C.c_void_p), ("d_color", C.c_void_p), ("d_dir", C.c_void_p),
-                ("d_w", C.c_void_p * 9), ("d_b", C.c_void_p * 9)]
+                ("d_w", C.c_void_p * 9), ("d_b", C.c_void_p * 9),
+                ("d_point_grads", C.c_void_p), ("d_point_index", C.c_void_p), ("point_cap", C.c_int64)]
 
 
 _lib: Optional[C.CDLL] = None
@@ -96,6 +105,10 @@ def load() -> C.CDLL:
     lib.pnr_scene_build.argtypes = [vp, vp, i64, C.POINTER(GridParams), vp]
     lib.pnr_scene_info.argtypes = [vp, C.POINTER(i64 * 8)]
     lib.pnr_points_pack.argtypes = [vp, vp, vp, vp, vp, vp, i64, vp]
+    lib.pnr_scene_update.argtypes = [vp, vp, i64, C.POINTER(GridParams), vp, vp]
+    lib.pnr_scene_update_info.argtypes = [vp, C.POINTER(i64 * 4)]
+    lib.pnr_render_probe.argtypes = [vp, C.POINTER(CameraC), i32, vp, i64, C.POINTER(RenderOpts), i64, vp, sz, i64,
+                                     C.POINTER(ProbeC), vp]
     lib.pnr_weights_create.argtypes = [C.POINTER(vp)]
     lib.pnr_weights_destroy.argtypes = [vp]
     lib.pnr_weights_pack.argtypes = [vp, C.POINTER(vp * 9), C.POINTER(vp * 9), vp, vp]

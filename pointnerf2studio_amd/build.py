@@ -26,7 +26,10 @@ SOURCES = ["pnr_scan.hip", "pnr_scene.hip", "pnr_query.hip", "pnr_shade.hip", "p
 # -ffp-contract=off: the voxel coordinate, the sample position (o + d*t) and the neighbour distance
 # must be evaluated exactly as the reference / oracle do (no FMA contraction); the MLP runs on fp32
 # MFMA, whose fma chain is explicit.
+# -pragma-unroll-threshold: the pair kernels are ONE basic block of 3360 MFMAs with everything else placed between them by
+# hand; `#pragma unroll` silently gives up above LLVM's default of 16 k instructions per unrolled loop.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-mllvm", "-pragma-unroll-threshold=4000000",
          "-Wall", "-Wno-unused-function", "-I", INCLUDE, "-I", CSRC]
 
 

@@ -204,6 +204,13 @@ int scan_exclusive_i32(const int *in, int *out, int64_t n_max, const int *n_dev,
 // ------------------------------------------------------------------------------------------------
 }  // namespace pnr
 
+// device buffer that is kept (and grown geometrically) across builds / updates of a scene
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;  // elements
+};
+
 struct pnr_scene {
     bool built = false;
     bool packed = false;
@@ -219,6 +226,21 @@ struct pnr_scene {
     float *point_rows = nullptr;  // [N, PNR_POINT_ROW_FLOATS]
     int64_t packed_N = 0;
     size_t bytes = 0;
+    // build scratch, kept so that pnr_scene_update neither allocates nor recomputes what survives:
+    // cell code of every point of the current cloud ((brick << 6) | bit, 0xFFFFFFFF outside the grid) and of the
+    // previous one, the raw occupancy, counters, and the per-voxel work arrays
+    DevBuf<uint32_t> pt_cell[2];
+    int cur_cell = 0;
+    DevBuf<unsigned long long> occ_all, occ_pts, occ_dil_buf;
+    DevBuf<pnr::BrickRec> rec_buf;
+    DevBuf<int> popc, cnt, capped, full_start, cursor, full_list, vox_start_buf;
+    DevBuf<float4> cand_buf;
+    DevBuf<unsigned char> scan_tmp;
+    DevBuf<int> first_valid;               // [1] smallest index of a point inside the grid
+    DevBuf<unsigned long long> n_inside;   // [1]
+    DevBuf<long long> dropped;             // [1] cell code of the compat-dropped voxel, -1 none
+    size_t scratch_bytes = 0;
+    int64_t builds = 0, updates = 0, cells_reused = 0;
 };
 
 // Packed MLP weights.  Layer l, output tile m (32 features), k-step group g (4 k-steps), lane, 4 floats:

@@ -175,10 +175,22 @@ __global__ void __launch_bounds__(TPB) k_select(GridView g, CamRef cr, const flo
                     t_out = -3.0e38f;  // parallel to the slab and outside it
                 }
             }
-            // word range that can intersect the box.  The table is monotonic and (at jitter 0) linear: the range
-            // comes from its end points with 3 samples of slack, then the first/last kept word is verified against
-            // the table.  Jittered parameters drift from the table: every word is probed.
-            if (!jittered && D > 1) {
+            // word range that can intersect the box.  The table is monotonic and linear: the range comes from its end
+            // points with 3 samples of slack, then the first/last kept word is verified against the table.
+            // Jittered parameters drift from the table, but boundedly: sample j sits at near + f * (table_j - near)
+            // with f in [1 - jitter/2, 1 + jitter/2) (every segment is scaled by 1 + jitter * (u - 0.5), u in [0, 1)),
+            // so it can lie in [t_in, t_out] only if its TABLE value lies in
+            // [near + (t_in - near) / (1 + jitter/2), near + (t_out - near) / (1 - jitter/2)].
+            if (D > 1) {
+                if (jittered) {
+                    const float nr = cr.nears[cid];
+                    const float f_hi = 1.0f + 0.5f * cr.jitter, f_lo = 1.0f - 0.5f * cr.jitter;
+                    // (t - near) may be negative: the division by the wider / narrower factor then moves the bound
+                    // the other way, so take the looser of the two on each side
+                    const float a_in = t_in - nr, a_out = t_out - nr;
+                    t_in = nr + fminf(a_in / f_hi, a_in / f_lo) - 1e-4f;
+                    t_out = nr + fmaxf(a_out / f_lo, a_out / f_hi) + 1e-4f;
+                }
                 const float t0 = tmid[0], t1 = tmid[D - 1];
                 const float inv_dt = (float)(D - 1) / (t1 - t0);
                 const float jl = (t_in - t0) * inv_dt - 3.0f, jh = (t_out - t0) * inv_dt + 3.0f;
@@ -222,15 +234,18 @@ __global__ void __launch_bounds__(TPB) k_select(GridView g, CamRef cr, const flo
         // all probes of the ray first (one occupancy word per step, loads in flight together), then the ballots
         unsigned long long occ[MAXW];
         int bitpos[MAXW];
+        // jittered parameters are a running sum from sample 0: the scan runs over every word up to wh, the probes
+        // over [wl, wh] only
+        const int w_first = jittered ? 0 : wl;
 #pragma unroll
         for (int k = 0; k < MAXW; ++k) {
             occ[k] = 0ull;
             bitpos[k] = 0;
-            const int w = wl + k;
+            const int w = w_first + k;
             if (w > wh) continue;  // wave-uniform
             const int j = w * 64 + lane;
             const float t = raypos ? 0.f : sample_t(cr, tmid, near_plane, r, D, w, lane, carry, e_prev);
-            if (j < D) {
+            if (j < D && w >= wl) {
                 float px, py, pz;
                 sample_pos(raypos, rd, cam, r, D, j, t, px, py, pz);
                 int cx, cy, cz;
@@ -243,7 +258,7 @@ __global__ void __launch_bounds__(TPB) k_select(GridView g, CamRef cr, const flo
         }
 #pragma unroll
         for (int k = 0; k < MAXW; ++k) {
-            const int w = wl + k;
+            const int w = w_first + k;
             if (w > wh) continue;
             const unsigned long long m = __ballot((occ[k] >> bitpos[k]) & 1ull);
             if (lane == w) my_word = m;

@@ -118,6 +118,123 @@ __global__ void __launch_bounds__(TPB) k_composite(CamRef cr, pnr_render_opts_t 
     if (keep) shard_add(shards, SH_KEPT, 1ull);
 }
 
+// Probing outputs (neural_points_volumetric_model.py:331-352): one thread per ray.  First pass = the composite's own
+// ray_dist / opacity arithmetic to find the first sample of largest opacity; second = that sample's K neighbour rows.
+__global__ void __launch_bounds__(TPB) k_probe(CamRef cr, pnr_render_opts_t opts, int64_t R,
+                                                const int *__restrict__ ray_cnt, const int *__restrict__ ray_off,
+                                                const int *__restrict__ ray_flag, const float4 *__restrict__ smp_loc,
+                                                const float4 *__restrict__ smp_out, const int *__restrict__ n_sel,
+                                                const int *__restrict__ smp_pidx, const float4 *__restrict__ point_rows,
+                                                pnr_probe_t o)
+{
+    const int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (r >= R) return;
+    const int S = n_sel[0];
+    const int off = ray_off[r];
+    int cnt = ray_cnt[r];
+    if ((int64_t)off + cnt > S) cnt = max(0, S - off);
+    const bool keep = ray_flag[r] != 0 && cnt > 0;
+    float best = -1.0f;
+    int best_i = -1;
+    float4 best_loc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (keep) {
+        const Camera cam = load_cam_lanes(cr, cam_id(cr, r));
+        const float vs = opts.vsize_z, two_vs = 2.0f * vs;
+        auto zc = [&](float x, float y, float z) {
+            const float sx = x - cam.o[0], sy = y - cam.o[1], sz = z - cam.o[2];
+            return sx * cam.R[2] + sy * cam.R[5] + sz * cam.R[8];
+        };
+        const float z_unfilled = zc(0.f, 0.f, 0.f);
+        float4 p = smp_loc[off];
+        float cm = zc(p.x, p.y, p.z);
+        for (int i = 0; i < cnt; ++i) {
+            const float4 here = p;
+            float delta;
+            if (i == opts.SR - 1) {
+                delta = vs;
+            } else {
+                float z_next = z_unfilled;
+                if (i + 1 < cnt) {
+                    p = smp_loc[off + i + 1];
+                    z_next = zc(p.x, p.y, p.z);
+                }
+                const float cm_next = fmaxf(cm, z_next);
+                delta = cm_next - cm;
+                cm = cm_next;
+                if (delta < 1e-8f || delta > two_vs) delta = vs;
+            }
+            const float opacity = 1.0f - expf(-smp_out[off + i].x * delta);
+            if (opacity > best) {   // strictly: the first maximum wins
+                best = opacity;
+                best_i = i;
+                best_loc = here;
+            }
+        }
+    }
+    float far = 0.f, conf_avg = 0.f, col[3] = {0.f, 0.f, 0.f}, dir[3] = {0.f, 0.f, 0.f};
+    float emb[PNR_FEAT_DIM];
+#pragma unroll
+    for (int i = 0; i < PNR_FEAT_DIM; ++i) emb[i] = 0.f;
+    if (best_i >= 0) {
+        const int K = opts.K;
+        const int *list = smp_pidx + ((int64_t)off + best_i) * K;
+        float wsum = 0.f;
+        far = 1e10f;
+        for (int k = 0; k < K; ++k) {
+            const int pi = list[k];
+            if (pi < 0) continue;
+            const float4 a0 = point_rows[(int64_t)pi * 12];
+            const float dx = a0.x - best_loc.x, dy = a0.y - best_loc.y, dz = a0.z - best_loc.z;
+            const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+            wsum += 1.0f / fmaxf(nrm, 1e-6f);
+            far = fminf(far, nrm);
+        }
+        const float inv = 1.0f / fmaxf(wsum, 1e-8f);
+        for (int k = 0; k < K; ++k) {
+            const int pi = list[k];
+            if (pi < 0) continue;
+            const float4 *row = point_rows + (int64_t)pi * 12;
+            const float4 a0 = row[0], c0 = row[1], c1 = row[2];
+            const float dx = a0.x - best_loc.x, dy = a0.y - best_loc.y, dz = a0.z - best_loc.z;
+            const float w = (1.0f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-6f)) * inv *
+                            fminf(fmaxf(a0.w, 0.0001f), 1.0f);
+            conf_avg += w * a0.w;
+            col[0] += w * c0.x;
+            col[1] += w * c0.y;
+            col[2] += w * c0.z;
+            dir[0] += w * c0.w;
+            dir[1] += w * c1.x;
+            dir[2] += w * c1.y;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 e = row[4 + q];
+                emb[4 * q] += w * e.x;
+                emb[4 * q + 1] += w * e.y;
+                emb[4 * q + 2] += w * e.z;
+                emb[4 * q + 3] += w * e.w;
+            }
+        }
+    }
+    if (o.d_max_opacity) o.d_max_opacity[r] = best_i >= 0 ? best : 0.f;
+    if (o.d_max_index) o.d_max_index[r] = best_i;
+    if (o.d_far_dist) o.d_far_dist[r] = far;
+    if (o.d_avg_conf) o.d_avg_conf[r] = conf_avg;
+    if (o.d_max_loc) {
+        o.d_max_loc[3 * r] = best_loc.x;
+        o.d_max_loc[3 * r + 1] = best_loc.y;
+        o.d_max_loc[3 * r + 2] = best_loc.z;
+    }
+    if (o.d_avg_color)
+        for (int i = 0; i < 3; ++i) o.d_avg_color[3 * r + i] = col[i];
+    if (o.d_avg_dir)
+        for (int i = 0; i < 3; ++i) o.d_avg_dir[3 * r + i] = dir[i];
+    if (o.d_avg_embedding) {
+        float4 *dst = reinterpret_cast<float4 *>(o.d_avg_embedding + (int64_t)r * PNR_FEAT_DIM);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dst[q] = make_float4(emb[4 * q], emb[4 * q + 1], emb[4 * q + 2], emb[4 * q + 3]);
+    }
+}
+
 __global__ void k_publish_kept(const unsigned long long *__restrict__ shards, int64_t *__restrict__ counters)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) counters[PNR_CNT_RAYS_KEPT] = (int64_t)shard_sum(shards, SH_KEPT);
@@ -380,6 +497,47 @@ extern "C" int pnr_camera_rays(const pnr_view_t *views, int32_t n_views, int32_t
     const int64_t R = (int64_t)n_views * n_pixels;
     hipLaunchKernelGGL(k_camera_rays, dim3((unsigned)((R + TPB - 1) / TPB)), dim3(TPB), 0, (hipStream_t)stream, set, cr, R,
                        d_dirs);
+    PNR_HIP_CHECK(hipGetLastError());
+    return PNR_OK;
+}
+
+extern "C" int pnr_render_probe(const pnr_scene_t *scene, const pnr_camera_t *cams, int32_t n_cams,
+                                const int32_t *d_ray_cam, int64_t rays_per_cam, const pnr_render_opts_t *opts, int64_t R,
+                                void *d_render_workspace, size_t render_workspace_bytes, int64_t cap_samples,
+                                const pnr_probe_t *out, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    PNR_REQUIRE(scene && cams && opts && d_render_workspace && out, "pnr_render_probe: null argument");
+    if (!scene->built || !scene->packed) {
+        set_error("pnr_render_probe: scene not built / points not packed");
+        return PNR_ERR_STATE;
+    }
+    PNR_REQUIRE(R >= 1 && R < (int64_t)0x7FFFFFF0, "pnr_render_probe: R=%lld out of range", (long long)R);
+    PNR_REQUIRE(n_cams >= 1 && n_cams <= PNR_MAX_CAMS, "pnr_render_probe: n_cams=%d not in [1,%d]", n_cams,
+                PNR_MAX_CAMS);
+    PNR_REQUIRE(d_ray_cam != nullptr || (rays_per_cam >= 1 && rays_per_cam * n_cams >= R),
+                "pnr_render_probe: rays_per_cam=%lld does not cover R=%lld rays", (long long)rays_per_cam, (long long)R);
+    PNR_REQUIRE(opts->K >= 1 && opts->K <= PNR_MAX_K && opts->SR >= 1, "pnr_render_probe: K=%d SR=%d", opts->K,
+                opts->SR);
+    PNR_REQUIRE(opts->early_stop_eps == 0.f, "pnr_render_probe: needs a render with early_stop_eps = 0");
+    const size_t need = pnr_render_workspace_bytes_for(scene, opts, R, cap_samples);
+    if (render_workspace_bytes < need) {
+        set_error("pnr_render_probe: workspace of %zu bytes < %zu of the render it follows", render_workspace_bytes, need);
+        return PNR_ERR_WORKSPACE;
+    }
+    RenderWs ws = carve_render_ws(d_render_workspace, R, cap_samples, opts->K, scene->N, scene->info[2]);
+    CamSet set{};
+    float nears[PNR_MAX_CAMS] = {0};
+    camset_of(cams, n_cams, set, nears);
+    hipLaunchKernelGGL(k_set_cams, dim3(1), dim3(64), 0, stream, set, n_cams, ws.cams);
+    CamRef cr{};
+    cr.cams = ws.cams;
+    cr.ray_cam = d_ray_cam;
+    cr.rays_per_cam = d_ray_cam ? 1 : rays_per_cam;
+    cr.n_cams = n_cams;
+    hipLaunchKernelGGL(k_probe, dim3((unsigned)((R + TPB - 1) / TPB)), dim3(TPB), 0, stream, cr, *opts, R, ws.ray_cnt,
+                       ws.ray_off, ws.ray_flag, ws.smp_loc, ws.smp_out, ws.n_sel, ws.smp_pidx,
+                       reinterpret_cast<const float4 *>(scene->point_rows), *out);
     PNR_HIP_CHECK(hipGetLastError());
     return PNR_OK;
 }

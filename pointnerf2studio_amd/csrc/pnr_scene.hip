@@ -16,22 +16,34 @@ namespace pnr {
 constexpr int TPB = 256;
 
 // ---- B1: cell of every point, raw occupancy bits, first in-grid point -------------------------------
+// old_index (pnr_scene_update on an unchanged grid): point i of the new cloud was point old_index[i] of the previous
+// one (-1: added) -- a surviving point keeps its cell code, only added points pay the three fp32 divisions.
 __global__ void __launch_bounds__(TPB) k_point_cells(const float *__restrict__ xyz, int64_t N, GridView g,
+                                                      const int *__restrict__ old_index,
+                                                      const uint32_t *__restrict__ old_cell, int64_t N_old,
                                                       uint32_t *__restrict__ pt_cell,
                                                       unsigned long long *__restrict__ occ_all,
                                                       int *__restrict__ first_valid,
-                                                      unsigned long long *__restrict__ n_inside)
+                                                      unsigned long long *__restrict__ n_inside,
+                                                      unsigned long long *__restrict__ n_reused)
 {
     int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
     if (i >= N) return;
-    int cx, cy, cz;
-    bool ok = cell_of(g, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], cx, cy, cz);
     uint32_t code = 0xFFFFFFFFu;
-    if (ok) {
-        int brick, bit;
-        brick_of(g, cx, cy, cz, brick, bit);
-        code = ((uint32_t)brick << 6) | (uint32_t)bit;
-        atomicOr(&occ_all[brick], 1ull << bit);
+    const int oi = old_index ? old_index[i] : -1;
+    if (oi >= 0 && oi < N_old) {
+        code = old_cell[oi];
+        atomicAdd(n_reused, 1ull);
+    } else {
+        int cx, cy, cz;
+        if (cell_of(g, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], cx, cy, cz)) {
+            int brick, bit;
+            brick_of(g, cx, cy, cz, brick, bit);
+            code = ((uint32_t)brick << 6) | (uint32_t)bit;
+        }
+    }
+    if (code != 0xFFFFFFFFu) {
+        atomicOr(&occ_all[code >> 6], 1ull << (code & 63));
         atomicMin(first_valid, (int)i);
         atomicAdd(n_inside, 1ull);
     }
@@ -200,26 +212,217 @@ __global__ void __launch_bounds__(TPB) k_pack_points(const float *__restrict__ x
 
 static inline unsigned nblk(int64_t n) { return (unsigned)((n + TPB - 1) / TPB); }
 
+// grow-only device buffer: reallocated (with 1/8 headroom) when the request exceeds its capacity
 template <typename T>
-static int dev_alloc(T **p, size_t count, size_t *bytes)
+static int ensure(DevBuf<T> &b, size_t count, size_t *bytes)
 {
-    size_t b = (count > 0 ? count : 1) * sizeof(T);
-    PNR_HIP_CHECK(hipMalloc((void **)p, b));
-    if (bytes) *bytes += b;
+    if (count < 1) count = 1;
+    if (b.cap >= count) return PNR_OK;
+    if (b.p) {
+        (void)hipFree(b.p);
+        if (bytes) *bytes -= b.cap * sizeof(T);
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    const size_t cap = count + count / 8 + 16;
+    PNR_HIP_CHECK(hipMalloc((void **)&b.p, cap * sizeof(T)));
+    b.cap = cap;
+    if (bytes) *bytes += cap * sizeof(T);
     return PNR_OK;
+}
+
+template <typename T>
+static void release(DevBuf<T> &b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
 }
 
 static void scene_free_grid(pnr_scene *s)
 {
-    if (s->occ_dil) (void)hipFree(s->occ_dil);
-    if (s->rec) (void)hipFree(s->rec);
-    if (s->vox_start) (void)hipFree(s->vox_start);
-    if (s->cand) (void)hipFree(s->cand);
+    release(s->occ_dil_buf);
+    release(s->rec_buf);
+    release(s->vox_start_buf);
+    release(s->cand_buf);
+    release(s->pt_cell[0]);
+    release(s->pt_cell[1]);
+    release(s->occ_all);
+    release(s->occ_pts);
+    release(s->popc);
+    release(s->cnt);
+    release(s->capped);
+    release(s->full_start);
+    release(s->cursor);
+    release(s->full_list);
+    release(s->scan_tmp);
+    release(s->first_valid);
+    release(s->n_inside);
+    release(s->dropped);
     s->occ_dil = nullptr;
     s->rec = nullptr;
     s->vox_start = nullptr;
     s->cand = nullptr;
+    s->scratch_bytes = 0;
     s->built = false;
+}
+
+static bool same_grid(const pnr_grid_params_t &a, const pnr_grid_params_t &b)
+{
+    for (int i = 0; i < 3; ++i)
+        if (a.ranges[i] != b.ranges[i] || a.vox[i] != b.vox[i] || a.dims[i] != b.dims[i]) return false;
+    return true;
+}
+
+// The build proper.  d_old_index == nullptr: every cell is computed (pnr_scene_build).  Otherwise (pnr_scene_update)
+// surviving points reuse their cell code when the grid (origin, voxel size, dims) is unchanged.  All device memory is
+// kept in the scene and reused; the content written is a pure function of (xyz, params): identical to a fresh build.
+static int scene_build_impl(pnr_scene *scene, const float *d_xyz, int64_t N, const pnr_grid_params_t *p,
+                            const int *d_old_index, hipStream_t stream, const char *who)
+{
+    PNR_REQUIRE(scene && d_xyz && p, "%s: null argument", who);
+    PNR_REQUIRE(N > 0 && N < (int64_t)0x7FFFFFFF, "%s: N=%lld out of range", who, (long long)N);
+    PNR_REQUIRE(p->P >= 1 && p->P <= 1024, "%s: P=%d out of range", who, p->P);
+    for (int a = 0; a < 3; ++a) {
+        PNR_REQUIRE(p->dims[a] >= 1, "%s: dims[%d]=%d", who, a, p->dims[a]);
+        PNR_REQUIRE(p->vox[a] > 0.f, "%s: vox[%d]=%g", who, a, p->vox[a]);
+        PNR_REQUIRE(p->kernel_size[a] >= 1 && p->kernel_size[a] <= 9 && p->query_size[a] >= 1 &&
+                        p->query_size[a] <= 9,
+                    "%s: kernel/query size out of range", who);
+    }
+    GridView g{};
+    for (int a = 0; a < 3; ++a) {
+        g.shift[a] = p->ranges[a];
+        g.vox[a] = p->vox[a];
+        g.dims[a] = p->dims[a];
+        g.bdims[a] = (p->dims[a] + 3) / 4;
+        g.kernel_size[a] = p->kernel_size[a];
+    }
+    const int64_t nbricks64 = (int64_t)g.bdims[0] * g.bdims[1] * g.bdims[2];
+    PNR_REQUIRE(nbricks64 < (1ll << 25), "%s: grid of %lld bricks is too large", who, (long long)nbricks64);
+    g.nbricks = (int)nbricks64;
+
+    const bool reuse = d_old_index != nullptr && scene->built && same_grid(scene->params, *p);
+    const int64_t N_old = scene->N;
+    const int prev = scene->cur_cell, cur = reuse ? 1 - prev : prev;
+    scene->built = false;   // until this build completes
+    size_t *sb = &scene->scratch_bytes;
+    int rc = PNR_OK;
+#define TRY(x)                         \
+    do {                               \
+        rc = (x);                      \
+        if (rc != PNR_OK) return rc;   \
+    } while (0)
+    const size_t scan_n = (size_t)std::max<int64_t>(nbricks64, N) + 1;
+    TRY(ensure(scene->pt_cell[cur], (size_t)N, sb));
+    TRY(ensure(scene->occ_all, (size_t)g.nbricks, sb));
+    TRY(ensure(scene->occ_pts, (size_t)g.nbricks, sb));
+    TRY(ensure(scene->occ_dil_buf, (size_t)g.nbricks, sb));
+    TRY(ensure(scene->rec_buf, (size_t)g.nbricks, sb));
+    TRY(ensure(scene->popc, (size_t)g.nbricks + 1, sb));
+    TRY(ensure(scene->first_valid, 1, sb));
+    TRY(ensure(scene->n_inside, 2, sb));
+    TRY(ensure(scene->dropped, 1, sb));
+    TRY(ensure(scene->scan_tmp, scan_temp_bytes((int64_t)scan_n), sb));
+    uint32_t *pt_cell = scene->pt_cell[cur].p;
+    unsigned long long *occ_all = scene->occ_all.p, *occ_pts = scene->occ_pts.p, *occ_dil = scene->occ_dil_buf.p;
+    BrickRec *rec = scene->rec_buf.p;
+    int *popc = scene->popc.p, *first_valid = scene->first_valid.p;
+    unsigned long long *n_inside = scene->n_inside.p;
+    long long *dropped = scene->dropped.p;
+    void *scan_tmp = scene->scan_tmp.p;
+
+    PNR_HIP_CHECK(hipMemsetAsync(occ_all, 0, sizeof(unsigned long long) * g.nbricks, stream));
+    PNR_HIP_CHECK(hipMemsetAsync(occ_dil, 0, sizeof(unsigned long long) * g.nbricks, stream));
+    PNR_HIP_CHECK(hipMemsetAsync(first_valid, 0x7F, sizeof(int), stream));
+    PNR_HIP_CHECK(hipMemsetAsync(n_inside, 0, 2 * sizeof(unsigned long long), stream));
+    hipLaunchKernelGGL(k_point_cells, dim3(nblk(N)), dim3(TPB), 0, stream, d_xyz, N, g, reuse ? d_old_index : nullptr,
+                       reuse ? scene->pt_cell[prev].p : nullptr, N_old, pt_cell, occ_all, first_valid, n_inside,
+                       n_inside + 1);
+    PNR_HIP_CHECK(hipMemcpyAsync(occ_pts, occ_all, sizeof(unsigned long long) * g.nbricks, hipMemcpyDeviceToDevice,
+                                 stream));
+    hipLaunchKernelGGL(k_drop_voxel0, dim3(1), dim3(64), 0, stream, pt_cell, first_valid, N, p->compat_drop_voxel0,
+                       occ_pts, dropped);
+    hipLaunchKernelGGL(k_dilate, dim3(nblk(g.nbricks)), dim3(TPB), 0, stream, occ_all, g, p->query_size[0],
+                       p->query_size[1], p->query_size[2], occ_dil);
+    hipLaunchKernelGGL(k_brick_popc, dim3(nblk(g.nbricks)), dim3(TPB), 0, stream, occ_pts, g.nbricks, popc);
+    TRY(scan_exclusive_i32(popc, popc, g.nbricks, nullptr, nullptr, scan_tmp, stream));
+    hipLaunchKernelGGL(k_make_recs, dim3(nblk(g.nbricks)), dim3(TPB), 0, stream, occ_pts, popc, g.nbricks, rec);
+    int h_nvox = 0;
+    long long h_dropped = -1;
+    unsigned long long h_inside[2] = {0, 0};
+    PNR_HIP_CHECK(hipMemcpyAsync(&h_nvox, popc + g.nbricks, sizeof(int), hipMemcpyDeviceToHost, stream));
+    PNR_HIP_CHECK(hipMemcpyAsync(&h_dropped, dropped, sizeof(long long), hipMemcpyDeviceToHost, stream));
+    PNR_HIP_CHECK(hipMemcpyAsync(h_inside, n_inside, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    PNR_HIP_CHECK(hipStreamSynchronize(stream));
+    const int64_t nvox64 = h_nvox;
+    g.nvox = (int)nvox64;
+
+    TRY(ensure(scene->cnt, (size_t)nvox64 + 1, sb));
+    TRY(ensure(scene->capped, (size_t)nvox64 + 1, sb));
+    TRY(ensure(scene->full_start, (size_t)nvox64 + 1, sb));
+    TRY(ensure(scene->cursor, (size_t)nvox64 + 1, sb));
+    TRY(ensure(scene->vox_start_buf, (size_t)nvox64 + 1, sb));
+    int *cnt = scene->cnt.p, *capped = scene->capped.p, *full_start = scene->full_start.p, *cursor = scene->cursor.p,
+        *vox_start = scene->vox_start_buf.p;
+    PNR_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int) * (nvox64 + 1), stream));
+    PNR_HIP_CHECK(hipMemsetAsync(cursor, 0, sizeof(int) * (nvox64 + 1), stream));
+    PNR_HIP_CHECK(hipMemsetAsync(capped, 0, sizeof(int) * (nvox64 + 1), stream));
+    hipLaunchKernelGGL(k_count_points, dim3(nblk(N)), dim3(TPB), 0, stream, pt_cell, N, rec, cnt);
+    if (nvox64 > 0)
+        hipLaunchKernelGGL(k_cap_counts, dim3(nblk(nvox64)), dim3(TPB), 0, stream, cnt, (int)nvox64, p->P, capped);
+    TRY(scan_exclusive_i32(cnt, full_start, nvox64, nullptr, nullptr, scan_tmp, stream));
+    TRY(scan_exclusive_i32(capped, vox_start, nvox64, nullptr, nullptr, scan_tmp, stream));
+    int h_full = 0, h_cap = 0;
+    PNR_HIP_CHECK(hipMemcpyAsync(&h_full, full_start + nvox64, sizeof(int), hipMemcpyDeviceToHost, stream));
+    PNR_HIP_CHECK(hipMemcpyAsync(&h_cap, vox_start + nvox64, sizeof(int), hipMemcpyDeviceToHost, stream));
+    PNR_HIP_CHECK(hipStreamSynchronize(stream));
+    const int64_t total_full = h_full, total_capped = h_cap;
+    TRY(ensure(scene->full_list, (size_t)total_full, sb));
+    TRY(ensure(scene->cand_buf, (size_t)total_capped, sb));
+    hipLaunchKernelGGL(k_fill_lists, dim3(nblk(N)), dim3(TPB), 0, stream, pt_cell, N, rec, full_start, cursor,
+                       scene->full_list.p);
+    if (nvox64 > 0)
+        hipLaunchKernelGGL(k_select_first_p, dim3(nblk(nvox64)), dim3(TPB), 0, stream, full_start, scene->full_list.p,
+                           vox_start, (int)nvox64, d_xyz, scene->cand_buf.p);
+    PNR_HIP_CHECK(hipGetLastError());
+    PNR_HIP_CHECK(hipStreamSynchronize(stream));
+#undef TRY
+
+    scene->params = *p;
+    scene->N = N;
+    scene->cur_cell = cur;
+    scene->occ_dil = occ_dil;
+    scene->rec = rec;
+    scene->vox_start = vox_start;
+    scene->cand = scene->cand_buf.p;
+    g.occ_dil = scene->occ_dil;
+    g.rec = scene->rec;
+    g.vox_start = scene->vox_start;
+    g.cand = scene->cand;
+    scene->grid = g;
+    scene->built = true;
+    // what the render path reads: dilated occupancy, brick records, list bounds, candidates (+ the packed rows)
+    scene->bytes = (size_t)g.nbricks * (sizeof(unsigned long long) + sizeof(BrickRec)) +
+                   (size_t)(nvox64 + 1) * sizeof(int) + (size_t)total_capped * sizeof(float4) +
+                   (scene->point_rows ? (size_t)scene->packed_N * PNR_POINT_ROW_FLOATS * sizeof(float) : 0);
+    // occupied voxels of the reference include the compat-dropped one
+    scene->info[0] = nvox64 + (h_dropped >= 0 ? 1 : 0);
+    scene->info[1] = scene->info[0] > p->max_o;
+    scene->info[2] = total_capped;
+    scene->info[3] = g.nbricks;
+    scene->info[4] = (int64_t)scene->bytes;
+    scene->info[5] = N;
+    scene->info[6] = (int64_t)h_inside[0];
+    scene->info[7] = h_dropped;
+    if (d_old_index) {
+        ++scene->updates;
+        scene->cells_reused = reuse ? (int64_t)h_inside[1] : 0;
+    } else {
+        ++scene->builds;
+        scene->cells_reused = 0;
+    }
+    return PNR_OK;
 }
 
 }  // namespace pnr
@@ -245,164 +448,31 @@ extern "C" int pnr_scene_destroy(pnr_scene_t *scene)
 extern "C" int pnr_scene_build(pnr_scene_t *scene, const float *d_xyz, int64_t N, const pnr_grid_params_t *p,
                                void *stream_)
 {
-    hipStream_t stream = (hipStream_t)stream_;
-    PNR_REQUIRE(scene && d_xyz && p, "pnr_scene_build: null argument");
-    PNR_REQUIRE(N > 0 && N < (int64_t)0x7FFFFFFF, "pnr_scene_build: N=%lld out of range", (long long)N);
-    PNR_REQUIRE(p->P >= 1 && p->P <= 1024, "pnr_scene_build: P=%d out of range", p->P);
-    for (int a = 0; a < 3; ++a) {
-        PNR_REQUIRE(p->dims[a] >= 1, "pnr_scene_build: dims[%d]=%d", a, p->dims[a]);
-        PNR_REQUIRE(p->vox[a] > 0.f, "pnr_scene_build: vox[%d]=%g", a, p->vox[a]);
-        PNR_REQUIRE(p->kernel_size[a] >= 1 && p->kernel_size[a] <= 9 && p->query_size[a] >= 1 &&
-                        p->query_size[a] <= 9,
-                    "pnr_scene_build: kernel/query size out of range");
+    return scene_build_impl(scene, d_xyz, N, p, nullptr, (hipStream_t)stream_, "pnr_scene_build");
+}
+
+extern "C" int pnr_scene_update(pnr_scene_t *scene, const float *d_xyz, int64_t N, const pnr_grid_params_t *p,
+                                const int32_t *d_old_index, void *stream_)
+{
+    PNR_REQUIRE(scene != nullptr, "pnr_scene_update: null argument");
+    if (!scene->built) {
+        set_error("pnr_scene_update: scene not built (call pnr_scene_build first)");
+        return PNR_ERR_STATE;
     }
-    scene_free_grid(scene);
-    scene->params = *p;
-    scene->N = N;
-    scene->bytes = scene->point_rows ? (size_t)scene->packed_N * PNR_POINT_ROW_FLOATS * sizeof(float) : 0;
-
-    GridView g{};
-    for (int a = 0; a < 3; ++a) {
-        g.shift[a] = p->ranges[a];
-        g.vox[a] = p->vox[a];
-        g.dims[a] = p->dims[a];
-        g.bdims[a] = (p->dims[a] + 3) / 4;
-        g.kernel_size[a] = p->kernel_size[a];
-    }
-    int64_t nbricks64 = (int64_t)g.bdims[0] * g.bdims[1] * g.bdims[2];
-    PNR_REQUIRE(nbricks64 < (1ll << 25), "pnr_scene_build: grid of %lld bricks is too large", (long long)nbricks64);
-    g.nbricks = (int)nbricks64;
-
-    // temporaries
-    uint32_t *pt_cell = nullptr;
-    unsigned long long *occ_all = nullptr, *occ_pts = nullptr, *n_inside = nullptr;
-    int *first_valid = nullptr, *popc = nullptr, *cnt = nullptr, *capped = nullptr, *full_start = nullptr,
-        *cursor = nullptr, *full_list = nullptr;
-    long long *dropped = nullptr;
-    void *scan_tmp = nullptr;
-    int rc = PNR_OK;
-#define TRY(x)                  \
-    do {                        \
-        rc = (x);               \
-        if (rc != PNR_OK) goto done; \
-    } while (0)
-#define TRYHIP(x)                                                                                   \
-    do {                                                                                            \
-        hipError_t _e = (x);                                                                        \
-        if (_e != hipSuccess) {                                                                     \
-            set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #x, hipGetErrorString(_e));        \
-            rc = PNR_ERR_HIP;                                                                       \
-            goto done;                                                                              \
-        }                                                                                           \
-    } while (0)
-    {
-        int64_t nvox64 = 0, total_capped = 0, total_full = 0;
-        long long h_dropped = -1;
-        unsigned long long h_inside = 0;
-        size_t scan_n = (size_t)std::max<int64_t>(nbricks64, N) + 1;
-
-        TRY(dev_alloc(&pt_cell, (size_t)N, nullptr));
-        TRY(dev_alloc(&occ_all, (size_t)g.nbricks, nullptr));
-        TRY(dev_alloc(&occ_pts, (size_t)g.nbricks, nullptr));
-        TRY(dev_alloc(&scene->occ_dil, (size_t)g.nbricks, &scene->bytes));
-        TRY(dev_alloc(&scene->rec, (size_t)g.nbricks, &scene->bytes));
-        TRY(dev_alloc(&first_valid, 1, nullptr));
-        TRY(dev_alloc(&n_inside, 1, nullptr));
-        TRY(dev_alloc(&dropped, 1, nullptr));
-        TRY(dev_alloc(&popc, (size_t)g.nbricks + 1, nullptr));
-        TRYHIP(hipMalloc(&scan_tmp, scan_temp_bytes((int64_t)scan_n)));
-        TRYHIP(hipMemsetAsync(occ_all, 0, sizeof(unsigned long long) * g.nbricks, stream));
-        TRYHIP(hipMemsetAsync(scene->occ_dil, 0, sizeof(unsigned long long) * g.nbricks, stream));
-        TRYHIP(hipMemsetAsync(first_valid, 0x7F, sizeof(int), stream));
-        TRYHIP(hipMemsetAsync(n_inside, 0, sizeof(unsigned long long), stream));
-
-        hipLaunchKernelGGL(k_point_cells, dim3(nblk(N)), dim3(TPB), 0, stream, d_xyz, N, g, pt_cell, occ_all,
-                           first_valid, n_inside);
-        TRYHIP(hipMemcpyAsync(occ_pts, occ_all, sizeof(unsigned long long) * g.nbricks, hipMemcpyDeviceToDevice,
-                              stream));
-        hipLaunchKernelGGL(k_drop_voxel0, dim3(1), dim3(64), 0, stream, pt_cell, first_valid, N,
-                           p->compat_drop_voxel0, occ_pts, dropped);
-        hipLaunchKernelGGL(k_dilate, dim3(nblk(g.nbricks)), dim3(TPB), 0, stream, occ_all, g, p->query_size[0],
-                           p->query_size[1], p->query_size[2], scene->occ_dil);
-        hipLaunchKernelGGL(k_brick_popc, dim3(nblk(g.nbricks)), dim3(TPB), 0, stream, occ_pts, g.nbricks, popc);
-        TRY(scan_exclusive_i32(popc, popc, g.nbricks, nullptr, nullptr, scan_tmp, stream));
-        hipLaunchKernelGGL(k_make_recs, dim3(nblk(g.nbricks)), dim3(TPB), 0, stream, occ_pts, popc, g.nbricks,
-                           scene->rec);
-        {
-            int h_nvox = 0;
-            TRYHIP(hipMemcpyAsync(&h_nvox, popc + g.nbricks, sizeof(int), hipMemcpyDeviceToHost, stream));
-            TRYHIP(hipMemcpyAsync(&h_dropped, dropped, sizeof(long long), hipMemcpyDeviceToHost, stream));
-            TRYHIP(hipMemcpyAsync(&h_inside, n_inside, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-            TRYHIP(hipStreamSynchronize(stream));
-            nvox64 = h_nvox;
-        }
-        g.nvox = (int)nvox64;
-
-        TRY(dev_alloc(&cnt, (size_t)nvox64 + 1, nullptr));
-        TRY(dev_alloc(&capped, (size_t)nvox64 + 1, nullptr));
-        TRY(dev_alloc(&full_start, (size_t)nvox64 + 1, nullptr));
-        TRY(dev_alloc(&cursor, (size_t)nvox64 + 1, nullptr));
-        TRY(dev_alloc(&scene->vox_start, (size_t)nvox64 + 1, &scene->bytes));
-        TRYHIP(hipMemsetAsync(cnt, 0, sizeof(int) * (nvox64 + 1), stream));
-        TRYHIP(hipMemsetAsync(cursor, 0, sizeof(int) * (nvox64 + 1), stream));
-        hipLaunchKernelGGL(k_count_points, dim3(nblk(N)), dim3(TPB), 0, stream, pt_cell, N, scene->rec, cnt);
-        if (nvox64 > 0)
-            hipLaunchKernelGGL(k_cap_counts, dim3(nblk(nvox64)), dim3(TPB), 0, stream, cnt, (int)nvox64, p->P,
-                               capped);
-        TRY(scan_exclusive_i32(cnt, full_start, nvox64, nullptr, nullptr, scan_tmp, stream));
-        TRY(scan_exclusive_i32(capped, scene->vox_start, nvox64, nullptr, nullptr, scan_tmp, stream));
-        {
-            int h_full = 0, h_cap = 0;
-            TRYHIP(hipMemcpyAsync(&h_full, full_start + nvox64, sizeof(int), hipMemcpyDeviceToHost, stream));
-            TRYHIP(hipMemcpyAsync(&h_cap, scene->vox_start + nvox64, sizeof(int), hipMemcpyDeviceToHost, stream));
-            TRYHIP(hipStreamSynchronize(stream));
-            total_full = h_full;
-            total_capped = h_cap;
-        }
-        TRY(dev_alloc(&full_list, (size_t)total_full, nullptr));
-        TRY(dev_alloc(&scene->cand, (size_t)total_capped, &scene->bytes));
-        hipLaunchKernelGGL(k_fill_lists, dim3(nblk(N)), dim3(TPB), 0, stream, pt_cell, N, scene->rec, full_start,
-                           cursor, full_list);
-        if (nvox64 > 0)
-            hipLaunchKernelGGL(k_select_first_p, dim3(nblk(nvox64)), dim3(TPB), 0, stream, full_start, full_list,
-                               scene->vox_start, (int)nvox64, d_xyz, scene->cand);
-        TRYHIP(hipGetLastError());
-        TRYHIP(hipStreamSynchronize(stream));
-
-        g.occ_dil = scene->occ_dil;
-        g.rec = scene->rec;
-        g.vox_start = scene->vox_start;
-        g.cand = scene->cand;
-        scene->grid = g;
-        scene->built = true;
-        // occupied voxels of the reference include the compat-dropped one
-        scene->info[0] = nvox64 + (h_dropped >= 0 ? 1 : 0);
-        scene->info[1] = scene->info[0] > p->max_o;
-        scene->info[2] = total_capped;
-        scene->info[3] = g.nbricks;
-        scene->info[4] = (int64_t)scene->bytes;
-        scene->info[5] = N;
-        scene->info[6] = (int64_t)h_inside;
-        scene->info[7] = h_dropped;
-    }
-done:
-#undef TRY
-#undef TRYHIP
-    (void)hipFree(pt_cell);
-    (void)hipFree(occ_all);
-    (void)hipFree(occ_pts);
-    (void)hipFree(first_valid);
-    (void)hipFree(n_inside);
-    (void)hipFree(dropped);
-    (void)hipFree(popc);
-    (void)hipFree(cnt);
-    (void)hipFree(capped);
-    (void)hipFree(full_start);
-    (void)hipFree(cursor);
-    (void)hipFree(full_list);
-    (void)hipFree(scan_tmp);
-    if (rc != PNR_OK) scene_free_grid(scene);
+    PNR_REQUIRE(d_old_index != nullptr, "pnr_scene_update: d_old_index is null (use pnr_scene_build for a new cloud)");
+    const int rc = scene_build_impl(scene, d_xyz, N, p, d_old_index, (hipStream_t)stream_, "pnr_scene_update");
+    if (rc == PNR_OK) scene->packed = false;   // the packed rows describe the previous cloud
     return rc;
+}
+
+extern "C" int pnr_scene_update_info(const pnr_scene_t *scene, int64_t info[4])
+{
+    PNR_REQUIRE(scene && info, "pnr_scene_update_info: null argument");
+    info[0] = scene->builds;
+    info[1] = scene->updates;
+    info[2] = scene->cells_reused;
+    info[3] = (int64_t)scene->scratch_bytes;
+    return PNR_OK;
 }
 
 extern "C" int pnr_scene_info(const pnr_scene_t *scene, int64_t info[8])

@@ -167,6 +167,29 @@ __device__ __forceinline__ void fast_sincos(float x, float &sn, float &cs)
     cs = ((q + 1) & 2) ? -cc : cc;
 }
 
+// The same without any fallback (no branch, nothing if-converted): three-constant Cody-Waite reduction, exact for
+// |k| < 2^15 (|x| < ~5e4); beyond that the result degrades gracefully (it stays in [-1, 1]) where fp32 arguments no
+// longer resolve the period anyway.  Used by the fp32 pair kernel, whose arguments are voxel-sized distances times
+// 2^0..2^4.
+__device__ __forceinline__ void fast_sincos_nb(float x, float &sn, float &cs)
+{
+    const float k = rintf(x * 0.636619772367581343f);           // x * 2/pi
+    float r = fmaf(-k, 1.5703125f, x);                          // pi/2 = 1.5703125 + 4.837512969970703125e-4 + 7.54978995489188216e-8
+    r = fmaf(-k, 4.837512969970703125e-4f, r);
+    r = fmaf(-k, 7.54978995489188216e-8f, r);
+    const float z = r * r;
+    float ps = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = fmaf(z, ps, -1.6666654611e-1f);
+    const float s0 = fmaf(r * z, ps, r);
+    float pc = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = fmaf(z, pc, 4.166664568298827e-2f);
+    const float c0 = fmaf(z * z, pc, fmaf(z, -0.5f, 1.0f));
+    const int q = (int)k;
+    const float ss = (q & 1) ? c0 : s0, cc = (q & 1) ? s0 : c0;
+    sn = (q & 2) ? -ss : ss;
+    cs = ((q + 1) & 2) ? -cc : cc;
+}
+
 // v + (v of the lane DPP control CTRL selects): 0xB1 / 0x4E = quad_perm xor 1 / xor 2, 0x141 = row_half_mirror,
 // 0x140 = row_mirror
 template <int CTRL>
@@ -366,8 +389,11 @@ __device__ __forceinline__ void point_inputs(const float (&e)[16], float *x0)
     }
 }
 
-// the lane's pair inputs: weight, encoded distances (xq[0:32] = x0[112:144]) and the extra head inputs
-template <int SEG, bool FAST_PE>
+// the lane's pair inputs: weight, encoded distances (xq[0:32] = x0[112:144]) and the extra head inputs.
+// FAST_PE: the branch-free Cody-Waite sincos (1e-7 absolute) instead of libm's; with DOUBLE_ANGLE the octaves above the
+// first follow by the double-angle identities (the bf16x3 mode: their error stays below that mode's 2^-16 products),
+// without it every octave is evaluated from its own argument x * 2^f (exact scaling).
+template <int SEG, bool FAST_PE, bool DOUBLE_ANGLE = true>
 __device__ __forceinline__ void pair_inputs(const ShadeParams &P, const RowFetch &f, const Camera &cam, int lane,
                                             float *xq, RowCtx &ctx)
 {
@@ -409,10 +435,12 @@ __device__ __forceinline__ void pair_inputs(const ShadeParams &P, const RowFetch
             if (PNR_ABLATE & 1) {
                 sn = dd[d] * (float)(1 << f);
                 cs = 1.0f - sn;
-            } else if (FAST_PE && f > 0) {
+            } else if (FAST_PE && DOUBLE_ANGLE && f > 0) {
                 const float s2 = 2.0f * sn * cs, c2 = (cs - sn) * (cs + sn);
                 sn = s2;
                 cs = c2;
+            } else if (FAST_PE && !DOUBLE_ANGLE) {
+                fast_sincos_nb(dd[d] * (float)(1 << f), sn, cs);
             } else if (FAST_PE) {
                 fast_sincos(dd[d], sn, cs);
             } else {

@@ -57,36 +57,142 @@ __device__ __forceinline__ void dense_layer(__amdgpu_buffer_rsrc_t rsrc, int wba
         for (int r = 0; r < 16; ++r) out[m * 16 + r] = acc[m][r];
 }
 
+// ================================================================================================
+// The pair kernel as ONE stream of weight groups.
+//
+// k_shade_pairs above runs its four layers as four separate loops: every layer start refills the weight pipeline
+// (first load -> first MFMA: an L2 round trip with the matrix pipe idle), loads its 32 bias float4 and waits for them,
+// and every layer end reads 128 accumulators back, applies LeakyReLU and only then starts the next layer -- 430
+// instructions with no MFMA in flight, three times per tile, plus 1800 instructions of epilogue (density head,
+// K-aggregation, stores) and a prologue whose fifteen libm sincosf calls cost 2200 instructions (their Payne-Hanek
+// argument reduction is computed unconditionally).
+//
+// Here the 840 weight groups of a tile (64 + 256 + 264 + 256 groups of 4 k-steps) form one sequence with a rolling
+// window of PFS loads in flight that never drains -- not at a layer boundary and not at a tile boundary (the window of
+// the next tile's first groups fills during this tile's last groups).  Everything that is not an MFMA is cut in
+// pieces of a few VALU instructions and placed BEHIND individual MFMAs, where an in-order wave can issue them while
+// the matrix pipe works (a 32x32x2 fp32 MFMA holds the pipe for 64 cycles):
+//   * the activation of output tile m (16 x read accumulator, LeakyReLU, write the next layer's operand) runs in the
+//     shadow of tile m + 1's first 16 MFMAs -- of the NEXT layer's tile 0 for the last tile (its values are that
+//     layer's k-steps 112..127, 448 MFMAs away);
+//   * the accumulator initial values (bias, 16 per lane and output tile) are loaded one output tile ahead;
+//   * the last layer's outputs never form an array: each finished value goes through LeakyReLU, the density-head
+//     product, the neighbour weight and the three DPP steps of the K-sum in MFMA shadows of the following output
+//     tile (three pieces per value, behind three different MFMAs), every fourth one stores its float4 of the
+//     aggregated feature; what is left behind the last MFMA of a tile is the sink of its last 16 values;
+//   * positional encodings use the branch-free Cody-Waite sincos (1e-7 absolute), each octave from its own argument.
+constexpr int PFS = 8;                  // weight groups (1 KiB per wave each) in flight; divides NG_TILE
+constexpr int NG_L1 = 8 * (32 / 4), NG_L2 = 8 * (128 / 4), NG_L3 = 8 * (132 / 4), NG_L4 = 8 * (128 / 4);
+constexpr int NG_TILE = NG_L1 + NG_L2 + NG_L3 + NG_L4;   // 840
+static_assert(NG_TILE % PFS == 0, "the window slot of a group must not depend on the tile");
+
+struct WBase {
+    int l1, l2, l3, l4;   // byte offsets of the four layers' packed weights
+};
+
+// byte offset of weight group G of the tile stream (G >= NG_TILE: the next tile, same weights)
+__device__ __forceinline__ int group_off(const WBase &wb, int G)
+{
+    G = G >= NG_TILE ? G - NG_TILE : G;
+    if (G < NG_L1) return wb.l1 + G * 1024;
+    if (G < NG_L1 + NG_L2) return wb.l2 + (G - NG_L1) * 1024;
+    if (G < NG_L1 + NG_L2 + NG_L3) return wb.l3 + (G - NG_L1 - NG_L2) * 1024;
+    return wb.l4 + (G - NG_L1 - NG_L2 - NG_L3) * 1024;
+}
+
+struct Ini {
+    float4 v[4];   // accumulator initial values 4q .. 4q+3 (q = 0..3) of one output tile
+};
+
+__device__ __forceinline__ f32x16 acc_from(const Ini &b)
+{
+    f32x16 a;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        a[4 * q + 0] = b.v[q].x;
+        a[4 * q + 1] = b.v[q].y;
+        a[4 * q + 2] = b.v[q].z;
+        a[4 * q + 3] = b.v[q].w;
+    }
+    return a;
+}
+
+// bias of output tile m for this lane half: values 4q..4q+3 = bias[32m + 8q + 4h + 0..3]
+__device__ __forceinline__ Ini bias_ini(const float *__restrict__ bias, int m, int h)
+{
+    Ini b;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b.v[q] = *reinterpret_cast<const float4 *>(bias + 32 * m + 8 * q + 4 * h);
+    return b;
+}
+
+// One layer of the stream.  G0: index of its first weight group in the tile stream.  `in`: the lane's B operands.
+// acc[0] must hold the initial values of output tile 0 on entry -- tile m + 1's are fetched by `next_ini(m + 1)`
+// during tile m; `fill(m, i)` runs behind MFMA i (0 .. 4 KG - 1) of output tile m.
+template <int KSP, int MT, int G0, typename NextIni, typename Fill>
+__device__ __forceinline__ void layer_stream(__amdgpu_buffer_rsrc_t rsrc, int voff, const WBase &wb, float4 (&wq)[PFS],
+                                             const float (&in)[KSP], f32x16 (&acc)[MT], NextIni next_ini, Fill fill)
+{
+    static_assert(KSP % 4 == 0, "k-steps are packed in groups of 4");
+    constexpr int KG = KSP / 4;
+    Ini nx;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        if (m > 0) acc[m] = acc_from(nx);
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+            const int G = G0 + m * KG + kg;
+            const float4 w = wq[G % PFS];
+            wq[G % PFS] = load_w(rsrc, voff, group_off(wb, G + PFS));
+            if (kg == 0 && m + 1 < MT) nx = next_ini(m + 1);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, in[4 * kg + 0], acc[m], 0, 0, 0);
+            fill(m, 4 * kg + 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, in[4 * kg + 1], acc[m], 0, 0, 0);
+            fill(m, 4 * kg + 1);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, in[4 * kg + 2], acc[m], 0, 0, 0);
+            fill(m, 4 * kg + 2);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, in[4 * kg + 3], acc[m], 0, 0, 0);
+            fill(m, 4 * kg + 3);
+            // one scheduling region per group: the compiler interleaves the group's pieces with its four MFMAs (a
+            // barrier behind every MFMA measured 3 % slower, none at all lets it hoist the loads of a whole layer)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 template <int SEG>
 __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
 {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    const int h = lane >> 5;
     const int SPT = (32 / seg_len<SEG>(P.K)) * WAVES;  // samples per workgroup tile
     const int V0 = P.n_sel[P.i_v0], S_valid = P.n_sel[P.i_v1];
     const int ntiles = (S_valid - V0 + SPT - 1) / SPT;
-    // XCD-aware tile order (see k_shade_pairs_bf16): 32 consecutive tiles per XCD and round, so that the pt_table rows
-    // neighbouring rays share are fetched into that XCD's L2 once (12.7 GB beyond L2 per launch with one contiguous
-    // tile range per workgroup)
+    // XCD-aware tile order (see k_shade_pairs_bf16)
     const int G = gridDim.x;
     const int t_begin = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
-    const int t_end = ntiles;
 
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wbuf), 0, (int)P.wbytes, 0x00020000);
-    const int w0_ = (int)(P.w32b_off * 4), w1_ = (int)(P.w_off[1] * 4), w2_ = (int)(P.w_off[2] * 4),
-              w3_ = (int)(P.w_off[3] * 4);
-    const float *b0 = P.wbuf + P.b_off[0], *b1 = P.wbuf + P.b_off[1], *b2 = P.wbuf + P.b_off[2],
-                *b3 = P.wbuf + P.b_off[3];
+    const int voff = lane * 16;
+    const WBase wb_ = {(int)(P.w32b_off * 4), (int)(P.w_off[1] * 4), (int)(P.w_off[2] * 4), (int)(P.w_off[3] * 4)};
+    const float *b1 = P.wbuf + P.b_off[1], *b2 = P.wbuf + P.b_off[2], *b3 = P.wbuf + P.b_off[3];
+    const float *w4t = P.wbuf + P.w4acc_off;   // density head in accumulator order: [(tile * 2 + h) * 16 + r]
+    const float b4 = P.wbuf[P.b_off[4]];
+    const int K = P.K;
 
-    for (int tile = t_begin; tile < t_end; tile += G) {
-        // opaque per iteration: otherwise the ~1000 scalar load offsets are hoisted out of this loop and
-        // spilled to VGPR lanes
-        int w0 = w0_, w1 = w1_, w2 = w2_, w3 = w3_;
-        asm volatile("" : "+s"(w0), "+s"(w1), "+s"(w2), "+s"(w3));
-        // mlp_base layer 0 is factorised as in the bf16x3 mode: the 224 point-only inputs were contracted once per
-        // distinct neighbour point by k_point_part_f32 (pt_table row, accumulator order); here the row starts the
-        // accumulators and only the 60 encoded distances (k-steps 112..143 of the lane's inputs) are multiplied
+    // the weight window of the first tile
+    float4 wq[PFS];
+    if (t_begin < ntiles) {
+#pragma unroll
+        for (int p = 0; p < PFS; ++p) wq[p] = load_w(rsrc, voff, group_off(wb_, p));
+    }
+
+    for (int tile = t_begin; tile < ntiles; tile += G) {
+        // opaque per iteration: otherwise the scalar load offsets are hoisted out of this loop and spilled
+        WBase wb = wb_;
+        asm volatile("" : "+s"(wb.l1), "+s"(wb.l2), "+s"(wb.l3), "+s"(wb.l4));
         float xq[32];
         RowCtx ctx;
         const float4 *trow;
@@ -95,31 +201,112 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
             fetch_a<SEG>(P, tile, lane, wave, V0, S_valid, f);
             fetch_b<SEG>(P, f);
             fetch_c_pair(P, f);
-            trow = P.pt_table + (int64_t)f.urow * 64 + 4 * (lane >> 5);
+            trow = P.pt_table + (int64_t)f.urow * 64 + 4 * h;
             const Camera cam = load_cam_lanes(P.cr, f.cid);
-            pair_inputs<SEG, false>(P, f, cam, lane, xq, ctx);
+            pair_inputs<SEG, true, false>(P, f, cam, lane, xq, ctx);
         }
-        float hA[128];
-        dense_layer<32, 8>(rsrc, w0, b0, lane, xq, hA, trow);
-#pragma unroll
-        for (int i = 0; i < 128; ++i) hA[i] = leaky(hA[i]);
-        float hB[132];
+        f32x16 acc[8];
+        float X[128], Y[132];
+        // ---- layer 1: the 60 encoded distances on top of the point's pt_table row ------------------------------
         {
-            float tmp[128];
-            dense_layer<128, 8>(rsrc, w1, b1, lane, hA, tmp);
+            Ini r0;
 #pragma unroll
-            for (int i = 0; i < 128; ++i) hB[i] = leaky(tmp[i]);
+            for (int q = 0; q < 4; ++q) r0.v[q] = trow[q];
+            acc[0] = acc_from(r0);
         }
+        layer_stream<32, 8, 0>(
+            rsrc, voff, wb, wq, xq, acc,
+            [&](int m) {
+                Ini r;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) hB[128 + i] = ctx.ex[i];
-        dense_layer<132, 8>(rsrc, w2, b2, lane, hB, hA);
+                for (int q = 0; q < 4; ++q) r.v[q] = trow[8 * m + q];
+                return r;
+            },
+            [&](int m, int i) {
+                if (m > 0 && i < 16) X[16 * (m - 1) + i] = leaky(acc[m - 1][i]);
+            });
+        // ---- layer 2 ---------------------------------------------------------------------------------------------
+        {
+            const f32x16 last = acc[7];
+            acc[0] = acc_from(bias_ini(b1, 0, h));
+            layer_stream<128, 8, NG_L1>(
+                rsrc, voff, wb, wq, X, acc, [&](int m) { return bias_ini(b1, m, h); },
+                [&](int m, int i) {
+                    if (m == 0 && i < 16) X[112 + i] = leaky(last[i]);
+                    if (m > 0 && i < 16) Y[16 * (m - 1) + i] = leaky(acc[m - 1][i]);
+                });
+        }
+        // ---- layer 3: + the seven extra head inputs --------------------------------------------------------------
+        {
+            const f32x16 last = acc[7];
 #pragma unroll
-        for (int i = 0; i < 128; ++i) hA[i] = leaky(hA[i]);
-        float hC[128];
-        dense_layer<128, 8>(rsrc, w3, b3, lane, hA, hC);
+            for (int i = 0; i < 4; ++i) Y[128 + i] = ctx.ex[i];
+            acc[0] = acc_from(bias_ini(b2, 0, h));
+            layer_stream<132, 8, NG_L1 + NG_L2>(
+                rsrc, voff, wb, wq, Y, acc, [&](int m) { return bias_ini(b2, m, h); },
+                [&](int m, int i) {
+                    if (m == 0 && i < 16) Y[112 + i] = leaky(last[i]);
+                    if (m > 0 && i < 16) X[16 * (m - 1) + i] = leaky(acc[m - 1][i]);
+                });
+        }
+        // ---- layer 4 + density head + K-aggregation in its shadows ----------------------------------------------
+        float part = 0.f;   // this lane's share of <head, w4>
+        const bool writer = ctx.row_ok && ctx.slot == 0;
+        float *dst = P.agg + (int64_t)ctx.v_idx * 256;
+        float4 hw[4], hw_nx[4];   // density-head weights of the output tile being sunk / of the next one
+        float o4[4], sv = 0.f;
+        // value r of output tile t in three pieces, each small enough for one MFMA shadow: (a) LeakyReLU, density
+        // product, neighbour weight; (b) the K-sum's DPP steps; (c) every fourth value: the float4 store
+        auto sink_a = [&](int r, float a) {
+            const float v = leaky(a);
+            const float4 w = hw[r >> 2];
+            part += v * ((r & 3) == 0 ? w.x : (r & 3) == 1 ? w.y : (r & 3) == 2 ? w.z : w.w);
+            sv = v * ctx.wgt;
+        };
+        auto sink_b = [&](int r) { o4[r & 3] = seg_sum<SEG>(sv, K, lane); };
+        auto sink_c = [&](int t, int r) {
+            if ((r & 3) == 3 && writer)
+                *reinterpret_cast<float4 *>(dst + 32 * t + 8 * (r >> 2) + 4 * h) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+        };
+        {
+            const f32x16 last = acc[7];
+            acc[0] = acc_from(bias_ini(b3, 0, h));
 #pragma unroll
-        for (int i = 0; i < 128; ++i) hC[i] = leaky(hC[i]);
-        finish_rows<SEG, false>(P, lane, hC, ctx);
+            for (int q = 0; q < 4; ++q) hw_nx[q] = *reinterpret_cast<const float4 *>(w4t + (0 * 2 + h) * 16 + 4 * q);
+            layer_stream<128, 8, NG_L1 + NG_L2 + NG_L3>(
+                rsrc, voff, wb, wq, X, acc, [&](int m) { return bias_ini(b3, m, h); },
+                [&](int m, int i) {
+                    if (m == 0 && i < 16) X[112 + i] = leaky(last[i]);
+                    if (m > 0 && i == 0) {
+                        // the head weights of tile m - 1 become current, those of tile m are fetched
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) hw[q] = hw_nx[q];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            hw_nx[q] = *reinterpret_cast<const float4 *>(w4t + (m * 2 + h) * 16 + 4 * q);
+                    }
+                    // value r of output tile m - 1 behind MFMAs 8r + 2 / + 4 / + 6 of tile m (16 values, 128 MFMAs)
+                    if (m > 0 && (i & 7) == 2) sink_a(i >> 3, acc[m - 1][i >> 3]);
+                    if (m > 0 && (i & 7) == 4) sink_b(i >> 3);
+                    if (m > 0 && (i & 7) == 6) sink_c(m - 1, i >> 3);
+                });
+        }
+        // behind the tile's last MFMA: the sink of output tile 7
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hw[q] = hw_nx[q];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sink_a(r, acc[7][r]);
+            sink_b(r);
+            sink_c(7, r);
+        }
+        part += __shfl_xor(part, 32, 64);
+        const float alpha = fmaxf(part + b4, 0.f);
+        const float sigma = seg_sum<SEG>(alpha * ctx.wgt, K, lane);
+        if (writer && h == 0) {
+            P.smp_sigma[ctx.v_idx] = sigma;
+            if (P.smp_sig_s) P.smp_sig_s[ctx.s] = sigma;
+        }
     }
 }
 
@@ -243,3 +430,4 @@ void launch_color_fp32(dim3 grid, hipStream_t stream, const ShadeParams &P)
 }
 
 }  // namespace pnr
+

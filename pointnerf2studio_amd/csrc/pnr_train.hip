@@ -829,6 +829,12 @@ struct TrainWs {
     float *part;                    // partial tiles of the weight-gradient GEMM in flight: [splits, M, ld]
     float *dw_begin;                // dWp / dbp are contiguous: [dw_begin, dw_begin + dw_floats)
     size_t dw_floats;
+    // point gradients: rows grouped by their point (a segmented, order-fixed sum instead of float atomics)
+    int *pt_cnt;      // [rows + 1] rows per touched point (indexed by the point's rank in the call's pt_list)
+    int *pt_start;    // [rows + 1] exclusive scan of pt_cnt
+    int *pt_cursor;   // [rows]
+    int *pt_rows;     // [rows] row ids grouped by point
+    void *pt_scan;    // scan scratch
     size_t total;
 };
 
@@ -878,6 +884,11 @@ static TrainWs carve_train_ws(void *base, int64_t cap, int K)
     for (int i = 0; i < 9; ++i) w.dbp[i] = (float *)take((size_t)W_OUT[i] * 4);
     w.dw_begin = base ? (float *)((char *)base + dw0) : nullptr;
     w.dw_floats = (off - dw0) / 4;
+    w.pt_cnt = (int *)take((rows + 1) * 4);
+    w.pt_start = (int *)take((rows + 1) * 4);
+    w.pt_cursor = (int *)take(rows * 4);
+    w.pt_rows = (int *)take(rows * 4);
+    w.pt_scan = take(scan_temp_bytes((int64_t)rows + 1));
     w.total = off;
     return w;
 }
@@ -1386,10 +1397,20 @@ __global__ void __launch_bounds__(256) k_train_head_agg_bwd(TrainWs w, int K, co
     }
 }
 
-// One wavefront per row: gradients of the point tensors, scattered with float atomics (index_select backward).
+// Gradients of the point tensors (index_select backward), WITHOUT float atomics: a point is the neighbour of ~7 samples
+// of a batch, and the order in which atomics would add its rows changes from run to run.  Instead:
+//   k_train_rowgrad    one wavefront per row: the row's 38 gradient values (d embedding 32 | d colour 3 | d dir 3) into
+//                      rowgrad [rows, 40]; counts the rows of every touched point (integer atomics: order-free)
+//   (scan)             pt_start = exclusive scan of the counts, over the U touched points of the call (their rank in
+//                      the render's pt_list, ascending point index)
+//   k_train_fill       groups the row ids by point (slot order inside a group is arbitrary here ...)
+//   k_train_point_sum  ... one wavefront per touched point SORTS its group and adds its rows in ascending row order:
+//                      the sum is a fixed expression, bitwise repeatable.  Writes either the dense tensors (+=, rows of
+//                      touched points only) or one compact row per touched point (sparse emission).
 //   dX0 [row, 0:224] is in G2, the taped encodings in X0, d[color | sdir - view | <sdir, view>] in H2[:, 256:263]
-__global__ void __launch_bounds__(256) k_train_scatter(TrainParams P, TrainWs w, float *__restrict__ d_emb,
-                                                       float *__restrict__ d_color, float *__restrict__ d_dir)
+constexpr int LD_RG = 40;
+__global__ void __launch_bounds__(256) k_train_rowgrad(TrainParams P, TrainWs w, const int *__restrict__ pt_rank,
+                                                       float *__restrict__ rowgrad)
 {
     const int lane = threadIdx.x & 63;
     const int wv = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwv = (gridDim.x * blockDim.x) >> 6;
@@ -1398,6 +1419,7 @@ __global__ void __launch_bounds__(256) k_train_scatter(TrainParams P, TrainWs w,
     for (int row = wv; row < rows; row += nwv) {
         const int pidx = w.row_pidx[row];
         if (pidx < 0) continue;
+        if (lane == 0) atomicAdd(&w.pt_cnt[pt_rank[pidx]], 1);
         const float *dh = w.H2 + (int64_t)row * LD_H2 + 256;
         // the row of dX0 (224 floats) and of the taped encodings (columns 0..223 of X0) through wave-private LDS: two
         // coalesced float4 loads per lane instead of thirteen 4-byte loads at a stride of 24 bytes
@@ -1408,18 +1430,18 @@ __global__ void __launch_bounds__(256) k_train_scatter(TrainParams P, TrainWs w,
             reinterpret_cast<float4 *>(x0)[lane] = reinterpret_cast<const float4 *>(w.X0 + (int64_t)row * LD_X0)[lane];
         }
         __builtin_amdgcn_wave_barrier();
+        float g = 0.f;
         if (lane < 32) {
             // d/de [e, sin(e 2^f), cos(e 2^f)] = [1, 2^f cos, -2^f sin]
-            float g = dx[lane];
+            g = dx[lane];
 #pragma unroll
             for (int f = 0; f < 3; ++f) {
                 const int i = 32 + 2 * (3 * lane + f);
                 g += (float)(1 << f) * (x0[i + 1] * dx[i] - x0[i] * dx[i + 1]);
             }
-            if (d_emb) unsafeAtomicAdd(d_emb + (int64_t)pidx * 32 + lane, g);
         } else if (lane < 35) {
-            if (d_color) unsafeAtomicAdd(d_color + (int64_t)pidx * 3 + (lane - 32), dh[lane - 32]);
-        } else if (lane < 38 && d_dir) {
+            g = dh[lane - 32];
+        } else if (lane < 38) {
             const int jd = lane - 35;
             const int ray = P.smp_ray[P.vs_list[row / K]];
             float vx, vy, vz;
@@ -1429,8 +1451,74 @@ __global__ void __launch_bounds__(256) k_train_scatter(TrainParams P, TrainWs w,
             const float gd = dh[6];
             const float gs0 = dh[3] + gd * vx, gs1 = dh[4] + gd * vy, gs2 = dh[5] + gd * vz;
             // sdir[i] = sum_j dir[j] M[i][j]  =>  d dir[j] = sum_i d sdir[i] M[i][j]
-            const float gj = gs0 * P.Rw2c[jd] + gs1 * P.Rw2c[3 + jd] + gs2 * P.Rw2c[6 + jd];
-            unsafeAtomicAdd(d_dir + (int64_t)pidx * 3 + jd, gj);
+            g = gs0 * P.Rw2c[jd] + gs1 * P.Rw2c[3 + jd] + gs2 * P.Rw2c[6 + jd];
+        }
+        if (lane < LD_RG) rowgrad[(int64_t)row * LD_RG + lane] = lane < 38 ? g : 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_train_fill(TrainWs w, const int *__restrict__ pt_rank)
+{
+    const int rows = w.cnt[0];
+    for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += gridDim.x * blockDim.x) {
+        const int pidx = w.row_pidx[row];
+        if (pidx < 0) continue;
+        const int u = pt_rank[pidx];
+        w.pt_rows[w.pt_start[u] + atomicAdd(&w.pt_cursor[u], 1)] = row;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_train_point_sum(TrainWs w, const int *__restrict__ n_sel,
+                                                         const int *__restrict__ pt_list,
+                                                         const float *__restrict__ rowgrad, float *__restrict__ d_emb,
+                                                         float *__restrict__ d_color, float *__restrict__ d_dir,
+                                                         float *__restrict__ sp_rows, int *__restrict__ sp_index,
+                                                         long long sp_cap)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwv = (gridDim.x * blockDim.x) >> 6;
+    const int U = n_sel[3];
+    for (int u = wv; u < U; u += nwv) {
+        const int b = w.pt_start[u], c = w.pt_start[u + 1] - b;
+        float acc = 0.f;
+        if (c <= 64) {
+            // rank sort inside the wavefront (row ids are distinct), then the rows in ascending order
+            const int mine = lane < c ? w.pt_rows[b + lane] : 0x7FFFFFFF;
+            int rank = 0;
+            for (int j = 0; j < c; ++j) rank += __shfl(mine, j, 64) < mine ? 1 : 0;
+            // lane `rank` must end up holding `mine`: a gather by inverse permutation through ds_bpermute's twin
+            const int sorted = __builtin_amdgcn_ds_permute(rank << 2, mine);
+            for (int j = 0; j < c; ++j) {
+                const int row = __shfl(sorted, j, 64);
+                if (lane < 38) acc += rowgrad[(int64_t)row * LD_RG + lane];
+            }
+        } else {
+            // a point shared by more than 64 rows (rare): repeated selection of the next larger row id
+            int prev = -1;
+            for (int j = 0; j < c; ++j) {
+                int best = 0x7FFFFFFF;
+                for (int i = lane; i < c; i += 64) {
+                    const int r = w.pt_rows[b + i];
+                    if (r > prev && r < best) best = r;
+                }
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) best = min(best, __shfl_xor(best, d, 64));
+                prev = best;
+                if (lane < 38) acc += rowgrad[(int64_t)best * LD_RG + lane];
+            }
+        }
+        const int pidx = pt_list[u];
+        if (sp_rows) {
+            if (u < sp_cap) {
+                if (lane < LD_RG) sp_rows[(int64_t)u * LD_RG + lane] = lane < 38 ? acc : 0.f;
+                if (lane == 0) sp_index[u] = pidx;
+            }
+        } else if (lane < 32) {
+            if (d_emb) d_emb[(int64_t)pidx * 32 + lane] += acc;
+        } else if (lane < 35) {
+            if (d_color) d_color[(int64_t)pidx * 3 + (lane - 32)] += acc;
+        } else if (lane < 38) {
+            if (d_dir) d_dir[(int64_t)pidx * 3 + (lane - 35)] += acc;
         }
     }
 }
@@ -1683,8 +1771,21 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
     gemm_data(st, bf, tw.H2, LD_H2, tw.Wp[1], 256, tw.WT[1], tw.H1, LD_H, 256, 256, 256, n_rows, rows_max, tw.sgH1);  // H1 <- dZ1
     gemm_weight(st, bf, tw.H1, LD_H, tw.X0, LD_X0, tw.dWp[0], 288, 256, 288, n_rows, rows_max, tw.dbp[0], tw.part);
     gemm_data(st, bf, tw.H1, LD_H, tw.Wp[0], 288, tw.WT[0], tw.G2, LD_H, 224, 256, 0, n_rows, rows_max);     // G2 <- dX0[:, :224]
-    // point tensors
-    hipLaunchKernelGGL(k_train_scatter, eg, eb, 0, st, P, tw, grads->d_embedding, grads->d_color, grads->d_dir);
+    // point tensors: per-row gradients into H1 (its dZ1 is consumed), rows grouped by point, one ordered sum per point
+    if (grads->d_embedding || grads->d_color || grads->d_dir || grads->d_point_grads) {
+        PNR_REQUIRE(!grads->d_point_grads || (grads->d_point_index && grads->point_cap >= 1),
+                    "%s: sparse point gradients need d_point_index and point_cap", who);
+        float *rowgrad = tw.H1;
+        PNR_HIP_CHECK(hipMemsetAsync(tw.pt_cnt, 0, (size_t)(rows_max + 1) * 4, st));
+        PNR_HIP_CHECK(hipMemsetAsync(tw.pt_cursor, 0, (size_t)rows_max * 4, st));
+        hipLaunchKernelGGL(k_train_rowgrad, eg, eb, 0, st, P, tw, ws.pt_rank, rowgrad);
+        int rcs = scan_exclusive_i32(tw.pt_cnt, tw.pt_start, rows_max, ws.n_sel + 3, nullptr, tw.pt_scan, st);
+        if (rcs != PNR_OK) return rcs;
+        hipLaunchKernelGGL(k_train_fill, dim3(1024), eb, 0, st, tw, ws.pt_rank);
+        hipLaunchKernelGGL(k_train_point_sum, eg, eb, 0, st, tw, ws.n_sel, ws.pt_list, rowgrad, grads->d_embedding,
+                           grads->d_color, grads->d_dir, grads->d_point_grads, grads->d_point_index,
+                           (long long)grads->point_cap);
+    }
     // weight gradients out of the padded buffers
     {
         NineMats mw{}, mb{};

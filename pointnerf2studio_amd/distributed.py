@@ -204,6 +204,38 @@ class GradExchange:
                 t.copy_(flat[off:off + t.numel()].view_as(t))
                 off += t.numel()
 
+    def reduce_points_sparse(self, point_index: torch.Tensor, point_grads: torch.Tensor):
+        """The sparse form end to end: this rank's rows as pnr_render_backward emits them (`point_index` [U] int64
+        ascending, `point_grads` [U, 40] = [d_embedding 32 | d_color 3 | d_dir 3 | 0 0]; RendererHIP.backward(...,
+        sparse_points=True)) in, the union over all ranks out: (index [U_all] ascending, rows [U_all, 40]), rows of a
+        point several ranks touched summed in rank order (deterministic).  No dense [N, .] tensor exists on the way:
+        the optimiser (or an index_add_ into .grad) consumes the rows."""
+        dev = point_grads.device
+        idx = point_index.to(device=dev, dtype=torch.long).reshape(-1)
+        if self.world == 1:
+            return idx, point_grads
+        u = torch.tensor([idx.numel()], dtype=torch.long, device=dev)
+        counts = torch.empty(self.world, dtype=torch.long, device=dev)
+        dist.all_gather_into_tensor(counts, u)
+        counts_h = counts.tolist()
+        u_max = max(max(counts_h), 1)
+        block = torch.zeros((u_max, 40), dtype=torch.float32, device=dev)
+        n = idx.numel()
+        block[:n, :38] = point_grads[:, :38]
+        block[:n, 38], block[:n, 39] = _index_to_f32_halves(idx)     # the two pad columns carry the index
+        gathered = torch.empty((self.world * u_max, 40), dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(gathered, block)
+        rows = torch.cat([gathered[r * u_max: r * u_max + counts_h[r]] for r in range(self.world)])
+        all_idx = _index_from_f32_halves(rows[:, 38], rows[:, 39])
+        uniq, inv = torch.unique(all_idx, sorted=True, return_inverse=True)
+        out = torch.zeros((uniq.numel(), 40), dtype=torch.float32, device=dev)
+        # rank order inside every point: index_add_ over a stable sort by (point, rank) position
+        order = torch.argsort(inv, stable=True)
+        out.index_add_(0, inv[order], torch.cat([rows[order, :38], torch.zeros((rows.shape[0], 2), device=dev)], dim=1))
+        if self.average:
+            out.div_(self.world)
+        return uniq, out
+
     def reduce_points(self, touched: torch.Tensor, d_embedding: torch.Tensor, d_color: torch.Tensor,
                       d_dir: torch.Tensor) -> int:
         """In place on the dense [N,32] / [N,3] / [N,3] gradients.  `touched`: the (unique) point indices this rank's

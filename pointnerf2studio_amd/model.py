@@ -370,6 +370,34 @@ class PointNerf(Model):
         conf_coefficient = conf_all - (conf_all - torch.clamp(conf_all, min=0.0001, max=1)).detach()
         return {"coarse_raycolor": rgb, "ray_mask": ray_mask, "conf_coefficient": conf_coefficient}
 
+    # ---- point growing / pruning (absent from the reference's plugin, present in its
+    # legacy trainer: run/train_studio.py:335-444,676-735) -------------------------------------------------------------
+    @torch.no_grad()
+    def get_probe_outputs(self, ray_bundle) -> Dict[str, torch.Tensor]:
+        """One eval render + the probing outputs of the legacy model (`opt.prob == 1`,
+        models/neural_points_volumetric_model.py:331-352) under the legacy key names: coarse_raycolor, ray_mask,
+        ray_max_shading_opacity, ray_max_sample_loc_w, ray_max_far_dist, shading_avg_{color,dir,conf,embedding} --
+        what probe_hole (run/train_studio.py:335-429) scatters into its per-pixel maps."""
+        if not self._fusable():
+            raise RuntimeError("get_probe_outputs needs the fused HIP path (default network shape)")
+        was_training = self.training
+        self.eval()
+        try:
+            out = self._get_outputs_fused(ray_bundle)
+            out.update(self._renderer.probe())
+        finally:
+            self.train(was_training)
+        return out
+
+    def prune_points(self, thresh: float) -> int:
+        """models/neural_points_volumetric_model.py prune_points -> neural_points.prune (neural_points.py:341-364).  The
+        caller re-creates its optimisers afterwards (the parameters are new tensors), as the reference's trainer does."""
+        return self.neural_points.prune(thresh)
+
+    def grow_points(self, add_xyz, add_embedding, add_color, add_dir, add_conf) -> int:
+        """neural_points.py:367-393 (called at run/train_studio.py:714)."""
+        return self.neural_points.grow_points(add_xyz, add_embedding, add_color, add_dir, add_conf)
+
     def get_outputs(self, ray_bundle):
         if self.mlp_base is None:
             raise ValueError("populate_fields() must be called before get_outputs")

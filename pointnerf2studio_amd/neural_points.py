@@ -226,6 +226,55 @@ class NeuralPoints(nn.Module):
             self._packed_key = pkey
         return self._fused_scene
 
+    # ---- point growing / pruning (reference models/neural_points/neural_points.py:341-393) ---------------------
+    def _replace_points(self, xyz, emb, conf, pdir, color, old_index: torch.Tensor) -> None:
+        """New Parameters (the cloud's size changed, so the optimiser has to be re-created by the caller, as the
+        reference's trainer does: run/train_studio.py:676-684,714-716) and the voxel structure updated in place
+        (pnr_scene_update) instead of rebuilt from nothing."""
+        cfg = self.config
+        self.points_xyz = nn.Parameter(xyz.contiguous(), requires_grad=False)
+        self.points_embeding = nn.Parameter(emb.contiguous(), requires_grad=bool(cfg.feat_grad))
+        self.points_conf = nn.Parameter(conf.contiguous(), requires_grad=bool(cfg.conf_grad))
+        self.points_dir = nn.Parameter(pdir.contiguous(), requires_grad=bool(cfg.dir_grad))
+        self.points_color = nn.Parameter(color.contiguous(), requires_grad=bool(cfg.color_grad))
+        self._packed_key = None
+        self.query_worldcoords_cuda._key = None      # the compat op's own cache follows the cloud by key
+        if self._fused_scene is not None and self.points_xyz.is_cuda:
+            self._hyp_key = None
+            self.get_hyperparameters(cfg.vsize, self.points_xyz, ranges=cfg.ranges)
+            h = self._hyp[3]
+            self._fused_scene.update(self.points_xyz.detach(), old_index, h.ranges, h.scaled_vsize, h.scaled_vdim,
+                                     cfg.kernel_size, cfg.query_size, cfg.P, cfg.max_o, True)
+            self._fused_key = (self.points_xyz.data_ptr(), self.points_xyz._version, cfg.P, cfg.max_o)
+        else:
+            self._fused_key = None
+
+    @torch.no_grad()
+    def prune(self, thresh: float) -> int:
+        """neural_points.py:341-364: keeps the points with points_conf >= thresh.  Returns how many were removed."""
+        mask = self.points_conf[0, ..., 0] >= thresh
+        old = torch.nonzero(mask).reshape(-1).to(torch.int32)
+        n_before = int(mask.shape[0])
+        self._replace_points(self.points_xyz[mask, :], self.points_embeding[:, mask, :], self.points_conf[:, mask, :],
+                             self.points_dir[:, mask, :], self.points_color[:, mask, :], old)
+        return n_before - int(old.numel())
+
+    @torch.no_grad()
+    def grow_points(self, add_xyz, add_embedding, add_color, add_dir, add_conf) -> int:
+        """neural_points.py:367-393: appends points (add_xyz [A,3], add_embedding [A,32], add_color [A,3], add_dir [A,3],
+        add_conf [A,1]) behind the existing ones.  Returns the new point count."""
+        dev = self.points_xyz.device
+        N, A = self.points_xyz.shape[0], add_xyz.shape[0]
+        old = torch.cat([torch.arange(N, dtype=torch.int32, device=dev),
+                         torch.full((A,), -1, dtype=torch.int32, device=dev)])
+        f = lambda t: t.to(device=dev, dtype=torch.float32)
+        self._replace_points(torch.cat([self.points_xyz, f(add_xyz)], dim=0),
+                             torch.cat([self.points_embeding, f(add_embedding)[None, ...]], dim=1),
+                             torch.cat([self.points_conf, f(add_conf)[None, ...]], dim=1),
+                             torch.cat([self.points_dir, f(add_dir)[None, ...]], dim=1),
+                             torch.cat([self.points_color, f(add_color)[None, ...]], dim=1), old)
+        return N + A
+
     def invalidate(self) -> None:
         """Forces a rebuild of the voxel structure + repack at the next fused render (the cloud itself changed)."""
         self._fused_key = None

@@ -178,6 +178,36 @@ class SceneHIP:
                                                 _stream_ptr(self.device)), "pnr_scene_build")
         return self.info()
 
+    def update(self, xyz: torch.Tensor, old_index: torch.Tensor, ranges, scaled_vsize, scaled_vdim, kernel_size,
+               query_size, P: int, max_o: int, compat_drop_voxel0: bool = True) -> Dict[str, int]:
+        """pnr_scene_update: the cloud changed (prune / grow).  old_index [N] int32: the index point i of the new
+        cloud had in the previous one, -1 for an added point.  Rebuilds inside the memory the scene holds; surviving
+        points keep their cell code when the grid is unchanged.  Same content as a fresh build().  The packed rows
+        are stale afterwards: call pack_points."""
+        if not xyz.is_cuda:
+            raise RuntimeError("SceneHIP.update: xyz must be a GPU tensor")
+        pts = _f32c(xyz.reshape(-1, 3), self.device)
+        oi = old_index.to(device=self.device, dtype=torch.int32).contiguous()
+        if oi.numel() != pts.shape[0]:
+            raise ValueError(f"old_index has {oi.numel()} entries for {pts.shape[0]} points")
+        gp = _lib.GridParams()
+        gp.ranges[:] = [float(v) for v in np.asarray(ranges, dtype=np.float32)]
+        gp.vox[:] = [float(v) for v in np.asarray(scaled_vsize, dtype=np.float32)]
+        gp.dims[:] = [int(v) for v in scaled_vdim]
+        gp.kernel_size[:] = [int(v) for v in kernel_size]
+        gp.query_size[:] = [int(v) for v in query_size]
+        gp.P, gp.max_o, gp.compat_drop_voxel0 = int(P), int(max_o), int(bool(compat_drop_voxel0))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.pnr_scene_update(self.handle, _ptr(pts), pts.shape[0], C.byref(gp), _ptr(oi),
+                                                 _stream_ptr(self.device)), "pnr_scene_update")
+        self.N, self.params = pts.shape[0], gp
+        return self.info()
+
+    def update_info(self) -> Dict[str, int]:
+        arr = (C.c_int64 * 4)()
+        _lib.check(self.lib.pnr_scene_update_info(self.handle, C.byref(arr)), "pnr_scene_update_info")
+        return dict(zip(["builds", "updates", "cells_reused", "scratch_bytes"], [int(v) for v in arr]))
+
     def info(self) -> Dict[str, int]:
         arr = (C.c_int64 * 8)()
         _lib.check(self.lib.pnr_scene_info(self.handle, C.byref(arr)), "pnr_scene_info")
@@ -438,12 +468,16 @@ class RendererHIP:
             cap = int(cnt[2] * 1.125) + 1024
 
     def backward(self, grad_rgb: torch.Tensor, state: Dict[str, torch.Tensor], num_points: int,
-                 point_grads: bool = True, weight_grads: bool = True) -> Dict[str, torch.Tensor]:
+                 point_grads: bool = True, weight_grads: bool = True, sparse_points: bool = False
+                 ) -> Dict[str, torch.Tensor]:
         """Gradients of the LAST render / render_views call (pnr_render_backward): d loss / d {embedding [N,32],
         color [N,3], dir [N,3], '<module>.weight', '<module>.bias'} for grad_rgb = d loss / d rgb [R,3].  `state` holds
         the raw MLP tensors the weights were packed from.  What torch autograd derives for studio_model.py:263-399;
         the MLP forward is recomputed in the renderer's precision ('rgb' in the result is that recomputed image; fp32:
-        gradients agree with fp32 autograd to ~1e-6, bf16x3: the GEMMs on bf16 hi/lo splits)."""
+        gradients agree with fp32 autograd to ~1e-6, bf16x3: the GEMMs on bf16 hi/lo splits).
+        sparse_points: instead of the three dense [N, .] tensors, 'point_index' [U] (int64, ascending) and 'point_grads'
+        [U, 40] = [d embedding | d color | d dir | 0 0] for the U distinct neighbour points of the render.
+        The point gradients are summed in a fixed order: repeated calls return the same bits."""
         if getattr(self, "_last", None) is None:
             raise RuntimeError("RendererHIP.backward: no render call to differentiate")
         d, R, arr, n, rc, rays_per_cam, cap = self._last
@@ -459,7 +493,15 @@ class RendererHIP:
         bp = (C.c_void_p * 9)(*[b.data_ptr() for b in bs_t])
         out: Dict[str, torch.Tensor] = {"rgb": torch.empty((R, 3), dtype=torch.float32, device=dev)}
         grads = _lib.GradsC()
-        if point_grads:
+        if point_grads and sparse_points:
+            if self.last_counters is None:
+                raise RuntimeError("sparse point gradients need the counters of the render (sync_counters=True)")
+            U = int(self.last_counters["points_unique"])
+            out["point_grads"] = torch.empty((max(U, 1), 40), dtype=torch.float32, device=dev)
+            sp_index = torch.empty((max(U, 1),), dtype=torch.int32, device=dev)
+            grads.d_point_grads, grads.d_point_index, grads.point_cap = (out["point_grads"].data_ptr(),
+                                                                         sp_index.data_ptr(), max(U, 1))
+        elif point_grads:
             out["embedding"] = torch.zeros((num_points, 32), dtype=torch.float32, device=dev)
             out["color"] = torch.zeros((num_points, 3), dtype=torch.float32, device=dev)
             out["dir"] = torch.zeros((num_points, 3), dtype=torch.float32, device=dev)
@@ -488,6 +530,35 @@ class RendererHIP:
                 rays_per_cam, C.byref(self.opts), _ptr(g), _ptr(ws), ws.numel(), cap, _ptr(self._tws),
                 self._tws.numel(), C.byref(grads), _ptr(out["rgb"]), _stream_ptr(dev)), "pnr_render_backward")
         # no synchronisation (see pack_points): everything is queued on torch's current stream
+        if point_grads and sparse_points:
+            out["point_grads"] = out["point_grads"][:U]
+            out["point_index"] = sp_index[:U].to(torch.long)
+        return out
+
+    PROBE_KEYS = {"ray_max_shading_opacity": ("d_max_opacity", ()), "ray_max_sample_loc_w": ("d_max_loc", (3,)),
+                  "ray_max_far_dist": ("d_far_dist", ()), "shading_avg_color": ("d_avg_color", (3,)),
+                  "shading_avg_dir": ("d_avg_dir", (3,)), "shading_avg_conf": ("d_avg_conf", ()),
+                  "shading_avg_embedding": ("d_avg_embedding", (32,))}
+
+    def probe(self) -> Dict[str, torch.Tensor]:
+        """Probing outputs of the LAST render call (pnr_render_probe; the reference's legacy model with opt.prob == 1,
+        models/neural_points_volumetric_model.py:331-352), under the reference's key names, over all R rays of the call
+        (zeros for rays that are not kept) plus `ray_max_sample_index` (int32, -1 for those)."""
+        if getattr(self, "_last", None) is None:
+            raise RuntimeError("RendererHIP.probe: no render call to probe")
+        d, R, arr, n, rc, rays_per_cam, cap = self._last
+        dev = self.scene.device
+        out, pc = {}, _lib.ProbeC()
+        for key, (field, tail) in self.PROBE_KEYS.items():
+            out[key] = torch.empty((R,) + tail, dtype=torch.float32, device=dev)
+            setattr(pc, field, out[key].data_ptr())
+        out["ray_max_sample_index"] = torch.empty((R,), dtype=torch.int32, device=dev)
+        pc.d_max_index = out["ray_max_sample_index"].data_ptr()
+        ws = self._ws
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.pnr_render_probe(self.scene.handle, arr, n, _ptr(rc), rays_per_cam, C.byref(self.opts), R,
+                                                 _ptr(ws), ws.numel(), cap, C.byref(pc), _stream_ptr(dev)),
+                       "pnr_render_probe")
         return out
 
     def touched_points(self) -> torch.Tensor:

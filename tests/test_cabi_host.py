@@ -173,7 +173,8 @@ def test_jitter_uniform_matches_oracle_generator(lib, oracle):
 
 def test_backward_workspace_size_and_grads_struct(lib):
     """Host-only entry points of the training step: the workspace size is a pure function of (cap_samples, K), grows
-    with both, and pnr_grads_t is 21 device pointers (3 point tensors + 9 weights + 9 biases)."""
+    with both, and pnr_grads_t is 21 device pointers (3 point tensors + 9 weights + 9 biases) + the sparse triple
+    (rows, indices, capacity)."""
     from pointnerf2studio_amd import _lib
     a = lib.pnr_backward_workspace_bytes(4096, 8)
     b = lib.pnr_backward_workspace_bytes(8192, 8)
@@ -183,4 +184,4 @@ def test_backward_workspace_size_and_grads_struct(lib):
     per_row = (b - a) / (4096 * 8)
     assert 5000 < per_row < 7000, per_row
     assert lib.pnr_backward_workspace_bytes(0, 0) == lib.pnr_backward_workspace_bytes(1, 1)   # clamped, never 0
-    assert C.sizeof(_lib.GradsC) == 21 * C.sizeof(C.c_void_p)
+    assert C.sizeof(_lib.GradsC) == 24 * C.sizeof(C.c_void_p)

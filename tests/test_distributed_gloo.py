@@ -131,6 +131,19 @@ def _grad_worker(rank, world, port, N, q):
             ex.reduce_mlp([a, b])
             ok = ok and torch.allclose(a, sum(x[4][:10] for x in everyone) / scale, atol=1e-6)
             ok = ok and torch.allclose(b, sum(x[4][10:30] for x in everyone) / scale, atol=1e-6)
+        # the sparse form end to end (rows in, union rows out; no dense tensor): equals the dense sums on its rows,
+        # covers exactly the points some rank touched, ascending
+        for average in (False, True):
+            sidx = torch.sort(idx)[0]
+            rows = torch.cat([emb[sidx], col[sidx], dr[sidx], torch.zeros(sidx.numel(), 2)], dim=1)
+            u_idx, u_rows = GradExchange(average=average).reduce_points_sparse(sidx, rows)
+            scale = world if average else 1
+            want_idx = torch.cat([x[0] for x in everyone]).unique()
+            ok = ok and torch.equal(u_idx, want_idx)
+            ok = ok and torch.allclose(u_rows[:, :32], sum(x[1] for x in everyone)[want_idx] / scale, atol=1e-6)
+            ok = ok and torch.allclose(u_rows[:, 32:35], sum(x[2] for x in everyone)[want_idx] / scale, atol=1e-6)
+            ok = ok and torch.allclose(u_rows[:, 35:38], sum(x[3] for x in everyone)[want_idx] / scale, atol=1e-6)
+            ok = ok and float(u_rows[:, 38:].abs().sum()) == 0.0
         # a rank whose rays hit nothing contributes zero rows
         e, c, d = torch.zeros(N, 32), torch.zeros(N, 3), torch.zeros(N, 3)
         mine = idx if rank == 0 else idx[:0]

@@ -263,3 +263,42 @@ def test_backward_edge_cases(oracle, gpu_device):
         _compare(k, got[k].cpu(), want[k])
     for name in MLP_TENSOR_ORDER:
         _compare(name + ".weight", got[name + ".weight"].cpu(), want[name + ".weight"])
+
+
+def test_point_gradients_are_bitwise_repeatable_and_sparse_rows_match(oracle, gpu_device):
+    """The point gradients are a segmented sum in a fixed order (rows grouped by point, ascending row index), not float
+    atomics: two backward calls on the same render return the same bits -- also for a crowded cloud in which single
+    points are the neighbour of hundreds of samples (groups longer than a wavefront take the selection path).  The sparse
+    emission (one row per distinct neighbour point) holds exactly the non-zero rows of the dense tensors."""
+    for N, shrink, H in ((60000, 1.0, 24), (300, 0.12, 20)):
+        pts = small_scene(N, shrink=shrink)
+        cfg = oracle_cfg(oracle, SR=80, K=8, P=12)
+        w = synthetic.make_weights(0, sigma_scale=300.0, bias_scale=0.1)
+        campos, camrot, dirs = camera_rays(H, H, az=35.0)
+        if shrink != 1.0:   # a small object: aim the window at it
+            campos, camrot, dirs = camera_rays(800, 800, az=35.0, window=(380, 420, 380, 420))
+        scene, wh, hyp, info = build_hip(pts, cfg, gpu_device, weights=w)
+        rnd = RendererHIP(scene, wh, SR=80, K=8, D=cfg.z_depth_dim, radius_limit=float(oracle.radius_limit(cfg)),
+                          vsize_z=cfg.vsize[2], eval_clamp=False)
+        out = rnd.render(dirs.to(gpu_device), campos, camrot, 2.0, 6.0)
+        assert out["counters"]["pairs_valid"] > 1000
+        G = torch.randn(dirs.shape[0], 3, generator=torch.Generator().manual_seed(8)).to(gpu_device)
+        a = rnd.backward(G, w, N)
+        b = rnd.backward(G, w, N)
+        for k in ("embedding", "color", "dir"):
+            assert torch.equal(a[k], b[k]), f"{k} differs between two identical backward calls"
+        sp = rnd.backward(G, w, N, sparse_points=True)
+        U = out["counters"]["points_unique"]
+        assert sp["point_index"].shape == (U,) and sp["point_grads"].shape == (U, 40)
+        assert torch.equal(sp["point_index"], rnd.touched_points())
+        idx = sp["point_index"]
+        assert torch.equal(sp["point_grads"][:, :32], a["embedding"][idx])
+        assert torch.equal(sp["point_grads"][:, 32:35], a["color"][idx]) and torch.equal(sp["point_grads"][:, 35:38], a["dir"][idx])
+        assert float(sp["point_grads"][:, 38:].abs().sum()) == 0.0
+        untouched = torch.ones(N, dtype=torch.bool, device=gpu_device)
+        untouched[idx] = False
+        assert float(a["embedding"][untouched].abs().sum()) == 0.0
+        if shrink != 1.0:
+            # the crowded case really has groups beyond one wavefront
+            rows = rnd.taps(dirs.shape[0])["smp_pidx"][:out["counters"]["samples_selected"]].reshape(-1)
+            assert torch.bincount(rows[rows >= 0]).max().item() > 64, "scene not crowded enough for the long-group path"
