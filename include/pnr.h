@@ -324,7 +324,9 @@ int pnr_render_probe(const pnr_scene_t *scene, const pnr_camera_t *cams, int32_t
 
 /* ---- per-stage device timing (bench / roofline) ------------------------------------------------- */
 /* When enabled, pnr_render records hipEvents on `stream` between its stages into a ring of
- * PNR_PROFILE_SLOTS slots, one slot per call (no host sync is added to the render).  pnr_profile_calls() is
+ * PNR_PROFILE_SLOTS slots, one slot per call, claimed atomically (calls from several host threads or on several
+ * streams get distinct slots and each records on its own stream; no host sync is added to the render).
+ * pnr_profile_calls() is
  * the number of calls recorded since pnr_profile_enable(1); pnr_profile_read(call, ms) synchronises on that
  * call's last event and returns the elapsed device time of each stage in milliseconds. */
 #define PNR_PROFILE_SLOTS 256

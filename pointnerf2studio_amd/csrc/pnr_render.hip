@@ -5,6 +5,8 @@
 #include <stdarg.h>
 
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 
 #include "pnr_internal.h"
 
@@ -22,11 +24,13 @@ void set_error(const char *fmt, ...)
 
 constexpr int TPB = 256;
 
-// per-stage timing: events recorded on the caller's stream into a ring of slots (one slot per pnr_render
-// call), read back on request -- the timed loop itself never synchronises
-static bool g_prof = false;
+// per-stage timing: events recorded on the CALLER's stream into a ring of slots (one slot per render call, claimed
+// atomically: calls from several host threads / on several streams each get their own slot and their own stream's
+// events), read back on request -- the timed loop itself never synchronises
+static std::atomic<bool> g_prof{false};
+static std::atomic<long long> g_prof_calls{0};
+static std::mutex g_prof_mu;   // event creation / enable
 static hipEvent_t g_evs[PNR_PROFILE_SLOTS][PNR_NUM_STAGES + 1] = {{nullptr}};
-static long long g_prof_calls = 0;
 
 // one thread per ray: its samples are contiguous in the compact list, at most SR of them.
 __global__ void k_set_cams(CamSet set, int n, Camera *__restrict__ dst)
@@ -346,8 +350,9 @@ static int render_views(const pnr_scene_t *scene, const pnr_weights_t *weights, 
     }
     // the shading stage reads directions per hit ray: the caller's tensor, or the rows k_expand generated
     const float *shade_dirs = gen ? ws.ray_dirs : d_dirs;
-    const bool prof = g_prof;
-    hipEvent_t *g_ev = g_evs[g_prof_calls % PNR_PROFILE_SLOTS];
+    const bool prof = g_prof.load();
+    const long long slot = prof ? g_prof_calls.fetch_add(1) : 0;
+    hipEvent_t *g_ev = g_evs[slot % PNR_PROFILE_SLOTS];
     if (prof) PNR_HIP_CHECK(hipEventRecord(g_ev[0], stream));
     int rc = launch_select_expand(scene->grid, cr, d_dirs, nullptr, R, opts->D, opts->SR, cap_samples, ws, d_counters,
                                   stream);
@@ -364,10 +369,7 @@ static int render_views(const pnr_scene_t *scene, const pnr_weights_t *weights, 
     if (prof) PNR_HIP_CHECK(hipEventRecord(g_ev[4], stream));
     rc = launch_composite(cr, *opts, R, ws, d_rgb, d_depth, d_acc, d_ray_mask, d_counters, stream);
     if (rc != PNR_OK) return rc;
-    if (prof) {
-        PNR_HIP_CHECK(hipEventRecord(g_ev[5], stream));
-        ++g_prof_calls;
-    }
+    if (prof) PNR_HIP_CHECK(hipEventRecord(g_ev[5], stream));
     return PNR_OK;
 }
 
@@ -544,22 +546,24 @@ extern "C" int pnr_render_probe(const pnr_scene_t *scene, const pnr_camera_t *ca
 
 extern "C" int pnr_profile_enable(int enable)
 {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     if (enable && !g_evs[0][0])
         for (int s = 0; s < PNR_PROFILE_SLOTS; ++s)
             for (int i = 0; i <= PNR_NUM_STAGES; ++i) PNR_HIP_CHECK(hipEventCreate(&g_evs[s][i]));
-    g_prof = enable != 0;
-    g_prof_calls = 0;
+    g_prof_calls.store(0);
+    g_prof.store(enable != 0);
     return PNR_OK;
 }
 
-extern "C" int64_t pnr_profile_calls(void) { return g_prof_calls; }
+extern "C" int64_t pnr_profile_calls(void) { return g_prof_calls.load(); }
 
 extern "C" int pnr_profile_read(int64_t call, float ms[PNR_NUM_STAGES])
 {
     PNR_REQUIRE(ms != nullptr, "pnr_profile_read: null argument");
-    if (call < 0 || call >= g_prof_calls || call < g_prof_calls - PNR_PROFILE_SLOTS) {
-        set_error("pnr_profile_read: call %lld not recorded (recorded %lld, ring of %d)", (long long)call,
-                  (long long)g_prof_calls, PNR_PROFILE_SLOTS);
+    const long long recorded = g_prof_calls.load();
+    if (call < 0 || call >= recorded || call < recorded - PNR_PROFILE_SLOTS) {
+        set_error("pnr_profile_read: call %lld not recorded (recorded %lld, ring of %d)", (long long)call, recorded,
+                  PNR_PROFILE_SLOTS);
         return PNR_ERR_STATE;
     }
     hipEvent_t *g_ev = g_evs[call % PNR_PROFILE_SLOTS];

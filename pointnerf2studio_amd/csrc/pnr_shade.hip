@@ -275,7 +275,6 @@ int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr,
     P.agg = ws.agg;
     P.smp_out = ws.smp_out;
     P.K = K;
-    P.dbg_off = cap - 8192;
     P.w16a_off = w->w16a_off;
     P.w16b_off = w->w16b_off;
     P.w4acc_off = w->w4acc_off;

@@ -48,7 +48,6 @@ struct Ring {
     int cur;
     u32x4 ah, al, bh, bl;
     f32x16 acc0;
-    unsigned long long stall_bar, stall_bias;  // PNR_STAMPS builds only
 };
 
 // One dense layer on bf16 hi/lo splits.  MT output tiles of 32 features.  Weight tiles
@@ -125,9 +124,7 @@ __device__ __forceinline__ void dense_layer_bf16(__amdgpu_buffer_rsrc_t rsrc, in
             const bool want_bias = NX_BIAS || m + 1 < MT;
             if (s == S_BI && want_bias) bias_issue((m + 1 < MT) ? bias + 32 * (m + 1) : bias_nx, breg);
             if (s == S_BF && want_bias) {
-                const unsigned long long tb0 = stamp();
                 bias_wait(breg);
-                ring.stall_bias += stamp() - tb0;
             }
             __builtin_amdgcn_sched_barrier(0);
             // fragments of k-step s+2: of this tile, or of the next tile (published by the mid-tile barrier)
@@ -144,14 +141,11 @@ __device__ __forceinline__ void dense_layer_bf16(__amdgpu_buffer_rsrc_t rsrc, in
             // the previous tile's accumulators are read two k-steps into this tile at the earliest: its last MFMA
             // needs ~64 cycles to retire
             constexpr int S0 = KS >= 10 ? 2 : 0;
-            const bool do_split = SPLIT_OUT && m > 0 && s >= S0 && s < S0 + 8 && !(PNR_ABLATE & 16);
+            const bool do_split = SPLIT_OUT && m > 0 && s >= S0 && s < S0 + 8;
             const int sp = s - S0;
             float v0 = 0.f, v1 = 0.f, r0 = 0.f, r1 = 0.f;
             __bf16 h0, h1;
-            if (PNR_ABLATE & 2)
-                asm volatile("" ::"v"(wh), "v"(wl), "v"(xh[s]), "v"(xl[s]));
-            else
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[s], acc, 0, 0, 0);
             if (do_split) {
                 v0 = leaky(prev[2 * sp]);
                 v1 = leaky(prev[2 * sp + 1]);
@@ -159,14 +153,14 @@ __device__ __forceinline__ void dense_layer_bf16(__amdgpu_buffer_rsrc_t rsrc, in
                 h1 = (__bf16)v1;
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (!(PNR_ABLATE & 2)) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[s], acc, 0, 0, 0);
             if (do_split) {
                 r0 = v0 - (float)h0;
                 r1 = v1 - (float)h1;
             }
             if (s >= S_BF && want_bias) bias_quarter(breg, s - S_BF, ring.acc0);
             __builtin_amdgcn_sched_barrier(0);
-            if (!(PNR_ABLATE & 2)) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[s], acc, 0, 0, 0);
             if (do_split) {
                 const int kk = 2 * (m - 1) + sp / 4, j0 = (2 * sp) % 8;
                 yh[kk][j0] = h0;
@@ -188,19 +182,17 @@ __device__ __forceinline__ void dense_layer_bf16(__amdgpu_buffer_rsrc_t rsrc, in
             ring.bh = ch;
             ring.bl = cl;
             constexpr int S_MID = KS / 2 - 1;
-            if (s == S_MID && !(PNR_ABLATE & 8)) {
+            if (s == S_MID) {
                 // ---- mid-tile: tile T+1 has landed everywhere, slot of tile T-1 is free ---------------------------
                 if (m + 2 < MT)
                     wait_vm<R_SAME>();
                 else
                     wait_vm<R_NX>();
-                const unsigned long long tb0 = stamp();
-                if (!(PNR_ABLATE & 64)) __builtin_amdgcn_s_barrier();
-                ring.stall_bar += stamp() - tb0;
+                __builtin_amdgcn_s_barrier();
             }
             // ---- DMA of tile T+3 into the freed slot: two 1-KiB pieces per k-step behind the barrier, so the
             //      scalar address arithmetic hides between MFMAs instead of stalling the matrix pipe in one burst
-            if (s > S_MID && !(PNR_ABLATE & (8 | 32))) {
+            if (s > S_MID) {
                 constexpr int R3 = 0;
                 (void)R3;
                 const int rounds = (m + 3 < MT) ? R_SAME : R_NX;
@@ -227,7 +219,7 @@ __device__ __forceinline__ void dense_layer_bf16(__amdgpu_buffer_rsrc_t rsrc, in
 #pragma unroll
         for (int r = 0; r < 16; ++r) sink(MT - 1, r, OUT_LEAKY ? leaky(prev[r]) : prev[r]);
     }
-    if (SPLIT_OUT && !(PNR_ABLATE & 16)) {
+    if (SPLIT_OUT) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const float v0 = leaky(prev[2 * s]), v1 = leaky(prev[2 * s + 1]);
@@ -280,7 +272,7 @@ __device__ __forceinline__ void dense_layer1b_bf16(__amdgpu_buffer_rsrc_t rsrc, 
             const bf16x8 wh = __builtin_bit_cast(bf16x8, ring.ah);
             const bf16x8 wl = __builtin_bit_cast(bf16x8, ring.al);
             // value pairs of the previous row block handled in this k-step
-            const bool do_split = B > 0 && xs >= 1 && !(PNR_ABLATE & 16);
+            const bool do_split = B > 0 && xs >= 1;
             const int p0 = 3 * (xs - 1), np = xs == 3 ? 2 : 3;
             float v0[3], v1[3], r0[3], r1[3];
             __bf16 h0[3], h1[3];
@@ -324,14 +316,14 @@ __device__ __forceinline__ void dense_layer1b_bf16(__amdgpu_buffer_rsrc_t rsrc, 
             ring.al = ring.bl;
             ring.bh = ch;
             ring.bl = cl;
-            if (s == 3 && !(PNR_ABLATE & 8)) {
+            if (s == 3) {
                 if (m + 2 < MT)
                     wait_vm<R_SAME>();
                 else
                     wait_vm<R_NX>();
-                if (!(PNR_ABLATE & 64)) __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_barrier();
             }
-            if (s > 3 && !(PNR_ABLATE & (8 | 32))) {
+            if (s > 3) {
                 const int rounds = (m + 3 < MT) ? R_SAME : R_NX;
                 const int per = (rounds + 3) / 4;  // pieces per k-step (1..3)
                 const int first = per * (s - 4);
@@ -347,7 +339,7 @@ __device__ __forceinline__ void dense_layer1b_bf16(__amdgpu_buffer_rsrc_t rsrc, 
         }
         ring.cur = nxs;
     }
-    if (!(PNR_ABLATE & 16)) {
+    {
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const float v0 = leaky(prev[2 * s]), v1 = leaky(prev[2 * s + 1]);
@@ -408,8 +400,6 @@ __global__ void __launch_bounds__(TPB, 1) k_point_part(ShadeParams P)
     if ((int)blockIdx.x >= ntiles) return;
     const float *__restrict__ b0 = P.wbuf + P.b_off[0];
     Ring ring;
-    ring.stall_bar = 0;
-    ring.stall_bias = 0;
     ring_start<14>(rsrc, wa_, b0, lane, tid, wave_u, lds, ring);
     // embeddings of the first tile; those of the next tile are fetched while this one is multiplied
     float4 en[4];
@@ -542,10 +532,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
     }
     const float b4 = P.wbuf[P.b_off[4]];
     Ring ring;
-    ring.stall_bar = 0;
-    ring.stall_bias = 0;
     ring_start<8>(rsrc, wb_, nullptr, lane, tid, wave_u, lds, ring);
-    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     RowFetch cur, nxt;
     fetch_a<SEG>(P, t_begin, lane, wave, V0, S_valid, cur);
     fetch_b<SEG>(P, cur);
@@ -553,7 +540,6 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
     for (int tile = t_begin; tile < t_end; tile += G) {
         int wb = wb_, w1 = w1_, w2 = w2_, w3 = w3_;
         asm volatile("" : "+s"(wb), "+s"(w1), "+s"(w2), "+s"(w3));
-        const unsigned long long ts0 = stamp();
         const Camera cam = load_cam_wave(P.cr, cur.cid);
         // first level of the next tile's gather chain (a tile past the end loads row 0: harmless); the other two
         // levels follow at the layer boundaries
@@ -579,7 +565,6 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
                 }
         }
         __builtin_amdgcn_sched_barrier(0);
-        const unsigned long long tsg = stamp();
         RowCtx ctx;
         bf16x8 xqh[4], xql[4];
         {
@@ -588,21 +573,17 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
 #pragma unroll
             for (int s = 0; s < 4; ++s) split8(&xq[8 * s], xqh[s], xql[s]);
         }
-        const unsigned long long ts1 = stamp();
         bf16x8 xh[17], xl[17], yh[17], yl[17];
         dense_layer1b_bf16<16>(rsrc, wb, w1, b1, lane, tid, wave_u, lds, ring, xqh, xql, pin, yh, yl);
-        const unsigned long long ts2 = stamp();
         fetch_b<SEG>(P, nxt);
         // layer 2's output (+ the 7 extra head inputs as k-step 16) goes to xh/xl
         dense_layer_bf16<16, 8, 17, true>(rsrc, w1, w2, b1, b2, lane, tid, wave_u, lds, ring, yh, yl, xh, xl, StoreOut{nullptr});
-        const unsigned long long ts3 = stamp();
         fetch_c_pair(P, nxt);
         {
             float v[8] = {ctx.ex[0], ctx.ex[1], ctx.ex[2], ctx.ex[3], 0.f, 0.f, 0.f, 0.f};
             split8(v, xh[16], xl[16]);
         }
         dense_layer_bf16<17, 8, 16, true>(rsrc, w2, w3, b2, b3, lane, tid, wave_u, lds, ring, xh, xl, yh, yl, StoreOut{nullptr});
-        const unsigned long long ts4 = stamp();
         // Last layer.  The chain wraps around: the next pair tile starts again with the pair half of layer 0, whose
         // accumulators come from pt_table (no bias prefetch).
         if (SEG != 0) {
@@ -653,8 +634,6 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
                 stage(128 - NS + i);
                 p1 = 0.f;
             }
-            const unsigned long long ts5 = stamp();
-            ph[4] += ts5 - ts4;
             // Retire the next tile's prefetched loads HERE, ahead of the stores (vector memory returns in order and
             // the last of them was issued a layer ago: the wait is free).  Left to the first use at the top of the
             // next iteration, hipcc waits vmcnt(0) across the back edge: for the stores just issued.
@@ -673,34 +652,15 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
                     agg4[agg_idx4(ctx.v_idx, 2 * ctx.slot + (q >> 1), lane >> 5, q & 1)] =
                         make_float4(mine[4 * q], mine[4 * q + 1], mine[4 * q + 2], mine[4 * q + 3]);
             }
-            ph[5] += stamp() - ts5;
         } else {
             float o[128];
             dense_layer_bf16<16, 8, 8, false, false, true>(rsrc, w3, wb, b3, nullptr, lane, tid, wave_u, lds, ring, yh,
                                                            yl, nullptr, nullptr, StoreOut{o});
-            const unsigned long long ts5 = stamp();
-            ph[4] += ts5 - ts4;
             asm volatile("" ::"v"(nxt.dirz), "v"(nxt.urow));
             finish_rows<SEG, true>(P, lane, o, ctx);  // o: LeakyReLU already applied inside the layer
-            ph[5] += stamp() - ts5;
         }
-        ph[0] += ts1 - ts0;
-        ph[1] += ts2 - ts1;
-        ph[2] += ts3 - ts2;
-        ph[3] += ts4 - ts3;
-        ph[7] += 1;
-        ph[6] += tsg - ts0;  // (PNR_STAMPS builds) issue time of the gathers; ring.stall_bar holds the barrier stalls
         cur = nxt;
     }
-#if PNR_STAMPS
-    if (lane == 0) {
-        // debug tail of the sigma buffer: [cap - 8192 .. cap) floats hold 8 x u64 per wave for the first 512 waves
-        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(P.smp_sigma + P.dbg_off);
-        const int wid = blockIdx.x * WAVES + wave;
-        if (wid < 256)
-            for (int i = 0; i < 8; ++i) dbg[wid * 8 + i] = ph[i];
-    }
-#endif
     // the two tiles prefetched for a pair tile that does not exist are simply dropped
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }

@@ -46,30 +46,6 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// diagnostic builds only (never shipped; results are wrong by construction): bit0 cheap PE, bit1 no MFMA, bit3 no
-// barrier + no DMA, bit4 no split, bit5 no DMA issue, bit6 no barrier (tools/build_ablate.sh)
-#ifndef PNR_ABLATE
-#define PNR_ABLATE 0
-#endif
-
-// diagnostic builds only: -DPNR_STAMPS=1 accumulates s_memtime deltas of the phases of k_shade_pairs_bf16 per wave
-// and writes them (never into an output) to the tail of the smp_sigma buffer
-#ifndef PNR_STAMPS
-#define PNR_STAMPS 0
-#endif
-__device__ __forceinline__ unsigned long long stamp()
-{
-#if PNR_STAMPS
-    unsigned long long t;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    __builtin_amdgcn_sched_barrier(0);
-    return t;
-#else
-    return 0;
-#endif
-}
-
 constexpr int WAVES = 4;
 constexpr int TPB = WAVES * 64;
 constexpr int PF = 6;  // fp32 path: weight loads (1 KiB each per wave) kept in flight
@@ -105,7 +81,6 @@ struct ShadeParams {
     float *agg;        // [S_valid, 256]
     float4 *smp_out;   // [S_sel]
     int K;
-    long long dbg_off;  // PNR_STAMPS builds: float offset into smp_sigma of the stamp area
     // bf16x3 mode: factorised first layer
     int i_v0, i_v1;        // the kernel works on positions [n_sel[i_v0], n_sel[i_v1]) of vs_list
     float *smp_sig_s;      // [S_sel] density by sample index (early ray termination), may be null
@@ -370,10 +345,7 @@ __device__ __forceinline__ void point_inputs(const float (&e)[16], float *x0)
         float sn = 0.f, cs = 1.f;
 #pragma unroll
         for (int f = 0; f < 3; ++f) {
-            if (PNR_ABLATE & 1) {
-                sn = e[d] * (float)(1 << f);
-                cs = 1.0f - sn;
-            } else if (FAST_PE && f > 0) {
+            if (FAST_PE && f > 0) {
                 // double angle from the previous octave: sin 2a = 2 sin a cos a, cos 2a = (cos a - sin a)(cos a + sin a)
                 const float s2 = 2.0f * sn * cs, c2 = (cs - sn) * (cs + sn);
                 sn = s2;
@@ -432,10 +404,7 @@ __device__ __forceinline__ void pair_inputs(const ShadeParams &P, const RowFetch
         float sn = 0.f, cs = 1.f;
 #pragma unroll
         for (int f = 0; f < 5; ++f) {
-            if (PNR_ABLATE & 1) {
-                sn = dd[d] * (float)(1 << f);
-                cs = 1.0f - sn;
-            } else if (FAST_PE && DOUBLE_ANGLE && f > 0) {
+            if (FAST_PE && DOUBLE_ANGLE && f > 0) {
                 const float s2 = 2.0f * sn * cs, c2 = (cs - sn) * (cs + sn);
                 sn = s2;
                 cs = c2;

@@ -60,12 +60,13 @@ __device__ __forceinline__ void dense_layer(__amdgpu_buffer_rsrc_t rsrc, int wba
 // ================================================================================================
 // The pair kernel as ONE stream of weight groups.
 //
-// k_shade_pairs above runs its four layers as four separate loops: every layer start refills the weight pipeline
-// (first load -> first MFMA: an L2 round trip with the matrix pipe idle), loads its 32 bias float4 and waits for them,
-// and every layer end reads 128 accumulators back, applies LeakyReLU and only then starts the next layer -- 430
-// instructions with no MFMA in flight, three times per tile, plus 1800 instructions of epilogue (density head,
-// K-aggregation, stores) and a prologue whose fifteen libm sincosf calls cost 2200 instructions (their Payne-Hanek
-// argument reduction is computed unconditionally).
+// The first version of this kernel (round 1: four dense_layer calls in a row, as the colour kernel below still does)
+// ran its layers as four separate loops: every layer start refilled the weight pipeline (first load -> first MFMA: an
+// L2 round trip with the matrix pipe idle), loaded its 32 bias float4 and waited for them, and every layer end read
+// 128 accumulators back, applied LeakyReLU and only then started the next layer -- 430 instructions with no MFMA in
+// flight, three times per tile, plus 1800 instructions of epilogue (density head, K-aggregation, stores) and a
+// prologue whose fifteen libm sincosf calls cost 2200 instructions (their Payne-Hanek argument reduction is computed
+// unconditionally).  35.1 ms per 800x800 frame, 0.81 of the fp32 MFMA peak.
 //
 // Here the 840 weight groups of a tile (64 + 256 + 264 + 256 groups of 4 k-steps) form one sequence with a rolling
 // window of PFS loads in flight that never drains -- not at a layer boundary and not at a tile boundary (the window of
@@ -81,6 +82,12 @@ __device__ __forceinline__ void dense_layer(__amdgpu_buffer_rsrc_t rsrc, int wba
 //     tile (three pieces per value, behind three different MFMAs), every fourth one stores its float4 of the
 //     aggregated feature; what is left behind the last MFMA of a tile is the sink of its last 16 values;
 //   * positional encodings use the branch-free Cody-Waite sincos (1e-7 absolute), each octave from its own argument.
+// Measured (s_memtime stamps in a development build): 34.4 ms, 0.83 of the peak; inside the
+// stream an MFMA issues every 72 cycles instead of 64 -- +4.6 cycles from the weight loads (the same stream without
+// loads: 69.6), +5.6 from the pieces between the MFMAs (most of them moves between the two register files: the
+// activations outgrow the 256 architectural VGPRs and live in AGPRs); prologue + epilogue are 7 k of a tile's 249 k
+// cycles.  Sharing the weights of the four waves through an LDS ring (LDS-DMA, one barrier per 32 groups) was built and
+// measured 6 % SLOWER (the DMA pieces cost the issuing wave more than the loads they replace).
 constexpr int PFS = 8;                  // weight groups (1 KiB per wave each) in flight; divides NG_TILE
 constexpr int NG_L1 = 8 * (32 / 4), NG_L2 = 8 * (128 / 4), NG_L3 = 8 * (132 / 4), NG_L4 = 8 * (128 / 4);
 constexpr int NG_TILE = NG_L1 + NG_L2 + NG_L3 + NG_L4;   // 840

@@ -24,17 +24,6 @@
 
 namespace pnr {
 
-// diagnostic builds only (results wrong by construction): bit0 = no epilogue memory traffic, bit1 = no MFMA in the
-// bf16x3 row GEMM
-#ifndef PNR_GEMM_ABL
-#define PNR_GEMM_ABL 0
-#endif
-
-#if PNR_STAMPS
-// diagnostic builds (-DPNR_STAMPS=1): cycle sums of the phases of k_gemm_nt_bf16x3, read with pnr_debug_read
-__device__ unsigned long long g_gemm_dbg[32];
-#endif
-
 // ------------------------------------------------------------------------------------------------
 // fp32 MFMA GEMM   C[M,N] = op(A) . op(B)      (all matrices row-major, leading dimensions multiples of 4)
 //   TA = false: A is [M, K] (tile rows m, contiguous k)     TA = true: A is [K, M] (A'[m][k] = A[k][m])
@@ -107,7 +96,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, const f32x16 (&
         for (int i = 0; i < 8; ++i) {
             const int row = row0 + 4 * i;
             float4 v = *reinterpret_cast<const float4 *>(lds_wave + (rr + 4 * i) * 64 + c4);
-            const bool ok = row < M && col < N && !((PNR_GEMM_ABL & 1) && v.x != 12345.678f);
+            const bool ok = row < M && col < N;
             if (EPI == EPI_BIAS_LEAKY) {
                 v.x += bias.x;
                 v.y += bias.y;
@@ -444,14 +433,9 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16x3(GemmArgs g)
     load_tiles(0);
     store_tiles(0);
     __syncthreads();
-    unsigned long long d_issue = 0, d_mfma = 0, d_store = 0, d_bar = 0;
-    const unsigned long long tl0 = stamp();
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
-        const unsigned long long p0 = stamp();
         if (c + 1 < nchunks) load_tiles((c + 1) * BK);
-        const unsigned long long p1 = stamp();
-        d_issue += p1 - p0;
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
             const int kg = 2 * s + h;
@@ -467,33 +451,14 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16x3(GemmArgs g)
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    if (PNR_GEMM_ABL & 2) {
-                        asm volatile("" ::"v"(ah[a]), "v"(al[a]), "v"(bh[b]), "v"(bl[b]));
-                        continue;
-                    }
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
                 }
         }
-        const unsigned long long p2 = stamp();
-        d_mfma += p2 - p1;
         if (c + 1 < nchunks) store_tiles(buf ^ 1);
-        const unsigned long long p3 = stamp();
-        d_store += p3 - p2;
         __syncthreads();
-        d_bar += stamp() - p3;
     }
-#if PNR_STAMPS
-    if (tid == 0) {
-        atomicAdd(&g_gemm_dbg[0], d_issue);
-        atomicAdd(&g_gemm_dbg[1], d_mfma);
-        atomicAdd(&g_gemm_dbg[2], d_store);
-        atomicAdd(&g_gemm_dbg[3], d_bar);
-        atomicAdd(&g_gemm_dbg[4], (unsigned long long)nchunks);
-        atomicAdd(&g_gemm_dbg[5], stamp() - tl0);
-    }
-#endif
     gemm_epilogue<EPI>(g, acc, M, N, m0, n0, wm, wn, lane, reinterpret_cast<float *>(&planes[0][0][0][0]) + wave * 2048);
     __syncthreads();   // before the next tile's operands overwrite the epilogue regions
     }
@@ -1808,15 +1773,3 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
     return PNR_OK;
 }
 
-#if PNR_STAMPS
-extern "C" int pnr_debug_read(unsigned long long out[32], int reset)
-{
-    PNR_HIP_CHECK(hipDeviceSynchronize());
-    PNR_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(pnr::g_gemm_dbg), 32 * sizeof(unsigned long long)));
-    if (reset) {
-        unsigned long long z[32] = {0};
-        PNR_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(pnr::g_gemm_dbg), z, sizeof(z)));
-    }
-    return PNR_OK;
-}
-#endif
