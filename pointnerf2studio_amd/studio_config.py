@@ -6,13 +6,19 @@ pointnerf/nerfstudio/studio_{config,pipeline,datamanager}.py:
   optimisers    "fields" Adam 5e-4, "neural_points" Adam 2e-3, exp decay 0.1 / 1e6 steps (studio_config.py:33-48)
   datamanager   one image per batch, `metadata["camrotc2w"]` = c2w[:3,:3]      (studio_datamanager.py:62-110)
 
-Everything here needs nerfstudio; without it (the build image) the module still imports and exposes
-METHOD_NAME / OPTIMIZER_GROUPS / the scheduler so the surface can be checked.
+The datamanager's logic (one image per batch, the camera rotation in the bundle's metadata) lives in
+`PointNerfDataManagerMixin`, which only duck-types its collaborators (image dataloader iterator, pixel sampler, ray
+generator, dataset.cameras): it runs -- and is tested, tests/test_studio_config.py -- without nerfstudio.  The classes
+that need nerfstudio's bases (VanillaDataManager, VanillaPipeline, TrainerConfig ...) are thin shells around it,
+defined only where nerfstudio imports.
 """
 from __future__ import annotations
 
+import random
 from dataclasses import dataclass, field
 from typing import Type
+
+import torch
 
 from torch.optim import lr_scheduler
 
@@ -30,11 +36,50 @@ def pointnerf_lr_lambda(lr_decay_exp: float = 0.1, lr_decay_iters: int = 1000000
     return lambda step: pow(lr_decay_exp, step / lr_decay_iters)
 
 
+class PointNerfDataManagerMixin:
+    """studio_datamanager.py:62-110.  Expects of `self` what nerfstudio's VanillaDataManager provides: `config`
+    (random_image_idx), `train_count` / `eval_count`, `iter_{train,eval}_image_dataloader` (iterators of
+    {"image_idx": [n], "image": [n,H,W,3]} batches), `{train,eval}_pixel_sampler.sample(batch)`,
+    `{train,eval}_ray_generator(indices)`, `{train,eval}_dataset.cameras[...]`.camera_to_worlds, `eval_dataloader`."""
+
+    def _one_image(self, loader_iter, count):
+        """One image of the batch: a random one, or image (count - 1) mod n (studio_datamanager.py:66-73,89-96)."""
+        image_batch = next(loader_iter)
+        n = image_batch["image_idx"].shape[0]
+        image_idx = random.randint(0, n - 1) if self.config.random_image_idx else (count - 1) % n
+        sel = torch.nonzero(image_batch["image_idx"] == image_idx).squeeze()
+        return {"image_idx": torch.tensor(image_idx).unsqueeze(0), "image": image_batch["image"][sel].unsqueeze(0)}
+
+    def next_train(self, step: int):
+        self.train_count += 1
+        batch = self.train_pixel_sampler.sample(self._one_image(self.iter_train_image_dataloader, self.train_count))
+        ray_bundle = self.train_ray_generator(batch["indices"])
+        cams = self.train_dataset.cameras[ray_bundle.camera_indices.cpu()]
+        ray_bundle.metadata["camrotc2w"] = cams.camera_to_worlds[0][0][0:3, 0:3]
+        return ray_bundle, batch
+
+    def next_eval(self, step: int):
+        self.eval_count += 1
+        # (the reference indexes the eval image by train_count as well, studio_datamanager.py:92)
+        batch = self.eval_pixel_sampler.sample(self._one_image(self.iter_eval_image_dataloader, self.train_count))
+        ray_bundle = self.eval_ray_generator(batch["indices"])
+        cams = self.eval_dataset.cameras[ray_bundle.camera_indices.cpu()]
+        ray_bundle.metadata["camrotc2w"] = cams.camera_to_worlds[0][0][0:3, 0:3]
+        return ray_bundle, batch
+
+    def next_eval_image(self, step: int):
+        for camera_ray_bundle, batch in self.eval_dataloader:
+            image_idx = int(camera_ray_bundle.camera_indices[0, 0, 0])
+            h, w = camera_ray_bundle.origins.shape[:2]   # the reference hard-codes 800 x 800 (:108)
+            rot = self.eval_dataset.cameras[image_idx].camera_to_worlds[0:3, 0:3]
+            camera_ray_bundle.metadata["camrotc2w"] = rot[None, None].expand(h, w, -1, -1).reshape(h, w, -1)
+            return image_idx, camera_ray_bundle, batch
+        raise ValueError("No more eval images")
+
+
 if HAVE_NERFSTUDIO:  # pragma: no cover - nerfstudio is not installable in the build image
-    import random
     import typing
 
-    import torch
     from nerfstudio.data.datamanagers.base_datamanager import VanillaDataManager, VanillaDataManagerConfig
     from nerfstudio.engine.optimizers import AdamOptimizerConfig
     from nerfstudio.engine.schedulers import Scheduler, SchedulerConfig
@@ -62,41 +107,9 @@ if HAVE_NERFSTUDIO:  # pragma: no cover - nerfstudio is not installable in the b
         near_plane: float = 2.0
         far_plane: float = 6.0
 
-    class PointNerfDataManager(VanillaDataManager):
+    class PointNerfDataManager(PointNerfDataManagerMixin, VanillaDataManager):
         """One image per batch; adds the camera rotation the model needs (studio_datamanager.py:62-110)."""
         config: PointNerfDataManagerConfig
-
-        def _one_image(self, loader_iter, count):
-            image_batch = next(loader_iter)
-            n = image_batch["image_idx"].shape[0]
-            image_idx = random.randint(0, n - 1) if self.config.random_image_idx else (count - 1) % n
-            sel = torch.nonzero(image_batch["image_idx"] == image_idx).squeeze()
-            return {"image_idx": torch.tensor(image_idx).unsqueeze(0), "image": image_batch["image"][sel].unsqueeze(0)}
-
-        def next_train(self, step: int):
-            self.train_count += 1
-            batch = self.train_pixel_sampler.sample(self._one_image(self.iter_train_image_dataloader, self.train_count))
-            ray_bundle = self.train_ray_generator(batch["indices"])
-            cams = self.train_dataset.cameras[ray_bundle.camera_indices.cpu()]
-            ray_bundle.metadata["camrotc2w"] = cams.camera_to_worlds[0][0][0:3, 0:3]
-            return ray_bundle, batch
-
-        def next_eval(self, step: int):
-            self.eval_count += 1
-            batch = self.eval_pixel_sampler.sample(self._one_image(self.iter_eval_image_dataloader, self.train_count))
-            ray_bundle = self.eval_ray_generator(batch["indices"])
-            cams = self.eval_dataset.cameras[ray_bundle.camera_indices.cpu()]
-            ray_bundle.metadata["camrotc2w"] = cams.camera_to_worlds[0][0][0:3, 0:3]
-            return ray_bundle, batch
-
-        def next_eval_image(self, step: int):
-            for camera_ray_bundle, batch in self.eval_dataloader:
-                image_idx = int(camera_ray_bundle.camera_indices[0, 0, 0])
-                h, w = camera_ray_bundle.origins.shape[:2]   # the reference hard-codes 800 x 800
-                rot = self.eval_dataset.cameras[image_idx].camera_to_worlds[0:3, 0:3]
-                camera_ray_bundle.metadata["camrotc2w"] = rot[None, None].expand(h, w, -1, -1).reshape(h, w, -1)
-                return image_idx, camera_ray_bundle, batch
-            raise ValueError("No more eval images")
 
     class PointNerfPipeline(VanillaPipeline):
         """studio_pipeline.py:16-53: hands the cameras to the model, wraps in DDP when world_size > 1."""
