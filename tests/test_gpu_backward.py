@@ -287,6 +287,11 @@ def test_point_gradients_are_bitwise_repeatable_and_sparse_rows_match(oracle, gp
         b = rnd.backward(G, w, N)
         for k in ("embedding", "color", "dir"):
             assert torch.equal(a[k], b[k]), f"{k} differs between two identical backward calls"
+        # ... and so are the MLP gradients (partial tiles + a reducer, no float atomics anywhere in the backward)
+        for name in MLP_TENSOR_ORDER:
+            for suf in (".weight", ".bias"):
+                assert torch.equal(a[name + suf], b[name + suf]), f"{name + suf} differs between two identical calls"
+        assert torch.equal(a["rgb"], b["rgb"])
         sp = rnd.backward(G, w, N, sparse_points=True)
         U = out["counters"]["points_unique"]
         assert sp["point_index"].shape == (U,) and sp["point_grads"].shape == (U, 40)
