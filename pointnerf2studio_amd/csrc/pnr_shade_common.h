@@ -335,7 +335,7 @@ __device__ __forceinline__ void fetch_c_pair(const ShadeParams &P, RowFetch &f)
 }
 
 // the lane's point-only layer-1 inputs: 16 embedding channels and their encodings (x0[0:112])
-template <bool FAST_PE>
+template <bool FAST_PE, bool DOUBLE_ANGLE = true>
 __device__ __forceinline__ void point_inputs(const float (&e)[16], float *x0)
 {
 #pragma unroll
@@ -345,11 +345,13 @@ __device__ __forceinline__ void point_inputs(const float (&e)[16], float *x0)
         float sn = 0.f, cs = 1.f;
 #pragma unroll
         for (int f = 0; f < 3; ++f) {
-            if (FAST_PE && f > 0) {
+            if (FAST_PE && DOUBLE_ANGLE && f > 0) {
                 // double angle from the previous octave: sin 2a = 2 sin a cos a, cos 2a = (cos a - sin a)(cos a + sin a)
                 const float s2 = 2.0f * sn * cs, c2 = (cs - sn) * (cs + sn);
                 sn = s2;
                 cs = c2;
+            } else if (FAST_PE && !DOUBLE_ANGLE) {
+                fast_sincos_nb(e[d] * (float)(1 << f), sn, cs);   // fp32 mode: every octave from its own argument
             } else if (FAST_PE) {
                 fast_sincos(e[d], sn, cs);
             } else {

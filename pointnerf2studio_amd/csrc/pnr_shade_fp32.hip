@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_color(ShadeParams P)
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
                 float sn, cs;
-                sincosf(vv[d] * (float)(1 << f), &sn, &cs);
+                fast_sincos_nb(vv[d] * (float)(1 << f), sn, cs);
                 x[128 + d * 4 + f] = h ? cs : sn;
             }
         float hA[64], hB[64];
@@ -403,7 +403,7 @@ __global__ void __launch_bounds__(TPB, 1) k_point_part_f32(ShadeParams P)
         const float e[16] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w,
                              e2.x, e2.y, e2.z, e2.w, e3.x, e3.y, e3.z, e3.w};
         float x0[112];
-        point_inputs<false>(e, x0);
+        point_inputs<true, false>(e, x0);   // branch-free sincos, 9e-8 absolute (libm's costs 150 instructions a call)
         float o[128];
         dense_layer<112, 8>(rsrc, wa, b0, lane, x0, o);
         float4 *dst = P.pt_table + (int64_t)u * 64 + 4 * h;   // rows beyond U: the table's padding rows

@@ -6,14 +6,15 @@
 //
 // First HIP version of this row: correct and matrix-core bound, not yet fused.  The query products of the
 // preceding pnr_render call (sample lists, neighbour indices) are taken from its workspace; the MLP forward is
-// recomputed (fp32, or bf16x3 as the render's default mode) with every activation kept ROW-MAJOR in HBM (the "tape"),
+// recomputed (fp32 by default, or bf16x3 after a render in that opt-in mode) with every activation kept ROW-MAJOR in HBM (the "tape"),
 // then walked backwards:
 //   * every Linear is one of three shapes of ONE hand-written fp32 MFMA GEMM (k_gemm: 128x128 tiles,
 //     v_mfma_f32_32x32x2_f32, LDS double buffer): forward X.W^T (+bias, LeakyReLU), data gradient dZ.W (times
 //     LeakyReLU' from the taped activation, written IN PLACE over that activation), weight gradient dZ^T.X
-//     (split over the rows, fp32 atomics into a padded buffer);
+//     (split over the rows into partial tiles that a reducer sums: no float atomics);
 //   * small row-parallel kernels for what is not a GEMM: inputs / encodings, density head + K-aggregation,
-//     colour head, composite (reverse scan per ray), and the scatter of point gradients with float atomics.
+//     colour head, composite (reverse scan per ray), and the point gradients (rows grouped by point, one ordered sum
+//     per point).  No float atomic anywhere: every gradient is bitwise repeatable.
 // Frozen tensors (xyz, Rw2c) and the sample positions get no gradient, as in the reference
 // (studio_utils.py:84-103: only embedding / conf / dir / color are Parameters with requires_grad; conf does not
 // enter the render, studio_model.py:285-292).
@@ -298,17 +299,19 @@ __global__ void __launch_bounds__(256, PNR_GEMM_WGS) k_gemm(GemmArgs g)
 
     if (want_csum) {
         // bias gradient: every thread summed the A elements it loaded (columns m0 + 4 (tid & 31) .. + 3, eight threads
-        // per column group): folded in LDS, one partial row per split (global atomics here meant 6 k adds per address)
+        // per column group): the eight partial rows go to LDS and are added in a FIXED order (LDS float atomics would
+        // add them in whatever order the waves arrive: the gradient must be bitwise repeatable), one partial row per
+        // split (global atomics here meant 6 k adds per address)
         float *cs = &As[0][0][0];
-        if (tid < TM) cs[tid] = 0.f;
         __syncthreads();
-        const int c4 = (tid & 31) * 4;
-        atomicAdd(&cs[c4 + 0], csum.x);
-        atomicAdd(&cs[c4 + 1], csum.y);
-        atomicAdd(&cs[c4 + 2], csum.z);
-        atomicAdd(&cs[c4 + 3], csum.w);
+        *reinterpret_cast<float4 *>(&cs[(tid >> 5) * TM + (tid & 31) * 4]) = csum;
         __syncthreads();
-        if (tid < TM && m0 + tid < M) g.colsum[(int64_t)blockIdx.z * g.M + m0 + tid] = cs[tid];
+        if (tid < TM && m0 + tid < M) {
+            float t = cs[tid];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) t += cs[q * TM + tid];
+            g.colsum[(int64_t)blockIdx.z * g.M + m0 + tid] = t;
+        }
         __syncthreads();   // cs lies in the epilogue region of wave 0
     }
     // (the loop's last barrier is behind every read of the operand buffers: they are free for the epilogue)
@@ -746,16 +749,12 @@ __global__ void __launch_bounds__(256, 2) k_gemm_tn_bf16x3(GemmArgs g)
     float *ldsf = reinterpret_cast<float *>(&planes[0][0][0][0]);
     if (g.colsum && blockIdx.y == 0) {   // uniform over the workgroup
         float *cs = ldsf + 4 * 2048;     // behind the four epilogue regions
-        if (tid < TM) cs[tid] = 0.f;
         __syncthreads();
-        if (!isB) {
-            atomicAdd(&cs[q4 + 0], csum.x);
-            atomicAdd(&cs[q4 + 1], csum.y);
-            atomicAdd(&cs[q4 + 2], csum.z);
-            atomicAdd(&cs[q4 + 3], csum.w);
-        }
+        // the four k groups' partial rows, added in a fixed order (no LDS float atomics: bitwise repeatable)
+        if (!isB) *reinterpret_cast<float4 *>(&cs[kg * TM + q4]) = csum;
         __syncthreads();
-        if (tid < TM && m0 + tid < M) g.colsum[(int64_t)blockIdx.z * g.M + m0 + tid] = cs[tid];
+        if (tid < TM && m0 + tid < M)
+            g.colsum[(int64_t)blockIdx.z * g.M + m0 + tid] = ((cs[tid] + cs[TM + tid]) + cs[2 * TM + tid]) + cs[3 * TM + tid];
     }
     GemmArgs gp = g;
     gp.C = g.C + (int64_t)blockIdx.z * g.M * g.ldc;
