@@ -499,21 +499,11 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
     const int SPT = (32 / seg_len<SEG>(P.K)) * WAVES;
     const int V0 = P.n_sel[P.i_v0], S_valid = P.n_sel[P.i_v1];
     const int ntiles = (S_valid - V0 + SPT - 1) / SPT;
-    // XCD-aware tile order.  Workgroup b runs on XCD b % 8 (round-robin dispatch), one workgroup per CU.  In every
-    // round of gridDim.x tiles XCD x takes the 32 CONSECUTIVE tiles [x * G/8, (x+1) * G/8) of the round, one per
-    // CU: the CUs behind one L2 then work on ~45 neighbouring rays at the same time, and the pt_table / point rows
-    // those rays share (a point serves ~7 pairs) are fetched into that L2 once instead of once per pair.  With a
-    // contiguous tile range per workgroup the 32 CUs of an XCD stream 4 MB of unrelated rows through the 4 MB L2 per
-    // tile time and nearly every gather misses (rocprofv3 FETCH_SIZE: 14.9 GB per launch for 10.8 GB gathered).
-#ifdef PNR_AB_CONTIG_TILES  // diagnostic A/B builds only: one contiguous tile range per workgroup
-    const int G = 1;
-    const int t_begin = (int)(((int64_t)ntiles * blockIdx.x) / gridDim.x);
-    const int t_end = (int)(((int64_t)ntiles * (blockIdx.x + 1)) / gridDim.x);
-#else
-    const int G = gridDim.x;
-    const int pos = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
-    const int t_begin = pos, t_end = ntiles;
-#endif
+    // XCD-aware tile order (TileWalk).  With a contiguous tile range per WORKGROUP instead, the 32 CUs of an XCD stream
+    // 4 MB of unrelated rows through the 4 MB L2 per tile time and nearly every gather misses (rocprofv3 FETCH_SIZE:
+    // 14.9 GB per launch for 10.8 GB gathered).
+    const TileWalk walk((int)blockIdx.x, (int)gridDim.x, ntiles);
+    const int t_begin = walk.at(0), t_end = ntiles;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wbuf), 0, (int)P.wbytes, 0x00020000);
     const int wb_ = (int)(P.w16b_off * 4), w1_ = (int)(P.w16_off[1] * 4), w2_ = (int)(P.w16_off[2] * 4),
@@ -537,13 +527,13 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_bf16(ShadeParams P)
     fetch_a<SEG>(P, t_begin, lane, wave, V0, S_valid, cur);
     fetch_b<SEG>(P, cur);
     fetch_c_pair(P, cur);
-    for (int tile = t_begin; tile < t_end; tile += G) {
+    for (int n = 0, tile = t_begin; tile < t_end; tile = walk.at(++n)) {
         int wb = wb_, w1 = w1_, w2 = w2_, w3 = w3_;
         asm volatile("" : "+s"(wb), "+s"(w1), "+s"(w2), "+s"(w3));
         const Camera cam = load_cam_wave(P.cr, cur.cid);
         // first level of the next tile's gather chain (a tile past the end loads row 0: harmless); the other two
         // levels follow at the layer boundaries
-        fetch_a<SEG>(P, tile + G, lane, wave, V0, S_valid, nxt);
+        fetch_a<SEG>(P, walk.at(n + 1), lane, wave, V0, S_valid, nxt);
         __builtin_amdgcn_sched_barrier(0);
         // Point halves of layer 1 (pt_table rows, accumulator order).  A lane reads 512 B in 32 scattered 16-byte
         // loads; 4 waves x 32 of them keep the CU's texture-address unit busy for ~7k cycles (tools/ub_gather.hip)

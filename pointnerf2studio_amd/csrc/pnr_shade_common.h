@@ -184,6 +184,38 @@ __device__ __forceinline__ float dpp_mov(float v)
 // the first K lanes of an 8- / 16-lane segment aligned to the DPP rows (the other lanes of the segment idle: pidx -1,
 // weight 0), so that sums over a sample are DPP steps.  SEG = 0 (K > 16): segments of exactly K lanes, summed with
 // K cross-lane reads.
+// Tile order of the persistent pair kernels.  Workgroup b runs on XCD b % 8 (round-robin dispatch), one workgroup per
+// CU.  The tiles are cut into strips of G/8 consecutive tiles (one per CU of an XCD) and an XCD takes XCD_CHUNK
+// consecutive strips before it jumps over the strips of the other seven: rays that are neighbours in the image share
+// their neural points, and the pt_table rows they gather stay in the L2 of the XCD that fetched them.  Measured on
+// cfg 1 (rocprofv3 FETCH_SIZE of the fp32 pair kernel, per launch): chunk 1 4.75 GB, 4 3.65, 8 3.43, 16 3.37, 32 3.41
+// -- for 1.9 GB of distinct rows; kernel time unchanged (+-0.2 %) once the last, partial super-round is walked strip
+// by strip (without that the XCDs finish up to a chunk apart: chunk 64 ran 10 % longer).
+#ifndef PNR_XCD_CHUNK
+#define PNR_XCD_CHUNK 16
+#endif
+struct TileWalk {
+    int x, j, g8, plain, G, n_full, t_full;
+    __device__ __forceinline__ TileWalk(int block, int grid, int ntiles)
+        : x(block % 8), j(block / 8), g8(grid / 8), plain(grid % 8 != 0 ? block : -1), G(grid)
+    {
+        // whole super-rounds (8 XCDs x XCD_CHUNK strips) are walked chunk by chunk, the rest strip by strip, so that
+        // the XCDs finish within one strip of each other
+        const int per_super = PNR_XCD_CHUNK * grid;
+        const int full = per_super > 0 ? ntiles / per_super : 0;
+        n_full = full * PNR_XCD_CHUNK;
+        t_full = full * per_super;
+    }
+    // the n-th tile of this workgroup; increasing in n
+    __device__ __forceinline__ int at(int n) const
+    {
+        if (plain >= 0) return plain + n * G;
+        constexpr int C = PNR_XCD_CHUNK;
+        if (n >= n_full) return t_full + (n - n_full) * G + x * g8 + j;
+        return ((n / C) * 8 + x) * (C * g8) + (n % C) * g8 + j;
+    }
+};
+
 template <int SEG>
 __device__ __forceinline__ int seg_len(int K)
 {

@@ -176,9 +176,8 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
     const int SPT = (32 / seg_len<SEG>(P.K)) * WAVES;  // samples per workgroup tile
     const int V0 = P.n_sel[P.i_v0], S_valid = P.n_sel[P.i_v1];
     const int ntiles = (S_valid - V0 + SPT - 1) / SPT;
-    // XCD-aware tile order (see k_shade_pairs_bf16)
-    const int G = gridDim.x;
-    const int t_begin = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    const TileWalk walk((int)blockIdx.x, (int)gridDim.x, ntiles);   // XCD-aware tile order
+    const int t_begin = walk.at(0);
 
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wbuf), 0, (int)P.wbytes, 0x00020000);
@@ -196,7 +195,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
         for (int p = 0; p < PFS; ++p) wq[p] = load_w(rsrc, voff, group_off(wb_, p));
     }
 
-    for (int tile = t_begin; tile < ntiles; tile += G) {
+    for (int n = 0, tile = t_begin; tile < ntiles; tile = walk.at(++n)) {
         // opaque per iteration: otherwise the scalar load offsets are hoisted out of this loop and spilled
         WBase wb = wb_;
         asm volatile("" : "+s"(wb.l1), "+s"(wb.l2), "+s"(wb.l3), "+s"(wb.l4));

@@ -1507,7 +1507,6 @@ static void gemm_bf(hipStream_t st, const GemmArgs &g, int m_max)
     const unsigned tiles = (unsigned)((g.N + TN - 1) / TN) * (unsigned)((m_max + TM - 1) / TM);
     const dim3 grid(std::min(tiles, (unsigned)PERSISTENT_WGS));
     const int nch = (g.K + BK - 1) / BK;
-#ifndef PNR_GEMM_ROLLED
     if (nch == 4) {
         hipLaunchKernelGGL((k_gemm_nt_bf16x3_u<EPI, 4>), grid, dim3(256), 0, st, g);
         return;
@@ -1520,7 +1519,6 @@ static void gemm_bf(hipStream_t st, const GemmArgs &g, int m_max)
         hipLaunchKernelGGL((k_gemm_nt_bf16x3_u<EPI, 9>), grid, dim3(256), 0, st, g);
         return;
     }
-#endif
     hipLaunchKernelGGL((k_gemm_nt_bf16x3<EPI>), grid, dim3(256), 0, st, g);
 }
 

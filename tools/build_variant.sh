@@ -1,6 +1,6 @@
 #!/bin/bash
 # Diagnostic: builds pointnerf2studio_amd/_abl/libpnr_<name>.so with extra compiler flags, e.g.
-#   tools/build_variant.sh contig -DPNR_AB_CONTIG_TILES
+#   tools/build_variant.sh xc4 -DPNR_XCD_CHUNK=4
 set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
