@@ -88,7 +88,14 @@ __device__ __forceinline__ void dense_layer(__amdgpu_buffer_rsrc_t rsrc, int wba
 // activations outgrow the 256 architectural VGPRs and live in AGPRs); prologue + epilogue are 7 k of a tile's 249 k
 // cycles.  Sharing the weights of the four waves through an LDS ring (LDS-DMA, one barrier per 32 groups) was built and
 // measured 6 % SLOWER (the DMA pieces cost the issuing wave more than the loads they replace).
-constexpr int PFS = 8;                  // weight groups (1 KiB per wave each) in flight; divides NG_TILE
+#ifndef PNR_PFS
+#define PNR_PFS 6
+#endif
+constexpr int PFS = PNR_PFS;
+#ifndef PNR_FPM
+#define PNR_FPM 4
+#endif
+constexpr int FPM = PNR_FPM;   // activation values sunk behind one MFMA                  // weight groups (1 KiB per wave each) in flight; divides NG_TILE
 constexpr int NG_L1 = 8 * (32 / 4), NG_L2 = 8 * (128 / 4), NG_L3 = 8 * (132 / 4), NG_L4 = 8 * (128 / 4);
 constexpr int NG_TILE = NG_L1 + NG_L2 + NG_L3 + NG_L4;   // 840
 static_assert(NG_TILE % PFS == 0, "the window slot of a group must not depend on the tile");
@@ -167,6 +174,15 @@ __device__ __forceinline__ void layer_stream(__amdgpu_buffer_rsrc_t rsrc, int vo
     }
 }
 
+// pins a value in the accumulator half of the register file.  MFMA B operands may come from there directly, so the
+// activations of every other layer live in AGPRs for their whole life and the two 128-value activation sets never
+// compete for the 256 architectural VGPRs.
+__device__ __forceinline__ float to_a(float v)
+{
+    asm("" : "+a"(v));
+    return v;
+}
+
 template <int SEG>
 __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
 {
@@ -195,22 +211,27 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
         for (int p = 0; p < PFS; ++p) wq[p] = load_w(rsrc, voff, group_off(wb_, p));
     }
 
+    // The gather chain of a tile (vs_list -> smp_pidx / smp_loc -> point row, three dependent latencies) is issued one
+    // tile ahead, one level per layer boundary: vector loads return in order, so by the time a level's consumer runs
+    // its load is older than the whole weight window and costs no wait.
+    RowFetch cur, nxt;
+    if (t_begin < ntiles) {
+        fetch_a<SEG>(P, t_begin, lane, wave, V0, S_valid, cur);
+        fetch_b<SEG>(P, cur);
+        fetch_c_pair(P, cur);
+    }
     for (int n = 0, tile = t_begin; tile < ntiles; tile = walk.at(++n)) {
         // opaque per iteration: otherwise the scalar load offsets are hoisted out of this loop and spilled
         WBase wb = wb_;
         asm volatile("" : "+s"(wb.l1), "+s"(wb.l2), "+s"(wb.l3), "+s"(wb.l4));
         float xq[32];
         RowCtx ctx;
-        const float4 *trow;
+        const float4 *trow = P.pt_table + (int64_t)cur.urow * 64 + 4 * h;
         {
-            RowFetch f;
-            fetch_a<SEG>(P, tile, lane, wave, V0, S_valid, f);
-            fetch_b<SEG>(P, f);
-            fetch_c_pair(P, f);
-            trow = P.pt_table + (int64_t)f.urow * 64 + 4 * h;
-            const Camera cam = load_cam_lanes(P.cr, f.cid);
-            pair_inputs<SEG, true, false>(P, f, cam, lane, xq, ctx);
+            const Camera cam = load_cam_wave(P.cr, cur.cid);   // scalar loads: no wait on the vector-load queue
+            pair_inputs<SEG, true, false>(P, cur, cam, lane, xq, ctx);
         }
+        fetch_a<SEG>(P, walk.at(n + 1), lane, wave, V0, S_valid, nxt);   // a tile past the end loads row 0: harmless
         f32x16 acc[8];
         float X[128], Y[132];
         // ---- layer 1: the 60 encoded distances on top of the point's pt_table row ------------------------------
@@ -229,7 +250,10 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
                 return r;
             },
             [&](int m, int i) {
-                if (m > 0 && i < 16) X[16 * (m - 1) + i] = leaky(acc[m - 1][i]);
+                if (m > 0 && i < 16 / FPM) {
+#pragma unroll
+                    for (int q = 0; q < FPM; ++q) X[16 * (m - 1) + FPM * i + q] = to_a(leaky(acc[m - 1][FPM * i + q]));
+                }
             });
         // ---- layer 2 ---------------------------------------------------------------------------------------------
         {
@@ -238,10 +262,17 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
             layer_stream<128, 8, NG_L1>(
                 rsrc, voff, wb, wq, X, acc, [&](int m) { return bias_ini(b1, m, h); },
                 [&](int m, int i) {
-                    if (m == 0 && i < 16) X[112 + i] = leaky(last[i]);
-                    if (m > 0 && i < 16) Y[16 * (m - 1) + i] = leaky(acc[m - 1][i]);
+                    if (i < 16 / FPM) {
+#pragma unroll
+                        for (int q = 0; q < FPM; ++q) {
+                            const int r = FPM * i + q;
+                            if (m == 0) X[112 + r] = to_a(leaky(last[r]));
+                            else Y[16 * (m - 1) + r] = leaky(acc[m - 1][r]);
+                        }
+                    }
                 });
         }
+        fetch_b<SEG>(P, nxt);
         // ---- layer 3: + the seven extra head inputs --------------------------------------------------------------
         {
             const f32x16 last = acc[7];
@@ -251,14 +282,27 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
             layer_stream<132, 8, NG_L1 + NG_L2>(
                 rsrc, voff, wb, wq, Y, acc, [&](int m) { return bias_ini(b2, m, h); },
                 [&](int m, int i) {
-                    if (m == 0 && i < 16) Y[112 + i] = leaky(last[i]);
-                    if (m > 0 && i < 16) X[16 * (m - 1) + i] = leaky(acc[m - 1][i]);
+                    if (i < 16 / FPM) {
+#pragma unroll
+                        for (int q = 0; q < FPM; ++q) {
+                            const int r = FPM * i + q;
+                            if (m == 0) Y[112 + r] = leaky(last[r]);
+                            else X[16 * (m - 1) + r] = to_a(leaky(acc[m - 1][r]));
+                        }
+                    }
                 });
         }
+        fetch_c_pair(P, nxt);
         // ---- layer 4 + density head + K-aggregation in its shadows ----------------------------------------------
         float part = 0.f;   // this lane's share of <head, w4>
         const bool writer = ctx.row_ok && ctx.slot == 0;
-        float *dst = P.agg + (int64_t)ctx.v_idx * 256;
+        // the sample's aggregated features leave through a buffer store: lanes that do not write carry an offset
+        // beyond the descriptor's range and the hardware drops them -- a branch around a plain store would split the
+        // layer's basic block 32 times per tile
+        const int v_wave = __builtin_amdgcn_readfirstlane(V0 + tile * SPT + wave * (SPT / WAVES));
+        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+            P.agg + (int64_t)v_wave * 256, 0, (SPT / WAVES) * 1024, 0x00020000);
+        const int ooff = writer ? (ctx.v_idx - v_wave) * 1024 + 16 * h : 0x40000000;
         float4 hw[4], hw_nx[4];   // density-head weights of the output tile being sunk / of the next one
         float o4[4], sv = 0.f;
         // value r of output tile t in three pieces, each small enough for one MFMA shadow: (a) LeakyReLU, density
@@ -271,8 +315,14 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
         };
         auto sink_b = [&](int r) { o4[r & 3] = seg_sum<SEG>(sv, K, lane); };
         auto sink_c = [&](int t, int r) {
-            if ((r & 3) == 3 && writer)
-                *reinterpret_cast<float4 *>(dst + 32 * t + 8 * (r >> 2) + 4 * h) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+            if ((r & 3) == 3) {
+                u32x4 v;
+                v.x = __float_as_uint(o4[0]);
+                v.y = __float_as_uint(o4[1]);
+                v.z = __float_as_uint(o4[2]);
+                v.w = __float_as_uint(o4[3]);
+                __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, ooff, 128 * t + 32 * (r >> 2), 0);
+            }
         };
         {
             const f32x16 last = acc[7];
@@ -282,7 +332,10 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
             layer_stream<128, 8, NG_L1 + NG_L2 + NG_L3>(
                 rsrc, voff, wb, wq, X, acc, [&](int m) { return bias_ini(b3, m, h); },
                 [&](int m, int i) {
-                    if (m == 0 && i < 16) X[112 + i] = leaky(last[i]);
+                    if (m == 0 && i < 16 / FPM) {
+#pragma unroll
+                        for (int q = 0; q < FPM; ++q) X[112 + FPM * i + q] = to_a(leaky(last[FPM * i + q]));
+                    }
                     if (m > 0 && i == 0) {
                         // the head weights of tile m - 1 become current, those of tile m are fetched
 #pragma unroll
@@ -313,6 +366,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
             P.smp_sigma[ctx.v_idx] = sigma;
             if (P.smp_sig_s) P.smp_sig_s[ctx.s] = sigma;
         }
+        cur = nxt;
     }
 }
 
