@@ -33,6 +33,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wall", "-Wno-unused-function", "-I", INCLUDE, "-I", CSRC]
 
 
+# per-file additions.  pnr_shade_fp32.hip: MFMA results in VGPRs rather than AGPRs -- every output value of the MLP is
+# read by vector-ALU code (LeakyReLU) right away, and one wave per SIMD does not overlap its own VALU and MFMA work
+# (tools/ub_mfma_dep.hip): the 512 v_accvgpr_read per tile that the AGPR form needs cost their full issue time.
+FILE_FLAGS = {"pnr_shade_fp32.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+
+
 def hipcc() -> str:
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
@@ -57,7 +63,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + headers):
-            jobs.append([cc, *FLAGS, "-c", s, "-o", o])
+            jobs.append([cc, *FLAGS, *FILE_FLAGS.get(src, []), "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

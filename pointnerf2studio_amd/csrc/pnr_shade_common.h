@@ -62,6 +62,16 @@ __device__ __forceinline__ float leaky(float x)
     return r;
 }
 
+// two LeakyReLUs with one packed multiply (v_pk_mul_f32: the same IEEE product as two v_mul_f32)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void leaky2(float a, float b, float &ra, float &rb)
+{
+    const f32x2 x = {a, b};
+    const f32x2 y = x * 0.1f;
+    asm("v_max_f32 %0, %1, %2" : "=v"(ra) : "v"(a), "v"(y.x));
+    asm("v_max_f32 %0, %1, %2" : "=v"(rb) : "v"(b), "v"(y.y));
+}
+
 struct ShadeParams {
     const float4 *point_rows;  // [N, 12] float4: a0 | c0 | c1 | pad | emb[8]
     const float *wbuf;         // packed weights (fp32 A-operand order, bf16x3 tiles, plain heads, biases)

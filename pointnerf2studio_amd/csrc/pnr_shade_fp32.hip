@@ -95,7 +95,8 @@ constexpr int PFS = PNR_PFS;
 #ifndef PNR_FPM
 #define PNR_FPM 4
 #endif
-constexpr int FPM = PNR_FPM;   // activation values sunk behind one MFMA                  // weight groups (1 KiB per wave each) in flight; divides NG_TILE
+constexpr int FPM = PNR_FPM;   // activation values sunk behind one MFMA (even: LeakyReLU runs on pairs)
+static_assert(FPM % 2 == 0 && 16 % FPM == 0, "");                  // weight groups (1 KiB per wave each) in flight; divides NG_TILE
 constexpr int NG_L1 = 8 * (32 / 4), NG_L2 = 8 * (128 / 4), NG_L3 = 8 * (132 / 4), NG_L4 = 8 * (128 / 4);
 constexpr int NG_TILE = NG_L1 + NG_L2 + NG_L3 + NG_L4;   // 840
 static_assert(NG_TILE % PFS == 0, "the window slot of a group must not depend on the tile");
@@ -252,7 +253,12 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
             [&](int m, int i) {
                 if (m > 0 && i < 16 / FPM) {
 #pragma unroll
-                    for (int q = 0; q < FPM; ++q) X[16 * (m - 1) + FPM * i + q] = to_a(leaky(acc[m - 1][FPM * i + q]));
+                    for (int q = 0; q < FPM; q += 2) {
+                        float u, v;
+                        leaky2(acc[m - 1][FPM * i + q], acc[m - 1][FPM * i + q + 1], u, v);
+                        X[16 * (m - 1) + FPM * i + q] = to_a(u);
+                        X[16 * (m - 1) + FPM * i + q + 1] = to_a(v);
+                    }
                 }
             });
         // ---- layer 2 ---------------------------------------------------------------------------------------------
@@ -264,10 +270,16 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
                 [&](int m, int i) {
                     if (i < 16 / FPM) {
 #pragma unroll
-                        for (int q = 0; q < FPM; ++q) {
+                        for (int q = 0; q < FPM; q += 2) {
                             const int r = FPM * i + q;
-                            if (m == 0) X[112 + r] = to_a(leaky(last[r]));
-                            else Y[16 * (m - 1) + r] = leaky(acc[m - 1][r]);
+                            float u, v;
+                            if (m == 0) {
+                                leaky2(last[r], last[r + 1], u, v);
+                                X[112 + r] = to_a(u);
+                                X[113 + r] = to_a(v);
+                            } else {
+                                leaky2(acc[m - 1][r], acc[m - 1][r + 1], Y[16 * (m - 1) + r], Y[16 * (m - 1) + r + 1]);
+                            }
                         }
                     }
                 });
@@ -284,10 +296,16 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
                 [&](int m, int i) {
                     if (i < 16 / FPM) {
 #pragma unroll
-                        for (int q = 0; q < FPM; ++q) {
+                        for (int q = 0; q < FPM; q += 2) {
                             const int r = FPM * i + q;
-                            if (m == 0) Y[112 + r] = leaky(last[r]);
-                            else X[16 * (m - 1) + r] = to_a(leaky(acc[m - 1][r]));
+                            float u, v;
+                            if (m == 0) {
+                                leaky2(last[r], last[r + 1], Y[112 + r], Y[113 + r]);
+                            } else {
+                                leaky2(acc[m - 1][r], acc[m - 1][r + 1], u, v);
+                                X[16 * (m - 1) + r] = to_a(u);
+                                X[16 * (m - 1) + r + 1] = to_a(v);
+                            }
                         }
                     }
                 });
@@ -304,24 +322,63 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
             P.agg + (int64_t)v_wave * 256, 0, (SPT / WAVES) * 1024, 0x00020000);
         const int ooff = writer ? (ctx.v_idx - v_wave) * 1024 + 16 * h : 0x40000000;
         float4 hw[4], hw_nx[4];   // density-head weights of the output tile being sunk / of the next one
-        float o4[4], sv = 0.f;
-        // value r of output tile t in three pieces, each small enough for one MFMA shadow: (a) LeakyReLU, density
-        // product, neighbour weight; (b) the K-sum's DPP steps; (c) every fourth value: the float4 store
-        auto sink_a = [&](int r, float a) {
+        float o4[4];
+        // One output value of the finished tile per 8 MFMAs, ALL of its work behind one MFMA: every gap between two
+        // MFMAs that holds vector-ALU work costs ~18 cycles plus ~4.5 per further instruction (tools/ub_mfma_dep.hip:
+        // one wave per SIMD does not overlap its own VALU and MFMA work), so the sink is 7 instructions in one place:
+        // LeakyReLU (2), density product (1), neighbour weight (1) and the three fused DPP adds of the K-sum, which run
+        // as a pipeline over consecutive values (p1 -> p2 -> p3): each add reads a register written one value earlier,
+        // so no wait states are needed between them.  Value L = 16 t + r leaves the pipeline NS values later; every
+        // fourth one completes a float4 that is stored.
+        constexpr int NS = SEG == 16 ? 4 : 3;
+        float p1 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f;
+        auto store4 = [&](int L) {
+            u32x4 v;
+            v.x = __float_as_uint(o4[0]);
+            v.y = __float_as_uint(o4[1]);
+            v.z = __float_as_uint(o4[2]);
+            v.w = __float_as_uint(o4[3]);
+            __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, ooff, 128 * (L >> 4) + 32 * ((L & 15) >> 2), 0);
+        };
+        auto stage = [&](int L) {   // value L leaves the pipeline, the others advance one step
+            float s, n3, n2, n4 = 0.f;
+            if (SEG == 16) {
+                asm volatile("s_nop 1\n\t"
+                             "v_add_f32_dpp %0, %4, %4 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                             "v_add_f32_dpp %1, %5, %5 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                             "v_add_f32_dpp %2, %6, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                             "v_add_f32_dpp %3, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                             : "=&v"(s), "=&v"(n4), "=&v"(n3), "=&v"(n2)
+                             : "v"(p4), "v"(p3), "v"(p2), "v"(p1));
+            } else {
+                asm volatile("s_nop 1\n\t"
+                             "v_add_f32_dpp %0, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                             "v_add_f32_dpp %1, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                             "v_add_f32_dpp %2, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                             : "=&v"(s), "=&v"(n3), "=&v"(n2)
+                             : "v"(p3), "v"(p2), "v"(p1));
+            }
+            p4 = n4;
+            p3 = n3;
+            p2 = n2;
+            if (L >= 0) {
+                o4[L & 3] = s;
+                if ((L & 3) == 3) store4(L);
+            }
+        };
+        float sv = 0.f;
+        auto sink = [&](int t, int r, float a) {
             const float v = leaky(a);
             const float4 w = hw[r >> 2];
             part += v * ((r & 3) == 0 ? w.x : (r & 3) == 1 ? w.y : (r & 3) == 2 ? w.z : w.w);
-            sv = v * ctx.wgt;
-        };
-        auto sink_b = [&](int r) { o4[r & 3] = seg_sum<SEG>(sv, K, lane); };
-        auto sink_c = [&](int t, int r) {
-            if ((r & 3) == 3) {
-                u32x4 v;
-                v.x = __float_as_uint(o4[0]);
-                v.y = __float_as_uint(o4[1]);
-                v.z = __float_as_uint(o4[2]);
-                v.w = __float_as_uint(o4[3]);
-                __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, ooff, 128 * t + 32 * (r >> 2), 0);
+            if (SEG != 0) {
+                stage(16 * t + r - NS);
+                p1 = v * ctx.wgt;
+            } else {
+                // K > 16: the sample's rows are not a DPP segment; shuffle sum per value
+                sv = v * ctx.wgt;
+                o4[r & 3] = seg_sum<SEG>(sv, K, lane);
+                if ((r & 3) == 3) store4(16 * t + r);
             }
         };
         {
@@ -334,7 +391,12 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
                 [&](int m, int i) {
                     if (m == 0 && i < 16 / FPM) {
 #pragma unroll
-                        for (int q = 0; q < FPM; ++q) X[112 + FPM * i + q] = to_a(leaky(last[FPM * i + q]));
+                        for (int q = 0; q < FPM; q += 2) {
+                            float u, v;
+                            leaky2(last[FPM * i + q], last[FPM * i + q + 1], u, v);
+                            X[112 + FPM * i + q] = to_a(u);
+                            X[113 + FPM * i + q] = to_a(v);
+                        }
                     }
                     if (m > 0 && i == 0) {
                         // the head weights of tile m - 1 become current, those of tile m are fetched
@@ -344,20 +406,21 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
                         for (int q = 0; q < 4; ++q)
                             hw_nx[q] = *reinterpret_cast<const float4 *>(w4t + (m * 2 + h) * 16 + 4 * q);
                     }
-                    // value r of output tile m - 1 behind MFMAs 8r + 2 / + 4 / + 6 of tile m (16 values, 128 MFMAs)
-                    if (m > 0 && (i & 7) == 2) sink_a(i >> 3, acc[m - 1][i >> 3]);
-                    if (m > 0 && (i & 7) == 4) sink_b(i >> 3);
-                    if (m > 0 && (i & 7) == 6) sink_c(m - 1, i >> 3);
+                    // value r of output tile m - 1 behind MFMA 8r + 4 of tile m (16 values, 128 MFMAs)
+                    if (m > 0 && (i & 7) == 4) sink(m - 1, i >> 3, acc[m - 1][i >> 3]);
                 });
         }
-        // behind the tile's last MFMA: the sink of output tile 7
+        // behind the tile's last MFMA: the sink of output tile 7, then the pipeline drains
 #pragma unroll
         for (int q = 0; q < 4; ++q) hw[q] = hw_nx[q];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            sink_a(r, acc[7][r]);
-            sink_b(r);
-            sink_c(7, r);
+        for (int r = 0; r < 16; ++r) sink(7, r, acc[7][r]);
+        if (SEG != 0) {
+#pragma unroll
+            for (int e = 0; e < NS; ++e) {
+                stage(128 - NS + e);
+                p1 = 0.f;
+            }
         }
         part += __shfl_xor(part, 32, 64);
         const float alpha = fmaxf(part + b4, 0.f);
