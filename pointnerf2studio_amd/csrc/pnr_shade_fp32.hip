@@ -70,33 +70,43 @@ __device__ __forceinline__ void dense_layer(__amdgpu_buffer_rsrc_t rsrc, int wba
 //
 // Here the 840 weight groups of a tile (64 + 256 + 264 + 256 groups of 4 k-steps) form one sequence with a rolling
 // window of PFS loads in flight that never drains -- not at a layer boundary and not at a tile boundary (the window of
-// the next tile's first groups fills during this tile's last groups).  Everything that is not an MFMA is cut in
-// pieces of a few VALU instructions and placed BEHIND individual MFMAs, where an in-order wave can issue them while
-// the matrix pipe works (a 32x32x2 fp32 MFMA holds the pipe for 64 cycles):
-//   * the activation of output tile m (16 x read accumulator, LeakyReLU, write the next layer's operand) runs in the
-//     shadow of tile m + 1's first 16 MFMAs -- of the NEXT layer's tile 0 for the last tile (its values are that
-//     layer's k-steps 112..127, 448 MFMAs away);
-//   * the accumulator initial values (bias, 16 per lane and output tile) are loaded one output tile ahead;
-//   * the last layer's outputs never form an array: each finished value goes through LeakyReLU, the density-head
-//     product, the neighbour weight and the three DPP steps of the K-sum in MFMA shadows of the following output
-//     tile (three pieces per value, behind three different MFMAs), every fourth one stores its float4 of the
-//     aggregated feature; what is left behind the last MFMA of a tile is the sink of its last 16 values;
+// the next tile's first groups fills during this tile's last groups).
+//
+// What shapes everything else (tools/ub_mfma_dep.hip): a SIMD does NOT overlap vector-ALU work
+// with MFMA work -- not within a wave, not across two waves.  A dependent chain of v_mfma_f32_32x32x2_f32 with a
+// 1-KiB weight load per 4 MFMAs and its B operands in AGPRs runs at 65.3 cycles per MFMA (0.98 of the pipe), scalar
+// and memory instructions between the MFMAs are free, but every VALU instruction costs its own issue time, and every
+// MFMA-to-MFMA gap that holds VALU work costs ~18 cycles on top.  So the kernel minimises the NUMBER of VALU
+// instructions and the number of places they sit in:
+//   * MFMA results live in VGPRs (this file is built with -amdgpu-mfma-vgpr-form): LeakyReLU reads them directly,
+//     no v_accvgpr_read; the activations of every other layer are pinned in AGPRs (to_a), where the MFMA reads its B
+//     operand directly -- the two 128-value activation sets never compete for the 256 architectural VGPRs;
+//   * the activation of output tile m (16 values: packed multiply, max, AGPR write) is ONE block behind the first MFMA
+//     of tile m + 1 -- of the NEXT layer's tile 0 for the last tile (its values are that layer's k-steps 112..127);
+//   * the accumulator initial values (bias / pt_table rows, 16 per lane and output tile) are loaded one output tile
+//     ahead, straight into the registers the MFMA accumulates in;
+//   * the last layer's outputs never form an array: the 16 finished values of an output tile go through LeakyReLU, the
+//     density-head product, the neighbour weight and the K-sum in one block, 7 instructions per value: the three DPP
+//     adds are fused (v_add_f32_dpp) and run as a pipeline over consecutive values, so none reads a register written
+//     by its predecessor; every fourth value stores a float4 of the aggregated feature through a buffer descriptor
+//     (non-writing lanes carry an out-of-range offset: no branch);
+//   * the gather chain of the NEXT tile is issued one dependent level per layer boundary;
 //   * positional encodings use the branch-free Cody-Waite sincos (1e-7 absolute), each octave from its own argument.
-// Measured (s_memtime stamps in a development build): 34.4 ms, 0.83 of the peak; inside the
-// stream an MFMA issues every 72 cycles instead of 64 -- +4.6 cycles from the weight loads (the same stream without
-// loads: 69.6), +5.6 from the pieces between the MFMAs (most of them moves between the two register files: the
-// activations outgrow the 256 architectural VGPRs and live in AGPRs); prologue + epilogue are 7 k of a tile's 249 k
-// cycles.  Sharing the weights of the four waves through an LDS ring (LDS-DMA, one barrier per 32 groups) was built and
+// 9 700 instructions per tile for 3 360 MFMAs, ~2 600 of them VALU.  33.1 ms per 800x800 frame (round 1: 35.3).
+// Sharing the weights of the four waves through an LDS ring (LDS-DMA, one barrier per 32 groups) was built and
 // measured 6 % SLOWER (the DMA pieces cost the issuing wave more than the loads they replace).
 #ifndef PNR_PFS
-#define PNR_PFS 6
+#define PNR_PFS 6   // weight groups (1 KiB per wave each) in flight; divides NG_TILE (5 / 6 / 8 / 12 measured equal)
 #endif
 constexpr int PFS = PNR_PFS;
-#ifndef PNR_FPM
-#define PNR_FPM 4
+#ifndef PNR_SINK_PER
+#define PNR_SINK_PER 16   // layer-4 output values sunk in one place (1 / 2 / 4 / 16: 33.2 / 33.1 / 33.1 / 33.06 ms)
 #endif
-constexpr int FPM = PNR_FPM;   // activation values sunk behind one MFMA (even: LeakyReLU runs on pairs)
-static_assert(FPM % 2 == 0 && 16 % FPM == 0, "");                  // weight groups (1 KiB per wave each) in flight; divides NG_TILE
+#ifndef PNR_FPM
+#define PNR_FPM 16        // activation values of layers 1-3 behind one MFMA (even: LeakyReLU runs on pairs)
+#endif
+constexpr int FPM = PNR_FPM;
+static_assert(FPM % 2 == 0 && 16 % FPM == 0, "");
 constexpr int NG_L1 = 8 * (32 / 4), NG_L2 = 8 * (128 / 4), NG_L3 = 8 * (132 / 4), NG_L4 = 8 * (128 / 4);
 constexpr int NG_TILE = NG_L1 + NG_L2 + NG_L3 + NG_L4;   // 840
 static_assert(NG_TILE % PFS == 0, "the window slot of a group must not depend on the tile");
@@ -407,7 +417,17 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
                             hw_nx[q] = *reinterpret_cast<const float4 *>(w4t + (m * 2 + h) * 16 + 4 * q);
                     }
                     // value r of output tile m - 1 behind MFMA 8r + 4 of tile m (16 values, 128 MFMAs)
+#if PNR_SINK_PER == 1
                     if (m > 0 && (i & 7) == 4) sink(m - 1, i >> 3, acc[m - 1][i >> 3]);
+#else
+                    if (m > 0 && (i % (8 * PNR_SINK_PER)) == 4) {
+#pragma unroll
+                        for (int e = 0; e < PNR_SINK_PER; ++e) {
+                            const int r = (i / (8 * PNR_SINK_PER)) * PNR_SINK_PER + e;
+                            sink(m - 1, r, acc[m - 1][r]);
+                        }
+                    }
+#endif
                 });
         }
         // behind the tile's last MFMA: the sink of output tile 7, then the pipeline drains

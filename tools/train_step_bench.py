@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", default="bf16x3", choices=["fp32", "bf16x3"])
+    ap.add_argument("--mode", default="fp32", choices=["fp32", "bf16x3"])
     ap.add_argument("--skip-autograd", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
