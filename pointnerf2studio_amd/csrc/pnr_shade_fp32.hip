@@ -326,11 +326,15 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
         const bool writer = ctx.row_ok && ctx.slot == 0;
         // the sample's aggregated features leave through a buffer store: lanes that do not write carry an offset
         // beyond the descriptor's range and the hardware drops them -- a branch around a plain store would split the
-        // layer's basic block 32 times per tile
+        // layer's basic block 32 times per tile.  Layout: agg_idx4 (whole blocks of 32 samples, one contiguous KiB per
+        // load of the colour kernel).
         const int v_wave = __builtin_amdgcn_readfirstlane(V0 + tile * SPT + wave * (SPT / WAVES));
         const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
-            P.agg + (int64_t)v_wave * 256, 0, (SPT / WAVES) * 1024, 0x00020000);
-        const int ooff = writer ? (ctx.v_idx - v_wave) * 1024 + 16 * h : 0x40000000;
+            P.agg + (int64_t)(v_wave >> 5) * 8192, 0, 65536, 0x00020000);
+        // (a wave's samples are consecutive: they lie in the block of the first one or, when a pass of the
+        // early-termination loop starts at an odd sample, in the next)
+        const int ooff =
+            writer ? 32768 * ((ctx.v_idx >> 5) - (v_wave >> 5)) + 16 * (ctx.v_idx & 31) + 1024 * h : 0x40000000;
         float4 hw[4], hw_nx[4];   // density-head weights of the output tile being sunk / of the next one
         float o4[4];
         // One output value of the finished tile per 8 MFMAs, ALL of its work behind one MFMA: every gap between two
@@ -348,7 +352,9 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
             v.y = __float_as_uint(o4[1]);
             v.z = __float_as_uint(o4[2]);
             v.w = __float_as_uint(o4[3]);
-            __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, ooff, 128 * (L >> 4) + 32 * ((L & 15) >> 2), 0);
+            // features 32 t + 8 q + 4 h + {0..3} -> chunk (k = 2 t + (q >> 1), hp = h, half q & 1) of the sample's block
+            const int t = L >> 4, q = (L & 15) >> 2;
+            __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, ooff, 2048 * (2 * t + (q >> 1)) + 512 * (q & 1), 0);
         };
         auto stage = [&](int L) {   // value L leaves the pipeline, the others advance one step
             float s, n3, n2, n4 = 0.f;
@@ -475,11 +481,13 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_color(ShadeParams P)
         const bool ok = v_idx < S_valid;
         const int s = ok ? P.vs_list[v_idx] : 0;
         const int ray = P.smp_ray[s];
-        const float *src = P.agg + (int64_t)(ok ? v_idx : 0) * 256;
+        const float4 *agg4 = reinterpret_cast<const float4 *>(P.agg);
+        const int vs = ok ? v_idx : 0;
         float x[140];
 #pragma unroll
         for (int c = 0; c < 32; ++c) {
-            const float4 a = *reinterpret_cast<const float4 *>(src + 8 * c + 4 * h);
+            // features 8 c + 4 h + {0..3}: one contiguous 512 B per lane half and load (agg_idx4)
+            const float4 a = agg4[agg_idx4(vs, 2 * (c >> 2) + ((c & 3) >> 1), h, c & 1)];
             x[4 * c + 0] = a.x;
             x[4 * c + 1] = a.y;
             x[4 * c + 2] = a.z;
