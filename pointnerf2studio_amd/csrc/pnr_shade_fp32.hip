@@ -7,60 +7,10 @@ namespace pnr {
 // ================================================================================================
 // fp32 mode
 // ================================================================================================
-// One dense layer.  in[KSP] are this lane's B-operand registers (k-step t: the lane supplies one input
-// feature of its row), out[MT*16] the accumulators.  The layer's packed A operands ([MT][KSP/4][64 lanes]
-// float4) start at byte offset wbase of the weight buffer: buffer loads with the wave-uniform offset in an
-// SGPR, so the ~1000 loads of an unrolled layer share ONE address VGPR (with 64-bit global addresses hipcc
-// hoists a distinct address pair per load out of the tile loop and spills ~2000 VGPRs).
-// `init` (per lane: float4 index 8m + q = accumulator values 4q..4q+3 of output tile m, the pt_table row of the
-// lane's pair) replaces the bias when the layer continues a sum started elsewhere.
-template <int KSP, int MT>
-__device__ __forceinline__ void dense_layer(__amdgpu_buffer_rsrc_t rsrc, int wbase, const float *__restrict__ bias,
-                                            int lane, const float (&in)[KSP], float (&out)[MT * 16],
-                                            const float4 *__restrict__ init = nullptr)
-{
-    static_assert(KSP % 4 == 0, "k-steps are packed in groups of 4");
-    constexpr int KG = KSP / 4;
-    constexpr int NG = MT * KG;
-    const int h = lane >> 5;
-    const int voff = lane * 16;
-    f32x16 acc[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 b = init ? init[8 * m + q] : *reinterpret_cast<const float4 *>(bias + 32 * m + 8 * q + 4 * h);
-            acc[m][4 * q + 0] = b.x;
-            acc[m][4 * q + 1] = b.y;
-            acc[m][4 * q + 2] = b.z;
-            acc[m][4 * q + 3] = b.w;
-        }
-    }
-    float4 wq[PF];
-#pragma unroll
-    for (int p = 0; p < PF; ++p) wq[p] = load_w(rsrc, voff, wbase + p * 1024);
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const int m = g / KG, kg = g % KG;
-        const float4 w = wq[g % PF];
-        if (g + PF < NG) wq[g % PF] = load_w(rsrc, voff, wbase + (g + PF) * 1024);
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, in[4 * kg + 0], acc[m], 0, 0, 0);
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, in[4 * kg + 1], acc[m], 0, 0, 0);
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, in[4 * kg + 2], acc[m], 0, 0, 0);
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, in[4 * kg + 3], acc[m], 0, 0, 0);
-        // pin the schedule: keep the rolling window of PF loads in flight, nothing hoisted further
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) out[m * 16 + r] = acc[m][r];
-}
-
 // ================================================================================================
 // The pair kernel as ONE stream of weight groups.
 //
-// The first version of this kernel (round 1: four dense_layer calls in a row, as the colour kernel below still does)
+// The first version of this kernel (round 1: four separate layer loops)
 // ran its layers as four separate loops: every layer start refilled the weight pipeline (first load -> first MFMA: an
 // L2 round trip with the matrix pipe idle), loaded its 32 bias float4 and waited for them, and every layer end read
 // 128 accumulators back, applied LeakyReLU and only then started the next layer -- 430 instructions with no MFMA in
@@ -151,11 +101,12 @@ __device__ __forceinline__ Ini bias_ini(const float *__restrict__ bias, int m, i
     return b;
 }
 
-// One layer of the stream.  G0: index of its first weight group in the tile stream.  `in`: the lane's B operands.
-// acc[0] must hold the initial values of output tile 0 on entry -- tile m + 1's are fetched by `next_ini(m + 1)`
-// during tile m; `fill(m, i)` runs behind MFMA i (0 .. 4 KG - 1) of output tile m.
-template <int KSP, int MT, int G0, typename NextIni, typename Fill>
-__device__ __forceinline__ void layer_stream(__amdgpu_buffer_rsrc_t rsrc, int voff, const WBase &wb, float4 (&wq)[PFS],
+// One layer of a stream.  G0: index of its first weight group in the tile stream; `off(G)`: byte offset of group G
+// (G up to one window past the tile's last group: the next tile, same weights); PF: loads in flight.  `in`: the lane's
+// B operands.  acc[0] must hold the initial values of output tile 0 on entry -- tile m + 1's are fetched by
+// `next_ini(m + 1)` during tile m; `fill(m, i)` runs behind MFMA i (0 .. 4 KG - 1) of output tile m.
+template <int KSP, int MT, int G0, int PF, typename Off, typename NextIni, typename Fill>
+__device__ __forceinline__ void layer_stream(__amdgpu_buffer_rsrc_t rsrc, int voff, Off off, float4 (&wq)[PF],
                                              const float (&in)[KSP], f32x16 (&acc)[MT], NextIni next_ini, Fill fill)
 {
     static_assert(KSP % 4 == 0, "k-steps are packed in groups of 4");
@@ -167,8 +118,8 @@ __device__ __forceinline__ void layer_stream(__amdgpu_buffer_rsrc_t rsrc, int vo
 #pragma unroll
         for (int kg = 0; kg < KG; ++kg) {
             const int G = G0 + m * KG + kg;
-            const float4 w = wq[G % PFS];
-            wq[G % PFS] = load_w(rsrc, voff, group_off(wb, G + PFS));
+            const float4 w = wq[G % PF];
+            wq[G % PF] = load_w(rsrc, voff, off(G + PF));
             if (kg == 0 && m + 1 < MT) nx = next_ini(m + 1);
             acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, in[4 * kg + 0], acc[m], 0, 0, 0);
             fill(m, 4 * kg + 0);
@@ -178,8 +129,7 @@ __device__ __forceinline__ void layer_stream(__amdgpu_buffer_rsrc_t rsrc, int vo
             fill(m, 4 * kg + 2);
             acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, in[4 * kg + 3], acc[m], 0, 0, 0);
             fill(m, 4 * kg + 3);
-            // one scheduling region per group: the compiler interleaves the group's pieces with its four MFMAs (a
-            // barrier behind every MFMA measured 3 % slower, none at all lets it hoist the loads of a whole layer)
+            // one scheduling region per group: the loads of a whole layer must not be hoisted to its top
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -235,6 +185,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
         // opaque per iteration: otherwise the scalar load offsets are hoisted out of this loop and spilled
         WBase wb = wb_;
         asm volatile("" : "+s"(wb.l1), "+s"(wb.l2), "+s"(wb.l3), "+s"(wb.l4));
+        const auto goff = [&](int G) { return group_off(wb, G); };
         float xq[32];
         RowCtx ctx;
         const float4 *trow = P.pt_table + (int64_t)cur.urow * 64 + 4 * h;
@@ -252,8 +203,8 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
             for (int q = 0; q < 4; ++q) r0.v[q] = trow[q];
             acc[0] = acc_from(r0);
         }
-        layer_stream<32, 8, 0>(
-            rsrc, voff, wb, wq, xq, acc,
+        layer_stream<32, 8, 0, PFS>(
+            rsrc, voff, goff, wq, xq, acc,
             [&](int m) {
                 Ini r;
 #pragma unroll
@@ -275,8 +226,8 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
         {
             const f32x16 last = acc[7];
             acc[0] = acc_from(bias_ini(b1, 0, h));
-            layer_stream<128, 8, NG_L1>(
-                rsrc, voff, wb, wq, X, acc, [&](int m) { return bias_ini(b1, m, h); },
+            layer_stream<128, 8, NG_L1, PFS>(
+                rsrc, voff, goff, wq, X, acc, [&](int m) { return bias_ini(b1, m, h); },
                 [&](int m, int i) {
                     if (i < 16 / FPM) {
 #pragma unroll
@@ -301,8 +252,8 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
 #pragma unroll
             for (int i = 0; i < 4; ++i) Y[128 + i] = ctx.ex[i];
             acc[0] = acc_from(bias_ini(b2, 0, h));
-            layer_stream<132, 8, NG_L1 + NG_L2>(
-                rsrc, voff, wb, wq, Y, acc, [&](int m) { return bias_ini(b2, m, h); },
+            layer_stream<132, 8, NG_L1 + NG_L2, PFS>(
+                rsrc, voff, goff, wq, Y, acc, [&](int m) { return bias_ini(b2, m, h); },
                 [&](int m, int i) {
                     if (i < 16 / FPM) {
 #pragma unroll
@@ -402,8 +353,8 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
             acc[0] = acc_from(bias_ini(b3, 0, h));
 #pragma unroll
             for (int q = 0; q < 4; ++q) hw_nx[q] = *reinterpret_cast<const float4 *>(w4t + (0 * 2 + h) * 16 + 4 * q);
-            layer_stream<128, 8, NG_L1 + NG_L2 + NG_L3>(
-                rsrc, voff, wb, wq, X, acc, [&](int m) { return bias_ini(b3, m, h); },
+            layer_stream<128, 8, NG_L1 + NG_L2 + NG_L3, PFS>(
+                rsrc, voff, goff, wq, X, acc, [&](int m) { return bias_ini(b3, m, h); },
                 [&](int m, int i) {
                     if (m == 0 && i < 16 / FPM) {
 #pragma unroll
@@ -461,6 +412,59 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
 
 // Colour MLP: one lane-column per valid sample, 32 samples per wavefront.
 // input 280 = [agg(256) | sin(view*2^f) (12) | cos(...) (12)] -> 128 -> 128 -> 128 -> 3, sigmoid, widen.
+// The same stream structure as the pair kernel: the 268 weight groups of a tile (140 + 64 + 64) behind one rolling
+// window that drains neither between the layers nor between the tiles, one activation block per output tile, biases a
+// tile ahead; the 128 aggregated features of the NEXT tile are loaded (straight into AGPRs, where the first layer's
+// MFMAs read them) as soon as the first layer has consumed the current ones, the sample -> ray -> direction chain of
+// the next tile one level per layer boundary.
+constexpr int PFC = 4;                         // divides 268
+constexpr int NGC1 = 4 * 35, NGC2 = 4 * 16;    // groups of the first / of each of the other two layers
+constexpr int NGC = NGC1 + 2 * NGC2;           // 268
+
+// colour head on the last hidden layer: 128 -> 3, sigmoid, widen (studio_model.py:357-359).  The 16 weight quads of a
+// colour are issued together, one colour ahead, and awaited once (left to hipcc, every quad is loaded and awaited on
+// its own -- behind the weight window still in flight that is 48 drained queues per tile).
+struct HeadW {
+    float4 v[16];
+};
+__device__ __forceinline__ HeadW head_w(__amdgpu_buffer_rsrc_t rsrc, int w8, int h, int c)
+{
+    HeadW w;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w.v[i] = load_w(rsrc, 16 * h, w8 + 512 * c + 128 * (i >> 2) + 32 * (i & 3));
+    return w;
+}
+__device__ __forceinline__ void color_head_f32(__amdgpu_buffer_rsrc_t rsrc, int w8, const float *__restrict__ b8, int h,
+                                               HeadW w0, const float (&hC)[64], float (&rgb)[3])
+{
+    HeadW wc = w0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        HeadW wn;
+        if (c < 2) wn = head_w(rsrc, w8, h, c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        float part = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            part += hC[4 * i + 0] * wc.v[i].x;
+            part += hC[4 * i + 1] * wc.v[i].y;
+            part += hC[4 * i + 2] * wc.v[i].z;
+            part += hC[4 * i + 3] * wc.v[i].w;
+        }
+        part += __shfl_xor(part, 32, 64);
+        const float z = part + b8[c];
+        const float sg = 1.0f / (1.0f + expf(-z));
+        rgb[c] = sg * (1.0f + 2.0f * 0.001f) - 0.001f;
+        if (c < 2) wc = wn;
+    }
+}
+
+struct ColorFetch {
+    int v_idx, s, ray;
+    bool ok;
+    float sigma, dx, dy, dz;
+};
+
 __global__ void __launch_bounds__(TPB, 1) k_shade_color(ShadeParams P)
 {
     const int lane = threadIdx.x & 63;
@@ -471,60 +475,151 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_color(ShadeParams P)
     const int ntiles = (S_valid - V0 + SPT - 1) / SPT;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wbuf), 0, (int)P.wbytes, 0x00020000);
+    const int voff = lane * 16;
     const int w5_ = (int)(P.w_off[5] * 4), w6_ = (int)(P.w_off[6] * 4), w7_ = (int)(P.w_off[7] * 4);
-    const float *b5 = P.wbuf + P.b_off[5], *b6 = P.wbuf + P.b_off[6], *b7 = P.wbuf + P.b_off[7];
+    const float *b5 = P.wbuf + P.b_off[5], *b6 = P.wbuf + P.b_off[6], *b7 = P.wbuf + P.b_off[7], *b8 = P.wbuf + P.b_off[8];
+    const int w8 = (int)(P.w_off[8] * 4);
+    const float4 *agg4 = reinterpret_cast<const float4 *>(P.agg);
+    if ((int)blockIdx.x >= ntiles) return;
 
+    // first level of a tile's chain: the valid-sample index -> sample (colour kernels are launched with V0 = 0)
+    auto fetch_s = [&](int tile, ColorFetch &f) {
+        f.v_idx = V0 + tile * SPT + wave * 32 + j;
+        f.ok = f.v_idx < S_valid;
+        f.s = P.vs_list[f.ok ? f.v_idx : 0];
+        f.sigma = P.smp_sigma[f.ok ? f.v_idx : 0];
+    };
+    auto fetch_ray = [&](ColorFetch &f) {
+        f.s = f.ok ? f.s : 0;
+        f.ray = P.smp_ray[f.s];
+    };
+    auto fetch_dir = [&](ColorFetch &f) {
+        f.dx = P.dirs[3 * (int64_t)f.ray];
+        f.dy = P.dirs[3 * (int64_t)f.ray + 1];
+        f.dz = P.dirs[3 * (int64_t)f.ray + 2];
+    };
+    // features 8 c + 4 h + {0..3} of the lane's sample: one contiguous 512 B per lane half and load (agg_idx4)
+    auto load_agg = [&](const ColorFetch &f, float *x) {
+        const int vs = f.ok ? f.v_idx : 0;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            const float4 a = agg4[agg_idx4(vs, 2 * (c >> 2) + ((c & 3) >> 1), h, c & 1)];
+            x[4 * c + 0] = to_a(a.x);
+            x[4 * c + 1] = to_a(a.y);
+            x[4 * c + 2] = to_a(a.z);
+            x[4 * c + 3] = to_a(a.w);
+        }
+    };
+
+    ColorFetch cur, nxt;
+    float x[140];
+    fetch_s(blockIdx.x, cur);
+    fetch_ray(cur);
+    fetch_dir(cur);
+    load_agg(cur, x);
+    float4 wq[PFC];
+    {
+        const int w5 = w5_;
+#pragma unroll
+        for (int p = 0; p < PFC; ++p) wq[p] = load_w(rsrc, voff, w5 + p * 1024);
+    }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int w5 = w5_, w6 = w6_, w7 = w7_;
         asm volatile("" : "+s"(w5), "+s"(w6), "+s"(w7));
-        const int v_idx = V0 + tile * SPT + wave * 32 + j;  // colour kernels are launched with V0 = 0
-        const bool ok = v_idx < S_valid;
-        const int s = ok ? P.vs_list[v_idx] : 0;
-        const int ray = P.smp_ray[s];
-        const float4 *agg4 = reinterpret_cast<const float4 *>(P.agg);
-        const int vs = ok ? v_idx : 0;
-        float x[140];
+        const auto goff = [&](int G) {
+            G = G >= NGC ? G - NGC : G;
+            return G < NGC1 ? w5 + G * 1024 : G < NGC1 + NGC2 ? w6 + (G - NGC1) * 1024 : w7 + (G - NGC1 - NGC2) * 1024;
+        };
+        // view-direction encodings of this tile (its direction was fetched a tile ago)
+        {
+            float vx, vy, vz;
+            rot_rows(P.Rw2c, cur.dx, cur.dy, cur.dz, vx, vy, vz);
+            const float vv[3] = {vx, vy, vz};
 #pragma unroll
-        for (int c = 0; c < 32; ++c) {
-            // features 8 c + 4 h + {0..3}: one contiguous 512 B per lane half and load (agg_idx4)
-            const float4 a = agg4[agg_idx4(vs, 2 * (c >> 2) + ((c & 3) >> 1), h, c & 1)];
-            x[4 * c + 0] = a.x;
-            x[4 * c + 1] = a.y;
-            x[4 * c + 2] = a.z;
-            x[4 * c + 3] = a.w;
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    float sn, cs;
+                    fast_sincos_nb(vv[d] * (float)(1 << f), sn, cs);
+                    x[128 + d * 4 + f] = to_a(h ? cs : sn);
+                }
         }
-        float vx, vy, vz;
-        rot_rows(P.Rw2c, P.dirs[3 * (int64_t)ray], P.dirs[3 * (int64_t)ray + 1], P.dirs[3 * (int64_t)ray + 2], vx, vy,
-                 vz);
-        const float vv[3] = {vx, vy, vz};
-#pragma unroll
-        for (int d = 0; d < 3; ++d)
-#pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                float sn, cs;
-                fast_sincos_nb(vv[d] * (float)(1 << f), sn, cs);
-                x[128 + d * 4 + f] = h ? cs : sn;
-            }
+        fetch_s(tile + gridDim.x, nxt);   // a tile past the end reads entry 0: harmless
         float hA[64], hB[64];
-        dense_layer<140, 4>(rsrc, w5, b5, lane, x, hA);
+        Ini ini_next;
+        f32x16 acc[4];
+        // ---- layer 1 -----------------------------------------------------------------------------------------------
+        acc[0] = acc_from(bias_ini(b5, 0, h));
+        layer_stream<140, 4, 0, PFC>(
+            rsrc, voff, goff, wq, x, acc, [&](int m) { return bias_ini(b5, m, h); },
+            [&](int m, int i) {
+                if (i != 0) return;
+                if (m > 0) {
 #pragma unroll
-        for (int i = 0; i < 64; ++i) hA[i] = leaky(hA[i]);
-        dense_layer<64, 4>(rsrc, w6, b6, lane, hA, hB);
+                    for (int r = 0; r < 16; r += 2) leaky2(acc[m - 1][r], acc[m - 1][r + 1], hA[16 * (m - 1) + r], hA[16 * (m - 1) + r + 1]);
+                }
+                if (m == 3) ini_next = bias_ini(b6, 0, h);
+            });
+        // the current tile's aggregated features are consumed: fetch the next tile's into the same registers
+        fetch_ray(nxt);
+        load_agg(nxt, x);
+        // ---- layer 2 -----------------------------------------------------------------------------------------------
+        {
+            const f32x16 last = acc[3];
+            acc[0] = acc_from(ini_next);
+            layer_stream<64, 4, NGC1, PFC>(
+                rsrc, voff, goff, wq, hA, acc, [&](int m) { return bias_ini(b6, m, h); },
+                [&](int m, int i) {
+                    if (i != 0) return;
+                    if (m == 0) {
+                        // values 48..63 are this layer's k-steps 48..63: long after MFMA 0
 #pragma unroll
-        for (int i = 0; i < 64; ++i) hB[i] = leaky(hB[i]);
-        dense_layer<64, 4>(rsrc, w7, b7, lane, hB, hA);
+                        for (int r = 0; r < 16; r += 2) leaky2(last[r], last[r + 1], hA[48 + r], hA[49 + r]);
+                    } else {
 #pragma unroll
-        for (int i = 0; i < 64; ++i) hA[i] = leaky(hA[i]);
+                        for (int r = 0; r < 16; r += 2) leaky2(acc[m - 1][r], acc[m - 1][r + 1], hB[16 * (m - 1) + r], hB[16 * (m - 1) + r + 1]);
+                    }
+                    if (m == 3) ini_next = bias_ini(b7, 0, h);
+                });
+        }
+        fetch_dir(nxt);
+        // ---- layer 3 -----------------------------------------------------------------------------------------------
+        float hC[64];
+        {
+            const f32x16 last = acc[3];
+            acc[0] = acc_from(ini_next);
+            layer_stream<64, 4, NGC1 + NGC2, PFC>(
+                rsrc, voff, goff, wq, hB, acc, [&](int m) { return bias_ini(b7, m, h); },
+                [&](int m, int i) {
+                    if (i != 0) return;
+                    if (m == 0) {
+#pragma unroll
+                        for (int r = 0; r < 16; r += 2) leaky2(last[r], last[r + 1], hB[48 + r], hB[49 + r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; r += 2) leaky2(acc[m - 1][r], acc[m - 1][r + 1], hC[16 * (m - 1) + r], hC[16 * (m - 1) + r + 1]);
+                    }
+                });
+        }
+        const HeadW hw0 = head_w(rsrc, w8, h, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) leaky2(acc[3][r], acc[3][r + 1], hC[48 + r], hC[49 + r]);
         float rgb[3];
-        color_head(P, lane, hA, rgb);
-        if (ok && h == 0) P.smp_out[s] = make_float4(P.smp_sigma[v_idx], rgb[0], rgb[1], rgb[2]);
+        color_head_f32(rsrc, w8, b8, h, hw0, hC, rgb);
+        if (cur.ok && h == 0) P.smp_out[cur.s] = make_float4(cur.sigma, rgb[0], rgb[1], rgb[2]);
+        cur = nxt;
     }
 }
 
-// ================================================================================================
-// bf16x3 mode
+// First-layer partial products of the listed points (pt_table, one 1-KiB row per point in accumulator order): the
+// 224 point-only inputs [emb (32) | PE(emb, 3) (192)] of mlp_base layer 0, once per distinct neighbour point.
+// One layer of 224 weight groups as a stream that does not drain between tiles; the finished output tile leaves as
+// four 16-byte stores per lane behind the first MFMA of the next one (no VALU work at all), the next tile's embedding
+// rows are fetched a tile ahead.
+constexpr int PFP = 8;          // divides 224
+constexpr int NGP = 8 * 28;     // 8 output tiles x 112 / 4 groups
 
-// fp32 mode of k_point_part below: the same table with v_mfma_f32_32x32x2_f32 (exact fp32), exact sincosf encodings
 __global__ void __launch_bounds__(TPB, 1) k_point_part_f32(ShadeParams P)
 {
     const int lane = threadIdx.x & 63;
@@ -535,28 +630,56 @@ __global__ void __launch_bounds__(TPB, 1) k_point_part_f32(ShadeParams P)
     const int ntiles = (U + PPT - 1) / PPT;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wbuf), 0, (int)P.wbytes, 0x00020000);
+    const int voff = lane * 16;
     const int wa_ = (int)(P.w32a_off * 4);
     const float *b0 = P.wbuf + P.b_off[0];
+    if ((int)blockIdx.x >= ntiles) return;
+
+    auto fetch_p = [&](int tile, int &pidx) {
+        const int u = tile * PPT + wave * 32 + j;
+        pidx = P.pt_list[u < U ? u : 0];
+    };
+    auto fetch_e = [&](int pidx, float4 (&e4)[4]) {
+        const float4 *row = P.point_rows + (int64_t)pidx * 12 + 4 + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e4[q] = row[q];
+    };
+    int pidx_n;
+    float4 e_cur[4], e_nxt[4];
+    fetch_p(blockIdx.x, pidx_n);
+    fetch_e(pidx_n, e_cur);
+    fetch_p(blockIdx.x + gridDim.x, pidx_n);
+    float4 wq[PFP];
+#pragma unroll
+    for (int p = 0; p < PFP; ++p) wq[p] = load_w(rsrc, voff, wa_ + p * 1024);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int wa = wa_;
         asm volatile("" : "+s"(wa));
-        const int u = tile * PPT + wave * 32 + j;
-        const int pidx = P.pt_list[u < U ? u : 0];
-        const float4 *row = P.point_rows + (int64_t)pidx * 12 + 4 + 4 * h;
-        const float4 e0 = row[0], e1 = row[1], e2 = row[2], e3 = row[3];
-        const float e[16] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w,
-                             e2.x, e2.y, e2.z, e2.w, e3.x, e3.y, e3.z, e3.w};
+        const auto goff = [&](int G) { return wa + (G >= NGP ? G - NGP : G) * 1024; };
+        const float e[16] = {e_cur[0].x, e_cur[0].y, e_cur[0].z, e_cur[0].w, e_cur[1].x, e_cur[1].y, e_cur[1].z, e_cur[1].w,
+                             e_cur[2].x, e_cur[2].y, e_cur[2].z, e_cur[2].w, e_cur[3].x, e_cur[3].y, e_cur[3].z, e_cur[3].w};
         float x0[112];
         point_inputs<true, false>(e, x0);   // branch-free sincos, 9e-8 absolute (libm's costs 150 instructions a call)
-        float o[128];
-        dense_layer<112, 8>(rsrc, wa, b0, lane, x0, o);
+        // the next tile's embedding rows (their point index was fetched a tile ago), the point index of the one after
+        fetch_e(pidx_n, e_nxt);
+        fetch_p(tile + 2 * gridDim.x, pidx_n);
+        const int u = tile * PPT + wave * 32 + j;
         float4 *dst = P.pt_table + (int64_t)u * 64 + 4 * h;   // rows beyond U: the table's padding rows
-#pragma unroll
-        for (int B = 0; B < 8; ++B)
+        auto store_tile = [&](int B, const f32x16 &a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                dst[8 * B + q] = make_float4(o[16 * B + 4 * q], o[16 * B + 4 * q + 1], o[16 * B + 4 * q + 2],
-                                             o[16 * B + 4 * q + 3]);
+                dst[8 * B + q] = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+        };
+        f32x16 acc[8];
+        acc[0] = acc_from(bias_ini(b0, 0, h));
+        layer_stream<112, 8, 0, PFP>(
+            rsrc, voff, goff, wq, x0, acc, [&](int m) { return bias_ini(b0, m, h); },
+            [&](int m, int i) {
+                if (m > 0 && i == 0) store_tile(m - 1, acc[m - 1]);
+            });
+        store_tile(7, acc[7]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e_cur[q] = e_nxt[q];
     }
 }
 
