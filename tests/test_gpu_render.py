@@ -205,24 +205,26 @@ def test_render_edge_cases(oracle, gpu_device, precision):
         _check(ref, out)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
-def test_early_ray_termination_option(oracle, gpu_device, precision):
+@pytest.mark.parametrize("precision,K", [("fp32", 8), ("bf16x3", 8), ("fp32", 12), ("fp32", 20), ("bf16x3", 12)])
+def test_early_ray_termination_option(oracle, gpu_device, precision, K):
     """opts.early_stop_eps > 0: rays stop being shaded once their transmittance is below eps.  The image stays within
     the same 1e-4 of the oracle (which shades everything), fewer samples go through the MLPs on an opaque scene, every
     sample that WAS shaded decodes to exactly the values of the full render, and eps = 0 is the full render."""
+    # (K = 12 / 20: the 16-lane and the K-lane segments; the passes of the termination loop start at arbitrary samples,
+    # so a wave's samples straddle the 32-sample blocks of the aggregated-feature layout)
     pts = small_scene(120000)
-    cfg = oracle_cfg(oracle)
+    cfg = oracle_cfg(oracle, K=K)
     w = synthetic.make_weights(0, sigma_scale=300.0, bias_scale=0.1)
     campos, camrot, dirs = camera_rays(40, 40, az=35.0)
     ref = oracle.render(pts, w, cfg, campos[None].expand(dirs.shape[0], 3), dirs, 2.0, 6.0, camrot)
     scene, wh, hyp, info = build_hip(pts, cfg, gpu_device, weights=w)
     d = dirs.to(gpu_device)
-    full = RendererHIP(scene, wh, precision=precision)
+    full = RendererHIP(scene, wh, precision=precision, K=K)
     of = full.render(d, campos, camrot, 2.0, 6.0)
     S = int(of["counters"]["samples_selected"])
     dec_full = full.taps(d.shape[0])["smp_out"][:S].clone()
     assert of["counters"]["samples_shaded"] == of["counters"]["samples_valid"]
-    es = RendererHIP(scene, wh, precision=precision, early_stop_eps=1e-5)
+    es = RendererHIP(scene, wh, precision=precision, early_stop_eps=1e-5, K=K)
     oe = es.render(d, campos, camrot, 2.0, 6.0)
     _check(ref, oe)
     assert (oe["rgb"] - of["rgb"]).abs().max().item() <= 2e-5
