@@ -463,14 +463,17 @@ __global__ void __launch_bounds__(TPB) k_knn(GridView g, int K, float radius_lim
 // thread handles one x-slab (up to 9 cells) at a time: the 9 brick records are loaded together, then the list bounds
 // of the occupied cells together, then each occupied cell's candidates twelve at a time, cells visited in the same
 // order and candidates tested in the same order as the reference, so the lists are identical (slot order included).
+// (occupancy is what this latency-bound kernel lives on: batches of 12 candidates at 133 VGPRs = 3 waves per SIMD ran
+// 0.91 ms on cfg 1; batches of 4 with the allocation capped for 6 waves per SIMD -- a few spilled registers included --
+// 0.68 ms; slab records fetched three cells at a time for 8 waves: 0.72)
 template <int KMAX>
-__global__ void __launch_bounds__(TPB) k_knn3(GridView g, int K, float radius_limit2,
+__global__ void __launch_bounds__(TPB, KMAX <= 8 ? 6 : 4) k_knn3(GridView g, int K, float radius_limit2,
                                                const float4 *__restrict__ smp_loc, const int *__restrict__ smp_ray,
                                                const int *__restrict__ n_sel, int *__restrict__ smp_pidx,
                                                int *__restrict__ smp_valid, int *__restrict__ ray_flag,
                                                unsigned long long *__restrict__ shards, int *__restrict__ pt_flag)
 {
-    constexpr int CB = 12;  // candidates fetched per batch
+    constexpr int CB = KMAX <= 8 ? 4 : 8;  // candidates fetched per batch
     const int S = n_sel[0];
     for (int64_t s = (int64_t)blockIdx.x * TPB + threadIdx.x; s < S; s += (int64_t)gridDim.x * TPB) {
         const float4 c = smp_loc[s];
