@@ -69,6 +69,13 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd), flush=True)
         p = subprocess.run(cmd, capture_output=True, text=True)
+        if p.returncode != 0 and "Unknown command line argument" in p.stderr:
+            # a toolchain without one of the FILE_FLAGS options (they are tuning, not semantics): build without them
+            extra = {f for fl in FILE_FLAGS.values() for f in fl if f != "-mllvm"}
+            slim = [c for i, c in enumerate(cmd) if c not in extra and not (c == "-mllvm" and cmd[i + 1] in extra)]
+            print(f"note: {os.path.basename(cmd[-3])}: per-file flags not supported by this hipcc, building without",
+                  file=sys.stderr)
+            p = subprocess.run(slim, capture_output=True, text=True)
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed:\n{' '.join(cmd)}\n{p.stdout}\n{p.stderr}")
         if verbose and p.stderr.strip():
