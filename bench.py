@@ -221,26 +221,27 @@ def main():
 
     # ---- rays: `world` views per step, this rank's tiles of each ----------------------------------------
     azimuths = list(range(8))   # the eight views of the configuration
-    shard = make_shard(H, W, world, rank).to(dev)
+    # (rotate: the i-th view of a step is rendered with the tiles of owner (rank + i) % world -- see TileShard)
+    shard = make_shard(H, W, world, rank, rotate=True).to(dev)
     # A view is pose + intrinsics; its rays are generated inside the kernels from the pixel ids this rank owns
     # (pnr_render_camera): no direction tensor exists.  --rays-from-tensor renders from a resident [R,3] tensor instead
     # (pnr_render_views, the plugin's ray-bundle contract).
-    shard_px = shard.pixels.to(torch.int32).contiguous()
+    shard_px = (shard.view_pixels if shard.rotate else shard.pixels).to(torch.int32).contiguous()   # [world, n_pad] / [n_pad]
     view_dirs, cams, views = [], [], []
     for az in azimuths:
         campos, camrot = synthetic.make_scene_camera(cfgd, az)
         cams.append((campos, camrot))
         views.append(View.from_angle(campos, camrot, H, W, cfgd["angle_x"], near, far))
         if args.rays_from_tensor:
-            d = synthetic.make_rays(H, W, campos, camrot, cfgd["angle_x"]).to(dev)
-            view_dirs.append(d.index_select(0, shard.pixels).contiguous())
+            view_dirs.append(synthetic.make_rays(H, W, campos, camrot, cfgd["angle_x"]).to(dev))   # whole frame
     n_local = shard.n_pad * world          # this rank's rays of one step: its tiles of `world` views
     # the view sets a step can consist of: views (s*world + i) % 8, i < world -- concatenated once, resident in HBM
     step_sets = {}
     for s0 in range(len(azimuths)):
         vs = tuple((s0 * world + i) % len(azimuths) for i in range(world))
         if vs not in step_sets:
-            step_sets[vs] = (torch.cat([view_dirs[v] for v in vs]).contiguous() if args.rays_from_tensor else None,
+            step_sets[vs] = (torch.cat([view_dirs[v].index_select(0, shard.pixels_of_view(i)) for i, v in enumerate(vs)]).contiguous()
+                             if args.rays_from_tensor else None,
                              [(cams[v][0], cams[v][1], near, far) for v in vs], [views[v] for v in vs])
 
     def render_step(renderer, vs, **kw):
@@ -458,7 +459,7 @@ def main():
                 "workload_key": workload_key,
                 "rays_per_step": rays_per_step, "global_batch": rays_per_step, "mlp_mode": args.precision,
                 "rays_per_rank_per_step": n_local,
-                "parallelism": f"ray-tile shard x{world} (16x16 tiles round-robin), one multi-camera render + one "
+                "parallelism": f"ray-tile shard x{world} (16x16 tiles round-robin, owner rotated per view), one multi-camera render + one "
                                f"all_gather per step",
                 "rays": "directions resident in HBM (pnr_render_views)" if args.rays_from_tensor else
                         "generated in the kernels from pose + intrinsics + pixel ids (pnr_render_camera)",

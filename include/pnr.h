@@ -235,6 +235,16 @@ int pnr_render_camera(const pnr_scene_t *scene, const pnr_weights_t *weights, co
                       const pnr_render_opts_t *opts, float *d_rgb, float *d_depth, float *d_acc, int8_t *d_ray_mask,
                       int64_t *d_counters, void *d_workspace, size_t workspace_bytes, int64_t cap_samples, void *stream);
 
+/* The same with ONE PIXEL LIST PER VIEW: d_pixels [n_views, n_pixels], ray r of the call is pixel d_pixels[r] of view
+ * r / n_pixels.  What a multi-GPU step uses to give every view a different tile owner (the views of a step look at
+ * the same object: with one list for all of them a rank's load imbalance repeats in every view instead of averaging
+ * out -- max / mean pairs per rank 1.05 -> 1.004 at 8 ranks, pointnerf2studio_amd.distributed.make_shard(rotate=True)). */
+int pnr_render_camera_lists(const pnr_scene_t *scene, const pnr_weights_t *weights, const pnr_view_t *views,
+                            int32_t n_views, int32_t H, int32_t W, const int32_t *d_pixels, int64_t n_pixels,
+                            const float *d_tmid, const pnr_render_opts_t *opts, float *d_rgb, float *d_depth, float *d_acc,
+                            int8_t *d_ray_mask, int64_t *d_counters, void *d_workspace, size_t workspace_bytes,
+                            int64_t cap_samples, void *stream);
+
 /* The same rays written out as a direction tensor d_dirs [n_views * n_pixels, 3] (for callers that need one: the
  * training step's pnr_render_backward, tests). */
 int pnr_camera_rays(const pnr_view_t *views, int32_t n_views, int32_t H, int32_t W, const int32_t *d_pixels,

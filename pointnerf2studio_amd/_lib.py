@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "pnr_weights_create", "pnr_weights_destroy", "pnr_weights_pack",
     "pnr_query_workspace_bytes", "pnr_query_raypos",
     "pnr_render_workspace_bytes", "pnr_render_workspace_bytes_for", "pnr_render", "pnr_render_views",
-    "pnr_render_camera", "pnr_camera_rays", "pnr_pinhole_ray",
+    "pnr_render_camera", "pnr_render_camera_lists", "pnr_camera_rays", "pnr_pinhole_ray",
     "pnr_render_taps",
     "pnr_backward_workspace_bytes", "pnr_render_backward",
     "pnr_profile_enable", "pnr_profile_calls", "pnr_profile_read",
@@ -125,6 +125,7 @@ def load() -> C.CDLL:
                                      vp, vp, vp, vp, sz, i64, vp]
     lib.pnr_render_camera.argtypes = [vp, vp, C.POINTER(ViewC), i32, i32, i32, vp, i64, vp, C.POINTER(RenderOpts), vp, vp, vp,
                                       vp, vp, vp, sz, i64, vp]
+    lib.pnr_render_camera_lists.argtypes = lib.pnr_render_camera.argtypes
     lib.pnr_camera_rays.argtypes = [C.POINTER(ViewC), i32, i32, i32, vp, i64, vp, vp]
     lib.pnr_pinhole_ray.restype = None
     lib.pnr_pinhole_ray.argtypes = [C.POINTER(ViewC), i32, i32, C.POINTER(C.c_float * 3)]

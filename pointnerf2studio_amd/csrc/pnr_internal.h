@@ -104,6 +104,7 @@ struct CamRef {
     int W;
     const int *pixels;
     long long n_pixels;
+    int pix_per_view;   // pixels holds one list of n_pixels entries PER VIEW (pnr_render_camera_lists)
 };
 
 // Direction of pixel (x, y) of a pinhole view: the arithmetic include/pnr.h states for pnr_view_t, fp32, unfused (the
@@ -176,7 +177,7 @@ __device__ __forceinline__ void ray_dir(const CamRef &cr, const Camera &cam, con
         return;
     }
     const unsigned i = (unsigned)((unsigned long long)r % (unsigned long long)cr.n_pixels);
-    const unsigned p = cr.pixels ? (unsigned)cr.pixels[i] : i;
+    const unsigned p = cr.pixels ? (unsigned)cr.pixels[cr.pix_per_view ? (unsigned long long)r : (unsigned long long)i] : i;
     const unsigned y = p / (unsigned)cr.W, x = p - y * (unsigned)cr.W;
     pinhole_dir(cam, (int)x, (int)y, dx, dy, dz);
 }

@@ -288,6 +288,7 @@ struct RayGen {
     int W = 0;
     const int *pixels = nullptr;
     int64_t n_pixels = 0;
+    int per_view = 0;
 };
 
 static int render_views(const pnr_scene_t *scene, const pnr_weights_t *weights, const float *d_dirs, int64_t R,
@@ -346,6 +347,7 @@ static int render_views(const pnr_scene_t *scene, const pnr_weights_t *weights, 
         cr.gen_rays = 1;
         cr.W = gen->W;
         cr.pixels = gen->pixels;
+        cr.pix_per_view = gen->per_view;
         cr.n_pixels = gen->n_pixels;
     }
     // the shading stage reads directions per hit ray: the caller's tensor, or the rows k_expand generated
@@ -439,14 +441,15 @@ static int check_views(const pnr_view_t *views, int32_t n_views, int32_t H, int3
     return PNR_OK;
 }
 
-extern "C" int pnr_render_camera(const pnr_scene_t *scene, const pnr_weights_t *weights, const pnr_view_t *views,
-                                 int32_t n_views, int32_t H, int32_t W, const int32_t *d_pixels, int64_t n_pixels,
-                                 const float *d_tmid, const pnr_render_opts_t *opts, float *d_rgb, float *d_depth,
-                                 float *d_acc, int8_t *d_ray_mask, int64_t *d_counters, void *d_workspace,
-                                 size_t workspace_bytes, int64_t cap_samples, void *stream)
+static int render_camera_impl(const pnr_scene_t *scene, const pnr_weights_t *weights, const pnr_view_t *views,
+                              int32_t n_views, int32_t H, int32_t W, const int32_t *d_pixels, int64_t n_pixels,
+                              int per_view, const float *d_tmid, const pnr_render_opts_t *opts, float *d_rgb,
+                              float *d_depth, float *d_acc, int8_t *d_ray_mask, int64_t *d_counters, void *d_workspace,
+                              size_t workspace_bytes, int64_t cap_samples, void *stream, const char *who)
 {
-    int rc = check_views(views, n_views, H, W, d_pixels, n_pixels, "pnr_render_camera");
+    int rc = check_views(views, n_views, H, W, d_pixels, n_pixels, who);
     if (rc != PNR_OK) return rc;
+    PNR_REQUIRE(!per_view || d_pixels != nullptr, "%s: per-view pixel lists need d_pixels", who);
     CamSet set{};
     float nears[PNR_MAX_CAMS] = {0};
     for (int v = 0; v < n_views; ++v) {
@@ -457,9 +460,33 @@ extern "C" int pnr_render_camera(const pnr_scene_t *scene, const pnr_weights_t *
     gen.W = W;
     gen.pixels = d_pixels;
     gen.n_pixels = n_pixels;
+    gen.per_view = per_view;
     return render_views(scene, weights, nullptr, (int64_t)n_views * n_pixels, set, nears, n_views, nullptr, n_pixels, &gen,
                         d_tmid, opts, d_rgb, d_depth, d_acc, d_ray_mask, d_counters, d_workspace, workspace_bytes,
-                        cap_samples, (hipStream_t)stream, "pnr_render_camera");
+                        cap_samples, (hipStream_t)stream, who);
+}
+
+extern "C" int pnr_render_camera(const pnr_scene_t *scene, const pnr_weights_t *weights, const pnr_view_t *views,
+                                 int32_t n_views, int32_t H, int32_t W, const int32_t *d_pixels, int64_t n_pixels,
+                                 const float *d_tmid, const pnr_render_opts_t *opts, float *d_rgb, float *d_depth,
+                                 float *d_acc, int8_t *d_ray_mask, int64_t *d_counters, void *d_workspace,
+                                 size_t workspace_bytes, int64_t cap_samples, void *stream)
+{
+    return render_camera_impl(scene, weights, views, n_views, H, W, d_pixels, n_pixels, 0, d_tmid, opts, d_rgb, d_depth,
+                              d_acc, d_ray_mask, d_counters, d_workspace, workspace_bytes, cap_samples, stream,
+                              "pnr_render_camera");
+}
+
+extern "C" int pnr_render_camera_lists(const pnr_scene_t *scene, const pnr_weights_t *weights, const pnr_view_t *views,
+                                       int32_t n_views, int32_t H, int32_t W, const int32_t *d_pixels,
+                                       int64_t n_pixels, const float *d_tmid, const pnr_render_opts_t *opts,
+                                       float *d_rgb, float *d_depth, float *d_acc, int8_t *d_ray_mask,
+                                       int64_t *d_counters, void *d_workspace, size_t workspace_bytes,
+                                       int64_t cap_samples, void *stream)
+{
+    return render_camera_impl(scene, weights, views, n_views, H, W, d_pixels, n_pixels, 1, d_tmid, opts, d_rgb, d_depth,
+                              d_acc, d_ray_mask, d_counters, d_workspace, workspace_bytes, cap_samples, stream,
+                              "pnr_render_camera_lists");
 }
 
 extern "C" void pnr_pinhole_ray(const pnr_view_t *view, int32_t x, int32_t y, float dir[3])

@@ -29,11 +29,24 @@ class TileShard:
     scatter_index: torch.Tensor  # [world * n_pad] flat pixel id of every gathered slot, -1 for padding
     slot_index: torch.Tensor   # [H*W] gathered slots that hold real pixels ...
     pixel_index: torch.Tensor  # [H*W] ... and the pixel each of them is
+    # rotate=True (multi-view steps): view i of a step is rendered with the tiles of owner (rank + i) % world, so a
+    # rank's load is a sum over DIFFERENT tile sets -- the views of a step look at the same object, and with one tile
+    # set for all of them a rank's imbalance repeats in every view (max / mean pairs per rank 1.05 at 8 ranks; 1.004
+    # rotated).  view_pixels [world, n_pad]: row i = the list this rank renders for the step's i-th view.
+    view_pixels: Optional[torch.Tensor] = None
+
+    @property
+    def rotate(self) -> bool:
+        return self.view_pixels is not None
+
+    def pixels_of_view(self, i: int) -> torch.Tensor:
+        return self.view_pixels[i % self.world] if self.rotate else self.pixels
 
     def to(self, device) -> "TileShard":
         return TileShard(self.H, self.W, self.tile, self.world, self.rank, self.pixels.to(device), self.n_valid,
                          self.n_pad, self.scatter_index.to(device), self.slot_index.to(device),
-                         self.pixel_index.to(device))
+                         self.pixel_index.to(device),
+                         None if self.view_pixels is None else self.view_pixels.to(device))
 
 
 def _rank_pixels(H: int, W: int, tile: int, world: int, rank: int) -> torch.Tensor:
@@ -47,8 +60,9 @@ def _rank_pixels(H: int, W: int, tile: int, world: int, rank: int) -> torch.Tens
     return (yy * W + xx)[ok].reshape(-1)
 
 
-def make_shard(H: int, W: int, world: int, rank: int, tile: int = 16) -> TileShard:
-    """Pixel ownership of `rank`; deterministic and identical on all ranks (no communication)."""
+def make_shard(H: int, W: int, world: int, rank: int, tile: int = 16, rotate: bool = False) -> TileShard:
+    """Pixel ownership of `rank`; deterministic and identical on all ranks (no communication).  rotate: see
+    TileShard.view_pixels."""
     per_rank = [_rank_pixels(H, W, tile, world, r) for r in range(world)]
     n_pad = max(int(p.numel()) for p in per_rank)
     scatter = torch.full((world * n_pad,), -1, dtype=torch.long)
@@ -59,8 +73,25 @@ def make_shard(H: int, W: int, world: int, rank: int, tile: int = 16) -> TileSha
     if n_valid < n_pad:  # pad with the rank's last pixel: rendered twice, dropped by scatter_index
         mine = torch.cat([mine, mine[-1:].expand(n_pad - n_valid)])
     slot_index = torch.nonzero(scatter >= 0).reshape(-1)
+    view_pixels = None
+    if rotate and world > 1:
+        def padded(p):   # every owner's list padded with its last pixel to the common length
+            return p if p.numel() == n_pad else torch.cat([p, p[-1:].expand(n_pad - p.numel())])
+        view_pixels = torch.stack([padded(per_rank[(rank + i) % world]) for i in range(world)]).contiguous()
     return TileShard(H, W, tile, world, rank, mine.contiguous(), n_valid, n_pad, scatter, slot_index,
-                     scatter[slot_index].contiguous())
+                     scatter[slot_index].contiguous(), view_pixels)
+
+
+def _owner_major(gathered: torch.Tensor, shard: TileShard) -> torch.Tensor:
+    """gathered [world (rank q), V, n_pad, C] -> [V, world (tile owner o), n_pad, C].  Without rotation rank = owner;
+    with it view i of rank q holds owner (q + i) % world, so owner o of view i comes from rank (o - i) % world."""
+    g = gathered.permute(1, 0, 2, 3)
+    if not shard.rotate:
+        return g
+    V, w = g.shape[0], shard.world
+    i = torch.arange(V, device=g.device)[:, None]
+    o = torch.arange(w, device=g.device)[None, :]
+    return g[i, (o - i) % w]
 
 
 def gather_views(local: torch.Tensor, shard: TileShard, n_views: int, out: Optional[torch.Tensor] = None,
@@ -78,7 +109,7 @@ def gather_views(local: torch.Tensor, shard: TileShard, n_views: int, out: Optio
     if out is None:
         out = torch.empty((n_views, shard.H * shard.W, C), dtype=local.dtype, device=local.device)
     # [world, V, n_pad, C] -> [V, world * n_pad, C]: the per-view layout gather_image produces
-    per_view = gathered.permute(1, 0, 2, 3).reshape(n_views, w * n, C)
+    per_view = _owner_major(gathered, shard).reshape(n_views, w * n, C)
     src = per_view if shard.slot_index.numel() == w * n else per_view.index_select(1, shard.slot_index)
     out.index_copy_(1, shard.pixel_index, src)
     return out
@@ -157,7 +188,7 @@ class ViewGatherPipe:
             self.work[b].wait()   # NCCL/RCCL: the current stream waits for the collective; gloo: the host does
             self.work[b] = None
         sh, w, n = self.shard, self.shard.world, self.shard.n_pad
-        per_view = self.gathered[b].permute(1, 0, 2, 3).reshape(self.n_views, w * n, self.C)
+        per_view = _owner_major(self.gathered[b], sh).reshape(self.n_views, w * n, self.C)
         src = per_view if sh.slot_index.numel() == w * n else per_view.index_select(1, sh.slot_index)
         self.images.index_copy_(1, sh.pixel_index, src)
 

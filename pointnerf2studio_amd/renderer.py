@@ -415,14 +415,20 @@ class RendererHIP:
                       cap_samples: Optional[int] = None, sync_counters: bool = True, out: Optional[dict] = None):
         """pnr_render_camera: the views' rays are generated inside the kernels from pose + intrinsics; no direction
         tensor is handed over.  `pixels` (int32 flat ids y * W + x on the device: what a tile shard owns) or None for
-        the whole frame; the outputs have len(views) * n_pixels rows, view-major in `pixels` order."""
+        the whole frame; the outputs have len(views) * n_pixels rows, view-major in `pixels` order.  A 2-D `pixels`
+        [len(views), n_pixels] gives every view its own list (pnr_render_camera_lists)."""
         dev = self.scene.device
         n = len(views)
         if not 1 <= n <= _lib.MAX_CAMS:
             raise ValueError(f"1..{_lib.MAX_CAMS} views per call, got {n}")
         px = None if pixels is None else pixels.to(device=dev, dtype=torch.int32).contiguous()
-        n_px = H * W if px is None else int(px.numel())
+        per_view = px is not None and px.dim() == 2
+        if per_view and px.shape[0] != n:
+            raise ValueError(f"per-view pixel lists: {px.shape[0]} lists for {n} views")
+        n_px = H * W if px is None else int(px.shape[-1])
         R = n * n_px
+        fn, who = ((self.lib.pnr_render_camera_lists, "pnr_render_camera_lists") if per_view
+                   else (self.lib.pnr_render_camera, "pnr_render_camera"))
         key = ("views",) + tuple(id(v) for v in views)
         cached = self._cam_cache.get(key)
         sig = [(v.fx, v.fy, v.cx, v.cy, v.near, v.far) for v in views]   # (a View is a value: not mutated in place)
@@ -454,10 +460,10 @@ class RendererHIP:
             self._last = ("camera", R, cams, n, None, n_px, cap)
             self.calls += 1
             with torch.cuda.device(dev):
-                _lib.check(self.lib.pnr_render_camera(
+                _lib.check(fn(
                     self.scene.handle, self.weights.handle, arr, n, int(H), int(W), _ptr(px), n_px, _ptr(tm),
                     C.byref(self.opts), _ptr(out["rgb"]), _ptr(out["depth"]), _ptr(out["acc"]), _ptr(out["ray_mask"]),
-                    _ptr(out["counters_dev"]), _ptr(ws), ws.numel(), cap, _stream_ptr(dev)), "pnr_render_camera")
+                    _ptr(out["counters_dev"]), _ptr(ws), ws.numel(), cap, _stream_ptr(dev)), who)
             if not sync_counters:
                 return out
             cnt = out["counters_dev"].cpu().tolist()

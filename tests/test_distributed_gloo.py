@@ -50,6 +50,19 @@ def _worker(rank, world, port, H, W, q):
         seen.append(pipe.drain().clone())
         ok = ok and len(seen) == 4 and all(
             torch.equal(seen[st][v], expect + 1000.0 * v + 7.0 * st) for st in range(4) for v in range(V))
+        # bench.py's shard: the tile owner rotates with the view's position in the step (view i of rank q holds the
+        # tiles of owner (q + i) % world): same images, synchronous and pipelined
+        rsh = make_shard(H, W, world, rank, rotate=True)
+        ok = ok and rsh.rotate and rsh.view_pixels.shape == (world, rsh.n_pad) and torch.equal(rsh.view_pixels[0], rsh.pixels)
+        local_r = torch.cat([_fake_render(rsh.pixels_of_view(v)) + 1000.0 * v for v in range(V)])
+        imgs_r = gather_views(local_r, rsh, V)
+        ok = ok and all(torch.equal(imgs_r[v], expect + 1000.0 * v) for v in range(V))
+        pipe_r = ViewGatherPipe(rsh, V, 4, torch.float32, torch.device("cpu"))
+        for step in range(3):
+            pipe_r.stage().copy_(local_r + 7.0 * step)
+            pipe_r.submit()
+        last = pipe_r.drain()
+        ok = ok and all(torch.equal(last[v], expect + 1000.0 * v + 14.0) for v in range(V))
         # bench.py's timing reduction: max over ranks
         t = torch.tensor([1.0 + rank], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -87,6 +100,12 @@ def test_shards_partition_the_image_and_interleave():
         for s in shards:
             ys = s.pixels[:s.n_valid] // W
             assert ys.min() < H // 4 and ys.max() > 3 * H // 4
+        # rotated owners: for every view position the ranks' lists still partition the image
+        rot = [make_shard(H, W, world, r, rotate=True) for r in range(world)]
+        for i in range(world):
+            owners = [(r + i) % world for r in range(world)]
+            allp = torch.cat([rot[r].pixels_of_view(i)[:shards[owners[r]].n_valid] for r in range(world)])
+            assert torch.equal(torch.sort(allp)[0], torch.arange(H * W))
 
 
 # ---- data-parallel training step: gradient exchange ---------------------------------------------------------------

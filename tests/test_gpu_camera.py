@@ -83,6 +83,21 @@ def test_render_camera_equals_render_from_the_direction_tensor(oracle, gpu_devic
     for v in range(len(views)):
         assert torch.equal(part["rgb"][v * n_px:(v + 1) * n_px],
                            full["rgb"][v * H * W:(v + 1) * H * W][shard.pixels.to(gpu_device)]) or jitter > 0
+    # one pixel list PER VIEW (pnr_render_camera_lists, the rotated shard of a multi-GPU step): view i renders the tiles
+    # of owner (1 + i) % 3 -- at jitter 0 every view's rows equal the whole-frame render at those pixels
+    rsh = make_shard(H, W, 3, 1, rotate=True)
+    rnd = RendererHIP(scene, wh, precision=precision, jitter=jitter, seed=5)
+    lists = rsh.view_pixels[:len(views)].to(torch.int32).to(gpu_device)
+    per_view = rnd.render_camera(views, H, W, pixels=lists)
+    assert per_view["rgb"].shape[0] == len(views) * rsh.n_pad
+    if jitter == 0.0:
+        for v in range(len(views)):
+            rows = slice(v * rsh.n_pad, (v + 1) * rsh.n_pad)
+            at = rsh.pixels_of_view(v).to(gpu_device)
+            assert torch.equal(per_view["rgb"][rows], full["rgb"][v * H * W:(v + 1) * H * W][at])
+            assert torch.equal(per_view["depth"][rows], full["depth"][v * H * W:(v + 1) * H * W][at])
+            assert torch.equal(per_view["ray_mask"][rows], full["ray_mask"][v * H * W:(v + 1) * H * W][at])
+    assert not torch.equal(rsh.view_pixels[0], rsh.view_pixels[1])
     if jitter == 0.0 and precision == "fp32":
         # ... and the oracle on the same rays (view 1)
         v = views[1]

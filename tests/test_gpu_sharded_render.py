@@ -1,7 +1,7 @@
 """SURVEY.md section 8e on the GPU: the ray-tile shard + ONE all_gather per step, rehearsed with THREE ranks sharing the
 one GPU of the test box over gloo (RCCL refuses several ranks on one device; the collectives are the same
-torch.distributed calls).  Every rank renders its 16x16-pixel tiles of two views in one pnr_render_camera call (views =
-pose + intrinsics, rays = the pixel ids of its shard) in the lego-like configuration of BASELINE.json configs[2] at
+torch.distributed calls).  Every rank renders its 16x16-pixel tiles of two views in one pnr_render_camera_lists call (views =
+pose + intrinsics, rays = the pixel ids of its shard, the tile owner rotated per view) in the lego-like configuration of BASELINE.json configs[2] at
 reduced size, the ranks all_gather their tiles (distributed.gather_views), and every rank must hold the two full
 images bit-identical to the single-process render of the whole frames -- RGB and depth."""
 import os
@@ -53,8 +53,10 @@ def _worker(rank, world, port, q):
         from pointnerf2studio_amd.distributed import gather_views, make_shard
         dev = torch.device("cuda:0")
         rnd, views = _setup(dev)
-        shard = make_shard(H, W, world, rank)
-        out = rnd.render_camera(views, H, W, pixels=shard.pixels.to(torch.int32).to(dev))
+        # bench.py's shard: the tile owner rotates with the view's position in the step, every view has its own pixel
+        # list (pnr_render_camera_lists)
+        shard = make_shard(H, W, world, rank, rotate=True)
+        out = rnd.render_camera(views, H, W, pixels=shard.view_pixels[:len(views)].to(torch.int32).to(dev))
         local = torch.cat([out["rgb"], out["depth"][:, None]], dim=1).cpu()     # gloo moves host memory
         images = gather_views(local, shard, len(views))                        # [2, H*W, 4] on every rank
         kept = int(out["counters"]["rays_kept"])
