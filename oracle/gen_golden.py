@@ -11,7 +11,15 @@ What is pinned:
                       and jitter 0.3 with an injected uniform tensor
   ref_raymarch.npz    ray_march + alpha_blend + radiance_render (diff_ray_marching.py:495-541)
   ref_aggregator.npz  legacy PointAggregator.forward (point_aggregators.py:745-830) configured as
-                      the plugin (LeakyReLU slope 0.1, ReLU density, widened sigmoid), seeded weights
+                      the plugin (LeakyReLU slope 0.1, ReLU density, widened sigmoid), seeded weights;
+                      also the `weight` and `conf_coefficient` tensors forward returns (:816-830) and a
+                      second pass WITH sampled_conf (the legacy weight x clamp(conf) path the probing
+                      outputs use)
+  ref_trained_aggregator.npz  the same forward with the TRAINED aggregator tensors the reference ships
+                      (mvsnet_checkpoints/init/dtu_dgt_d012_img0123_conf_agg2_32_dirclr20/
+                      best_net_ray_marching.pth, `aggregator.*` only, stored under the plugin's module
+                      names) at LeakyReLU slopes 0.01 (as trained) and 0.1 (the plugin's): sigma of
+                      10^2 .. 10^4, the stress SURVEY.md section 7 names
 """
 import argparse
 import importlib
@@ -103,17 +111,54 @@ def random_aggregator_inputs(seed, R=5, SR=6, K=8):
         sample_pnt_mask=pnt_mask, sample_loc=loc, sample_loc_w=loc_w, sample_ray_dirs=dirs)
 
 
-def run_aggregator(agg, inp, widen=True):
+def run_aggregator(agg, inp, widen=True, conf=None, full=False):
+    """forward (point_aggregators.py:745-830).  conf=None is the plugin's call (studio_model.py never multiplies the
+    weights by the confidence); with `conf` [1,R,SR,K,1] the legacy weight x clamp(conf) path runs.  full=True also
+    returns the `weight` and `conf_coefficient` tensors forward hands back (:816-830)."""
     with torch.no_grad():
-        decoded, valid, _, _ = agg(
-            inp["sampled_color"], inp["Rw2c"], inp["sampled_dir"], None, inp["sampled_embedding"].clone(),
+        decoded, valid, weight, conf_coefficient = agg(
+            inp["sampled_color"], inp["Rw2c"], inp["sampled_dir"], conf, inp["sampled_embedding"].clone(),
             inp["sampled_xyz_pers"], inp["sampled_xyz"], inp["sample_pnt_mask"], inp["sample_loc"],
             inp["sample_loc_w"], inp["sample_ray_dirs"], [0.004] * 3, 0)
         decoded = decoded.clone()
         if widen:   # plugin applies the widened sigmoid unconditionally (studio_model.py:359)
             v = valid[..., None].expand_as(decoded[..., 1:4])
             decoded[..., 1:4] = torch.where(v, decoded[..., 1:4] * (1 + 2 * 0.001) - 0.001, decoded[..., 1:4])
+    if full:
+        return decoded, valid, weight, conf_coefficient
     return decoded, valid
+
+
+SHIPPED = f"{REF}/mvsnet_checkpoints/init/dtu_dgt_d012_img0123_conf_agg2_32_dirclr20/best_net_ray_marching.pth"
+
+
+def trained_fixture():
+    """The shipped trained aggregator through the reference's forward on seeded inputs,
+    at the slope it was trained with (0.01) and at the plugin's (0.1).  The tensors are stored under the plugin's
+    module names (NAME_MAP) so the oracle and the HIP path load them as they load any weights."""
+    sd = torch.load(SHIPPED, map_location="cpu", weights_only=True)
+    agg_sd = {k[len("aggregator."):]: v.float() for k, v in sd.items() if k.startswith("aggregator.")}
+    save = {}
+    for slope, tag in ((0.01, "s001"), (0.1, "s01")):
+        agg = load_aggregator(slope=slope)
+        agg.load_state_dict(agg_sd, strict=True)
+        if tag == "s001":
+            save.update({f"w_{k}": v for k, v in plugin_weights(agg).items()})
+        for case, seed in enumerate([5, 6]):
+            inp = random_aggregator_inputs(seed, R=6, SR=8, K=8)
+            g = torch.Generator().manual_seed(100 + seed)
+            conf = torch.rand(inp["sampled_color"].shape[:-1] + (1,), generator=g) * 1.3 - 0.15   # some outside [1e-4, 1]
+            decoded, valid, weight, _ = run_aggregator(agg, inp, full=True)
+            decoded_c, _, _, cc = run_aggregator(agg, inp, conf=conf, full=True)
+            if tag == "s001":
+                save.update({f"c{case}_{k}": v for k, v in inp.items()})
+                save[f"c{case}_sampled_conf"] = conf
+                save[f"c{case}_valid"] = valid
+                save[f"c{case}_weight"] = weight
+                save[f"c{case}_conf_coefficient"] = cc
+            save[f"c{case}_{tag}_decoded"] = decoded
+            save[f"c{case}_{tag}_decoded_conf"] = decoded_c
+    np.savez_compressed(os.path.join(OUT, "ref_trained_aggregator.npz"), **to_np(save))
 
 
 def to_np(d):
@@ -175,12 +220,25 @@ def main():
     save = {}
     for case, seed in enumerate([1, 2]):
         inp = random_aggregator_inputs(seed)
-        decoded, valid = run_aggregator(agg, inp)
+        decoded, valid, weight, cc = run_aggregator(agg, inp, full=True)
+        assert cc == 1        # no sampled_conf: the plugin's call
         save.update({f"c{case}_{k}": v for k, v in inp.items()})
         save[f"c{case}_decoded"] = decoded
         save[f"c{case}_valid"] = valid
+        save[f"c{case}_weight"] = weight
+        # ... and the legacy weight x clamp(conf) path (what `opt.prob == 1` averages with, :816-830)
+        g = torch.Generator().manual_seed(50 + seed)
+        conf = torch.rand(inp["sampled_color"].shape[:-1] + (1,), generator=g) * 1.3 - 0.15
+        decoded_c, _, weight_c, cc = run_aggregator(agg, inp, conf=conf, full=True)
+        assert torch.equal(weight_c, weight)
+        save[f"c{case}_sampled_conf"] = conf
+        save[f"c{case}_conf_coefficient"] = cc
+        save[f"c{case}_decoded_conf"] = decoded_c
     save.update({f"wargs_{k}": np.asarray(v) for k, v in w_args.items()})
     np.savez_compressed(os.path.join(OUT, "ref_aggregator.npz"), **to_np(save))
+
+    # ---- the shipped TRAINED aggregator -------------------------------------------------------
+    trained_fixture()
 
     print("golden fixtures written to", os.path.abspath(OUT))
 

@@ -400,9 +400,21 @@ def linear_weights(dists, pnt_mask):
     return pnt_mask * (1.0 / torch.clamp(torch.norm(dists[..., :3], dim=-1), min=1e-6))
 
 
+def conf_coefficient(s_conf):
+    """studio_model.py:288-292 (== the legacy gradiant_clamp, point_aggregators.py:816-818): clamp(conf, 1e-4, 1) with
+    a straight-through gradient.  s_conf [..., K, 1] -> [..., K]."""
+    conf = s_conf[..., 0]
+    return conf - (conf - torch.clamp(conf, min=0.0001, max=1)).detach()
+
+
 def decode_features(w: Dict[str, torch.Tensor], cfg: OracleConfig, s_color, Rw2c, s_dir, s_emb, s_pers, s_xyz,
-                    loc, loc_w, pnt_mask, sample_ray_dirs):
-    """studio_model.py:270-365: per-sample [sigma, r, g, b]; zero where no neighbour."""
+                    loc, loc_w, pnt_mask, sample_ray_dirs, s_conf=None, slope: float = 0.1):
+    """studio_model.py:270-365: per-sample [sigma, r, g, b]; zero where no neighbour.  Returns (decoded, sample_valid,
+    weight): `weight` is the normalised inverse-distance weight the legacy forward also hands back
+    (point_aggregators.py:813-830).  The plugin never multiplies by the confidence (s_conf=None); with s_conf the
+    LEGACY path runs: the aggregation uses weight x clamp(conf) (point_aggregators.py:816-826) -- what the probing
+    outputs average with.  slope: LeakyReLU slope (0.1 in the plugin, studio_model.py:197-198; the legacy net was
+    trained with 0.01)."""
     sample_valid = torch.any(pnt_mask, dim=-1).view(-1)
     total_len = len(sample_valid)
     in_shape = loc_w.shape
@@ -429,15 +441,18 @@ def decode_features(w: Dict[str, torch.Tensor], cfg: OracleConfig, s_color, Rw2c
     feat = s_emb.reshape(-1, s_emb.shape[-1])[flat, :]
     feat = torch.cat([feat, positional_encoding(feat, cfg.num_feat_freqs)], dim=-1)
     feat = torch.cat([feat, d], dim=-1)
+    norm_weight = weight
+    if s_conf is not None:
+        weight = weight * conf_coefficient(s_conf)
     weight = weight.view(B * R * SR, K, 1)
-    feat = _mlp(feat, w, "mlp_base", 2)
+    feat = _mlp(feat, w, "mlp_base", 2, slope)
 
     col = s_color.reshape(-1, 3)[flat, :]
     feat = torch.cat([feat, col], dim=-1)
     sdir = s_dir.reshape(-1, 3)[flat, :] @ Rt
     ov = ori_view[..., None, :].repeat(1, K, 1).view(-1, 3)[flat, :]
     feat = torch.cat([feat, sdir - ov, torch.sum(sdir * ov, dim=-1, keepdim=True)], dim=-1)
-    feat = _mlp(feat, w, "mlp_head", 2)
+    feat = _mlp(feat, w, "mlp_head", 2, slope)
 
     alpha = F.relu(F.linear(feat, w["field_output_density.net.weight"], w["field_output_density.net.bias"]))
     holder = torch.zeros([B * R * SR * K, 1])
@@ -448,12 +463,12 @@ def decode_features(w: Dict[str, torch.Tensor], cfg: OracleConfig, s_color, Rw2c
     agg = torch.sum(holder.view(B * R * SR, K, -1) * weight, dim=-2).view(-1, feat.shape[-1])[sample_valid, :]
 
     c = torch.cat([agg, viewdirs], dim=-1)
-    c = _mlp(c, w, "mlp_color", 3)
+    c = _mlp(c, w, "mlp_color", 3, slope)
     c = torch.sigmoid(F.linear(c, w["field_output_color.net.weight"], w["field_output_color.net.bias"]))
     c = c * (1 + 2 * 0.001) - 0.001
     out = torch.zeros([total_len, 4])
     out[sample_valid] = torch.cat([alpha, c], dim=-1)
-    return out.view(in_shape[:-1] + (4,)), sample_valid.view(in_shape[:-1]), weight.view(B, R, SR, K)
+    return out.view(in_shape[:-1] + (4,)), sample_valid.view(in_shape[:-1]), norm_weight.view(B, R, SR, K)
 
 
 def compute_ray_dist(loc, sample_valid, vsize):
@@ -564,8 +579,7 @@ def probe_outputs(decoded, sample_valid, loc, loc_w, vsize, weight, s_conf, s_xy
     g3 = lambda t: torch.gather(t, 2, ind[..., None].expand(-1, -1, -1, t.shape[-1])).squeeze(2)
     g4 = lambda t: torch.gather(t, 2, ind[..., None, None].expand(-1, -1, -1, t.shape[-2], t.shape[-1])).squeeze(2)
     max_loc = g3(loc_w)                                                                  # [1,R'',3]
-    conf_c = torch.clamp(s_conf[..., 0], min=0.0001, max=1)
-    wk = g3(weight * conf_c)[..., None]                                                  # [1,R'',K,1]
+    wk = g3(weight * conf_coefficient(s_conf))[..., None]                                                  # [1,R'',K,1]
     nb_xyz, nb_mask = g4(s_xyz), g3(pnt_mask.float()) > 0
     d = torch.norm(nb_xyz - max_loc[..., None, :], dim=-1)
     d = torch.where(nb_mask, d, torch.full_like(d, 1e10))

@@ -30,9 +30,9 @@ def _oracle_cfg(oracle, c):
     return cfg
 
 
-def _renderer(scene, wh, c, oracle_mod, cfg, precision):
+def _renderer(scene, wh, c, oracle_mod, cfg, precision, jitter=0.0, seed=0):
     return RendererHIP(scene, wh, SR=c["SR"], K=c["K"], D=cfg.z_depth_dim, radius_limit=float(oracle_mod.radius_limit(cfg)),
-                       vsize_z=cfg.vsize[2], precision=precision)
+                       vsize_z=cfg.vsize[2], precision=precision, jitter=jitter, seed=seed)
 
 
 def _window_rays(c, view, window):
@@ -42,14 +42,16 @@ def _window_rays(c, view, window):
     return campos, camrot, dirs
 
 
-def _against_oracle(oracle, device, c, pts, scene, wh, cfg, view, window, min_kept=20):
+def _against_oracle(oracle, device, c, pts, scene, wh, cfg, view, window, min_kept=20, jitter=0.0, seed=0):
     campos, camrot, dirs = _window_rays(c, view, window)
+    # jitter > 0: the oracle is fed the counter-based uniforms the kernels draw (ray = index inside the call)
+    u = oracle.jitter_uniforms(dirs.shape[0], cfg.z_depth_dim, seed) if jitter > 0 else None
     ref = oracle.render(pts, _against_oracle.w, cfg, campos[None].expand(dirs.shape[0], 3), dirs, c["near"], c["far"],
-                        camrot)
+                        camrot, jitter=jitter, u=u)
     assert ref["stats"]["rays_kept"] >= min_kept, ref["stats"]
     lists = {}
     for mode, tol in (("fp32", NORTH_STAR), ("bf16x3", OPT_IN_BF16X3)):
-        rnd = _renderer(scene, wh, c, oracle, cfg, mode)
+        rnd = _renderer(scene, wh, c, oracle, cfg, mode, jitter, seed)
         out = rnd.render(dirs.to(device), campos, camrot, c["near"], c["far"])
         assert out["counters"]["overflow"] == 0
         assert out["counters"]["rays_hit"] == ref["stats"]["rays_hit"]
@@ -144,6 +146,14 @@ def test_cfg1_full_size(oracle, gpu_device):
     assert cnt["pairs_valid"] > 5_000_000
     # a 16 x 16 window of the frame against the oracle run on the full 6 M-point cloud
     _against_oracle(oracle, gpu_device, c, pts, scene, wh, cfg, 0, (392, 408, 392, 408), min_kept=100)
+    # ... and the same window at the reference's coarse-sample jitter of 0.3 (studio_utils.py:166), seed 7: the exact
+    # configuration bench.py's `value` is measured on
+    ref_j = _against_oracle(oracle, gpu_device, c, pts, scene, wh, cfg, 0, (392, 408, 392, 408), min_kept=100,
+                            jitter=0.3, seed=7)
+    campos, camrot, dirs = _window_rays(c, 0, (392, 408, 392, 408))
+    ref_0 = oracle.render(pts, _against_oracle.w, cfg, campos[None].expand(dirs.shape[0], 3), dirs, c["near"], c["far"],
+                          camrot)
+    assert (ref_j["coarse_raycolor"] - ref_0["coarse_raycolor"]).abs().max().item() > 1e-4   # the jitter moved samples
 
 
 def test_cfg3_dtu_full_size(oracle, gpu_device):
