@@ -142,6 +142,104 @@ def pmc_traffic(kernel, workload_key):
     return best
 
 
+def plugin_legs(args, cfgd, points, weights, cams, dev, near, far):
+    """rays/s through the plugin mirror's surface on the SAME workload as `value` (cloud, views, SR, K, jitter 0.3, planes
+    near / far handed over in the bundle as the datamanager's config states them, studio_datamanager.py:40-41): camera
+    ray bundles as studio_datamanager.py:104-110 builds them ([H, W, .] tensors resident in HBM, the rotation expanded
+    per pixel), one get_outputs_for_camera_ray_bundle call per frame.  Then the training step at the batch `ns-train`
+    draws (4096 random pixels of one image, studio_config.py:20-21)."""
+    from pointnerf2studio_amd.model import PointNerf, PointNerfConfig
+    from pointnerf2studio_amd.ns_compat import RayBundle
+    H, W = cfgd["H"], cfgd["W"]
+    sd = {"neural_points.xyz": points["xyz"], "neural_points.points_embeding": points["embedding"],
+          "neural_points.points_conf": points["conf"], "neural_points.points_dir": points["dir"],
+          "neural_points.points_color": points["color"], "neural_points.Rw2c": points["Rw2c"]}
+    cfg = PointNerfConfig(ranges=list(cfgd["ranges"]), max_o=cfgd["max_o"], SR=cfgd["SR"], K=cfgd["K"], P=cfgd["P"],
+                          vsize=[cfgd["vsize"]] * 3, hip_mlp_mode=args.precision, enable_collider=False,
+                          eval_num_rays_per_chunk=REF_CHUNK)
+    model = PointNerf(cfg, point_state_dict=sd).to(dev)
+    model.load_state_dict(weights, strict=False)
+    model.neural_points.jitter = float(args.jitter)
+    bundles = []
+    for campos, camrot in cams:
+        d = synthetic.make_rays(H, W, campos, camrot, cfgd["angle_x"]).to(dev).reshape(H, W, 3)
+        bundles.append(RayBundle(
+            origins=campos.to(dev)[None, None].expand(H, W, 3).contiguous(), directions=d,
+            nears=torch.full((H, W, 1), float(near), device=dev), fars=torch.full((H, W, 1), float(far), device=dev),
+            metadata={"camrotc2w": camrot.to(dev)[None, None].expand(H, W, -1, -1).reshape(H, W, -1)}))
+    model.eval()
+    for s in range(max(args.warmup, 1) + len(bundles)):      # warm-up: every view once (capacity, camera memo)
+        model.get_outputs_for_camera_ray_bundle(bundles[s % len(bundles)])
+    torch.cuda.synchronize()
+    reads0, calls0 = model.host_reads, model._render_calls
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        model.get_outputs_for_camera_ray_bundle(bundles[(args.warmup + s) % len(bundles)])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ev = {"value": H * W * args.steps / dt, "unit": "rays/s", "steps": args.steps, "ms_per_frame": dt / args.steps * 1e3,
+          "fused_calls_per_frame": (model._render_calls - calls0) / args.steps,
+          "host_reads_per_frame": (model.host_reads - reads0) / args.steps, "mode": args.precision,
+          "path": "PointNerf.get_outputs_for_camera_ray_bundle([H, W] RayBundle) -> one pnr_render_views call per frame "
+                  "(nerfstudio's inherited loop: 278 calls of 2304 rays, studio_config.py:25)"}
+    # the inherited chunk loop on the same frames, for the record (3 frames)
+    model.config.hip_eval_one_call = False
+    model.get_outputs_for_camera_ray_bundle(bundles[0])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(3):
+        model.get_outputs_for_camera_ray_bundle(bundles[s % len(bundles)])
+    torch.cuda.synchronize()
+    ev["chunk_loop_of_2304_rays"] = {"value": H * W * 3 / (time.perf_counter() - t0), "unit": "rays/s", "frames": 3}
+    model.config.hip_eval_one_call = True
+
+    # ---- training step: 4096 random pixels of view 0, a NEW bundle object per step as the datamanager hands them over
+    model.train()
+    gen = torch.Generator().manual_seed(12)
+    full = bundles[0].directions.reshape(-1, 3)
+    campos0, camrot0 = cams[0]
+    opt = torch.optim.Adam([{"params": g, "lr": lr} for g, lr in
+                            ((model.get_param_groups()["fields"], 5e-4), (model.get_param_groups()["neural_points"], 2e-3))])
+    callbacks = model.get_training_callbacks(None)
+    n_rays = 4096
+
+    def one_step(with_adam):
+        pick = torch.randperm(full.shape[0], generator=gen)[:n_rays].to(dev)
+        b = RayBundle(origins=campos0.to(dev)[None].expand(n_rays, 3), directions=full.index_select(0, pick),
+                      nears=torch.full((n_rays, 1), float(near), device=dev),
+                      fars=torch.full((n_rays, 1), float(far), device=dev), metadata={"camrotc2w": camrot0.to(dev)})
+        batch = {"image": torch.rand((n_rays, 3), device=dev)}
+        opt.zero_grad(set_to_none=True)
+        out = model(b)
+        loss = sum(model.get_loss_dict(out, batch).values())
+        loss.backward()
+        if with_adam:
+            opt.step()
+        for cb in callbacks:
+            cb.run_callback(step=0)
+
+    tr = {"rays": n_rays, "mode": args.precision}
+    for name, with_adam, iters in (("plugin_step_ms", False, 20), ("plugin_step_with_adam_ms", True, 20)):
+        for _ in range(5):
+            one_step(with_adam)
+        torch.cuda.synchronize()
+        reads0 = model.host_reads
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            one_step(with_adam)
+        torch.cuda.synchronize()
+        tr[name] = (time.perf_counter() - t0) / iters * 1e3
+        tr["host_reads_per_step"] = (model.host_reads - reads0) / iters
+    tr["rays_per_sec"] = n_rays / (tr["plugin_step_ms"] * 1e-3)
+    tr["note"] = ("wall clock per step over 20 steps, host running ahead of the device: PointNerf.forward (fused render, "
+                  "rows of the touched points refreshed from the bound parameters) + get_loss_dict + backward (fused; point "
+                  "gradients accumulated into persistent dense buffers) + the after-step callback; _with_adam adds "
+                  "torch.optim.Adam over all parameters (dense: 6 M x 38 point values), which is nerfstudio's, not this "
+                  "path's")
+    del model
+    return {"eval": ev, "train": tr}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -444,6 +542,14 @@ def main():
                                   "dense [N,32] gradient"})
             del rnd_t
 
+    # the PLUGIN surface, for the record beside `value` (which times the C-ABI call): the same workload through
+    # PointNerf.get_outputs_for_camera_ray_bundle -- the path `ns-eval` / the trainer's eval images take
+    # (studio_datamanager.py:104-110 -> studio_model.py:263) -- and one training step as `ns-train` runs it
+    # (PointNerf.forward + get_loss_dict + backward + the after-step callback, studio_model.py:263-431)
+    plugin = None
+    if world == 1 and not emulate and not args.no_other_mode:
+        plugin = plugin_legs(args, cfgd, points, weights, cams, dev, near, far)
+
     if rank == 0 or emulate:
         samples = acc_cnt[3]
         result = {
@@ -477,6 +583,10 @@ def main():
             result["with_early_ray_termination"] = early
         if train is not None:
             result["training_step"] = train
+        if plugin is not None:
+            result["plugin_eval"] = plugin["eval"]
+            result["plugin_eval"]["fraction_of_value"] = plugin["eval"]["value"] / value
+            result["plugin_training_step"] = plugin["train"]
         if world == 1 and not emulate and args.cpu_rays_side > 0:
             cb, ref, dirs, campos, camrot = cpu_baseline(points, weights, cfgd, args.cpu_rays_side, azimuths[0], args.cpu_passes,
                                                          args.cpu_budget_s)

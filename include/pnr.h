@@ -146,6 +146,27 @@ int pnr_scene_info(const pnr_scene_t *scene, int64_t info[8]);
 int pnr_points_pack(pnr_scene_t *scene, const float *d_xyz, const float *d_embedding, const float *d_conf,
                     const float *d_dir, const float *d_color, int64_t N, void *stream);
 
+/* Re-packs ONLY the listed rows: what a training loop needs after an optimiser step, which changes the features of
+ * the U points the batch's rays touched (about 60 k of 6 M at 4096 rays), not the whole cloud -- pnr_points_pack over
+ * 6 M points moves 2.3 GB per step.  d_index [n_index] int32 point indices (any order; duplicates allowed; entries
+ * outside [0, N) are skipped).  d_n_index (may be null): a DEVICE int64 -- only the first min(*d_n_index, n_index)
+ * entries are used, so a list whose length only the device knows (pnr_render_touched) needs no host read.  The scene
+ * must hold the packed rows of a cloud of the same N (pnr_points_pack once).  Replaces nothing in the reference: its
+ * gathers read the parameter tensors directly (studio_utils.py:199-207); this keeps the packed copy equal to them. */
+int pnr_points_pack_rows(pnr_scene_t *scene, const float *d_xyz, const float *d_embedding, const float *d_conf,
+                         const float *d_dir, const float *d_color, int64_t N, const int32_t *d_index, int64_t n_index,
+                         const int64_t *d_n_index, void *stream);
+
+/* Binds the caller's LIVE point tensors to the scene (same layouts as pnr_points_pack; the pointers are retained until
+ * re-bound or unbound with all five null, and must stay valid): every following pnr_render* call re-packs, between its
+ * neighbour search and its shading stage, the rows of the distinct neighbour points it found -- the rows it is about to
+ * read, U x 340 bytes -- from those tensors.  A training loop then never runs an O(N) re-pack: whatever the optimiser did
+ * to the tensors, a render reads their current values, and pnr_render_backward (which follows a render) too.  Rows no
+ * render has touched since the last full pnr_points_pack are stale; nothing reads them.  The scene must hold packed rows
+ * of the same N.  Renders that share a bound scene must not overlap on different streams. */
+int pnr_points_bind(pnr_scene_t *scene, const float *d_xyz, const float *d_embedding, const float *d_conf,
+                    const float *d_dir, const float *d_color, int64_t N);
+
 /* ---- MLP weights: packed once per weight version ------------------------------------------------ */
 int pnr_weights_create(pnr_weights_t **out);
 int pnr_weights_destroy(pnr_weights_t *w);
@@ -265,6 +286,15 @@ typedef struct {
 int pnr_render_taps(void *d_workspace, size_t workspace_bytes, int64_t R, int64_t cap_samples, int32_t K,
                     pnr_render_taps_t *taps);
 
+/* The distinct neighbour points of the LAST render in this workspace (ascending point index): the rows of the point
+ * tensors a backward of that render can touch, hence the rows to re-pack after the optimiser step
+ * (pnr_points_pack_rows) and the rows of a sparse gradient exchange.  Writes min(U, index_cap) indices to d_index
+ * [index_cap] (entries beyond U repeat the first entry, 0 when the list is empty: harmless duplicates for a consumer of
+ * fixed length) and U itself to d_count (DEVICE int64, may be null).  No host synchronisation. */
+int pnr_render_touched(const pnr_scene_t *scene, const pnr_render_opts_t *opts, int64_t R, void *d_render_workspace,
+                       size_t render_workspace_bytes, int64_t cap_samples, int32_t *d_index, int64_t index_cap,
+                       int64_t *d_count, void *stream);
+
 /* ---- training step: gradients of a render ----------------------------------------------------------
  * Replaces what torch autograd derives when `ns-train pointnerf-original` back-propagates
  * get_loss_dict (studio_model.py:415-431) through get_outputs (studio_model.py:263-399) and
@@ -291,6 +321,14 @@ typedef struct {
     int32_t *d_point_index;
     int64_t point_cap;
 } pnr_grads_t;
+
+/* Zeroes the rows d_index[0 .. n) of dense point-gradient tensors (d_embedding [N,32], d_color [N,3], d_dir [N,3]; any
+ * may be null), n = n_index or min(*d_n_index, n_index) with d_n_index a DEVICE int64 (pnr_render_touched).  A training
+ * loop that lets pnr_render_backward accumulate into persistent dense buffers resets them with this in O(U) instead of
+ * zero-filling 768 MB per step (torch's autograd would allocate and fill a dense gradient for the index_select of
+ * studio_utils.py:199-207). */
+int pnr_point_grads_clear(float *d_embedding, float *d_color, float *d_dir, int64_t N, const int32_t *d_index,
+                          int64_t n_index, const int64_t *d_n_index, void *stream);
 
 size_t pnr_backward_workspace_bytes(int64_t cap_samples, int32_t K);
 /* Call after pnr_render / pnr_render_views with the SAME scene, rays, cameras, options, cap_samples and render

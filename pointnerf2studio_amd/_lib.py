@@ -24,7 +24,7 @@ MAX_CAMS = 16
 EXPORTED_SYMBOLS = [
     "pnr_last_error", "pnr_version", "pnr_jitter_uniform",
     "pnr_scene_create", "pnr_scene_destroy", "pnr_scene_build", "pnr_scene_info", "pnr_points_pack",
-    "pnr_scene_update", "pnr_scene_update_info", "pnr_render_probe",
+    "pnr_scene_update", "pnr_scene_update_info", "pnr_render_probe", "pnr_points_pack_rows", "pnr_render_touched", "pnr_points_bind", "pnr_point_grads_clear",
     "pnr_weights_create", "pnr_weights_destroy", "pnr_weights_pack",
     "pnr_query_workspace_bytes", "pnr_query_raypos",
     "pnr_render_workspace_bytes", "pnr_render_workspace_bytes_for", "pnr_render", "pnr_render_views",
@@ -105,6 +105,10 @@ def load() -> C.CDLL:
     lib.pnr_scene_build.argtypes = [vp, vp, i64, C.POINTER(GridParams), vp]
     lib.pnr_scene_info.argtypes = [vp, C.POINTER(i64 * 8)]
     lib.pnr_points_pack.argtypes = [vp, vp, vp, vp, vp, vp, i64, vp]
+    lib.pnr_points_pack_rows.argtypes = [vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, vp]
+    lib.pnr_point_grads_clear.argtypes = [vp, vp, vp, i64, vp, i64, vp, vp]
+    lib.pnr_points_bind.argtypes = [vp, vp, vp, vp, vp, vp, i64]
+    lib.pnr_render_touched.argtypes = [vp, C.POINTER(RenderOpts), i64, vp, sz, i64, vp, i64, vp, vp]
     lib.pnr_scene_update.argtypes = [vp, vp, i64, C.POINTER(GridParams), vp, vp]
     lib.pnr_scene_update_info.argtypes = [vp, C.POINTER(i64 * 4)]
     lib.pnr_render_probe.argtypes = [vp, C.POINTER(CameraC), i32, vp, i64, C.POINTER(RenderOpts), i64, vp, sz, i64,

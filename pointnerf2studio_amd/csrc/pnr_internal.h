@@ -242,6 +242,10 @@ struct pnr_scene {
     DevBuf<long long> dropped;             // [1] cell code of the compat-dropped voxel, -1 none
     size_t scratch_bytes = 0;
     int64_t builds = 0, updates = 0, cells_reused = 0;
+    // pnr_points_bind: the caller's live tensors (xyz, embedding, conf, dir, color); every render re-packs the rows of
+    // its distinct neighbour points from them
+    const float *live[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int64_t live_N = 0;
 };
 
 // Packed MLP weights.  Layer l, output tile m (32 features), k-step group g (4 k-steps), lane, 4 floats:
@@ -339,6 +343,8 @@ int launch_knn(const GridView &g, int K, float radius_limit, RenderWs &ws, int64
 int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr, const float *d_dirs,
                  const pnr_render_opts_t &opts, int64_t R, RenderWs &ws, int64_t cap, int64_t *d_counters,
                  hipStream_t stream, hipEvent_t ev_points, hipEvent_t ev_between);
+int launch_refresh_rows(const pnr_scene *scene, const int *pt_list, const int *n_unique, int64_t u_cap,
+                        hipStream_t stream);
 int launch_composite(const CamRef &cr, const pnr_render_opts_t &opts, int64_t R, RenderWs &ws, float *d_rgb,
                      float *d_depth, float *d_acc, int8_t *d_ray_mask, int64_t *d_counters,
                      hipStream_t stream);

@@ -363,6 +363,9 @@ static int render_views(const pnr_scene_t *scene, const pnr_weights_t *weights, 
     rc = launch_knn(scene->grid, opts->K, opts->radius_limit, ws, cap_samples, d_counters, stream,
                     factored ? scene->N : 0);
     if (rc != PNR_OK) return rc;
+    // bound point tensors (pnr_points_bind, a training loop): the rows this call reads are re-packed from them first
+    rc = launch_refresh_rows(scene, ws.pt_list, ws.n_sel + 3, ws.u_cap, stream);
+    if (rc != PNR_OK) return rc;
     if (prof) PNR_HIP_CHECK(hipEventRecord(g_ev[2], stream));
     // events in time order: 0 select 1 knn 2 point-part 6 shade-pairs 3 shade-colour 4 composite 5
     rc = launch_shade(scene, weights, cr, shade_dirs, *opts, R, ws, cap_samples, d_counters, stream,
@@ -567,6 +570,42 @@ extern "C" int pnr_render_probe(const pnr_scene_t *scene, const pnr_camera_t *ca
     hipLaunchKernelGGL(k_probe, dim3((unsigned)((R + TPB - 1) / TPB)), dim3(TPB), 0, stream, cr, *opts, R, ws.ray_cnt,
                        ws.ray_off, ws.ray_flag, ws.smp_loc, ws.smp_out, ws.n_sel, ws.smp_pidx,
                        reinterpret_cast<const float4 *>(scene->point_rows), *out);
+    PNR_HIP_CHECK(hipGetLastError());
+    return PNR_OK;
+}
+
+namespace pnr {
+__global__ void __launch_bounds__(TPB) k_touched(const int *__restrict__ n_sel, const int *__restrict__ pt_list,
+                                                  int *__restrict__ out, int64_t cap, long long *__restrict__ count)
+{
+    const int U = n_sel[3];
+    const int pad = U > 0 ? pt_list[0] : 0;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < cap; i += (int64_t)gridDim.x * TPB)
+        out[i] = i < U ? pt_list[i] : pad;
+    if (count && blockIdx.x == 0 && threadIdx.x == 0) *count = U;
+}
+}  // namespace pnr
+
+extern "C" int pnr_render_touched(const pnr_scene_t *scene, const pnr_render_opts_t *opts, int64_t R,
+                                  void *d_render_workspace, size_t render_workspace_bytes, int64_t cap_samples,
+                                  int32_t *d_index, int64_t index_cap, int64_t *d_count, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    PNR_REQUIRE(scene && opts && d_render_workspace && d_index, "pnr_render_touched: null argument");
+    if (!scene->built) {
+        set_error("pnr_render_touched: scene not built");
+        return PNR_ERR_STATE;
+    }
+    PNR_REQUIRE(index_cap >= 1, "pnr_render_touched: index_cap=%lld", (long long)index_cap);
+    const size_t need = pnr_render_workspace_bytes_for(scene, opts, R, cap_samples);
+    if (render_workspace_bytes < need) {
+        set_error("pnr_render_touched: workspace of %zu bytes < %zu of the render it follows", render_workspace_bytes, need);
+        return PNR_ERR_WORKSPACE;
+    }
+    RenderWs ws = carve_render_ws(d_render_workspace, R, cap_samples, opts->K, scene->N, scene->info[2]);
+    const unsigned blocks = (unsigned)std::min<int64_t>((index_cap + TPB - 1) / TPB, 1024);
+    hipLaunchKernelGGL(k_touched, dim3(blocks), dim3(TPB), 0, stream, ws.n_sel, ws.pt_list, d_index, index_cap,
+                       reinterpret_cast<long long *>(d_count));
     PNR_HIP_CHECK(hipGetLastError());
     return PNR_OK;
 }

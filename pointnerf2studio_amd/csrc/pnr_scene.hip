@@ -210,6 +210,39 @@ __global__ void __launch_bounds__(TPB) k_pack_points(const float *__restrict__ x
     reinterpret_cast<float4 *>(rows)[i * 12 + c] = v;
 }
 
+// the same for a LIST of rows: one thread per (list entry, float4 chunk); the number of entries may live on the device
+__global__ void __launch_bounds__(TPB) k_pack_point_rows(const float *__restrict__ xyz, const float *__restrict__ emb,
+                                                          const float *__restrict__ conf, const float *__restrict__ dir,
+                                                          const float *__restrict__ color, int64_t N,
+                                                          const int *__restrict__ index, int64_t n_index,
+                                                          const long long *__restrict__ n_dev,
+                                                          const int *__restrict__ n_dev32, float *__restrict__ rows)
+{
+    int64_t n = n_index;
+    if (n_dev) n = min((int64_t)*n_dev, n_index);
+    if (n_dev32) n = min((int64_t)*n_dev32, n_index);
+    for (int64_t t = (int64_t)blockIdx.x * TPB + threadIdx.x; t < n * 12; t += (int64_t)gridDim.x * TPB) {
+        const int64_t e = t / 12;
+        const int c = (int)(t - e * 12);
+        const int64_t i = index[e];
+        if (i < 0 || i >= N) continue;
+        float4 v;
+        if (c == 0) {
+            v = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], conf ? conf[i] : 1.0f);
+        } else if (c == 1) {
+            v = make_float4(color[3 * i], color[3 * i + 1], color[3 * i + 2], dir[3 * i]);
+        } else if (c == 2) {
+            v = make_float4(dir[3 * i + 1], dir[3 * i + 2], 0.f, 0.f);
+        } else if (c == 3) {
+            v = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            const float *q = emb + i * PNR_FEAT_DIM + (c - 4) * 4;
+            v = make_float4(q[0], q[1], q[2], q[3]);
+        }
+        reinterpret_cast<float4 *>(rows)[i * 12 + c] = v;
+    }
+}
+
 static inline unsigned nblk(int64_t n) { return (unsigned)((n + TPB - 1) / TPB); }
 
 // grow-only device buffer: reallocated (with 1/8 headroom) when the request exceeds its capacity
@@ -448,6 +481,10 @@ extern "C" int pnr_scene_destroy(pnr_scene_t *scene)
 extern "C" int pnr_scene_build(pnr_scene_t *scene, const float *d_xyz, int64_t N, const pnr_grid_params_t *p,
                                void *stream_)
 {
+    if (scene) {   // tensors bound to the previous cloud say nothing about this one
+        for (auto &q : scene->live) q = nullptr;
+        scene->live_N = 0;
+    }
     return scene_build_impl(scene, d_xyz, N, p, nullptr, (hipStream_t)stream_, "pnr_scene_build");
 }
 
@@ -460,6 +497,8 @@ extern "C" int pnr_scene_update(pnr_scene_t *scene, const float *d_xyz, int64_t 
         return PNR_ERR_STATE;
     }
     PNR_REQUIRE(d_old_index != nullptr, "pnr_scene_update: d_old_index is null (use pnr_scene_build for a new cloud)");
+    for (auto &q : scene->live) q = nullptr;
+    scene->live_N = 0;
     const int rc = scene_build_impl(scene, d_xyz, N, p, d_old_index, (hipStream_t)stream_, "pnr_scene_update");
     if (rc == PNR_OK) scene->packed = false;   // the packed rows describe the previous cloud
     return rc;
@@ -514,3 +553,64 @@ extern "C" int pnr_points_pack(pnr_scene_t *scene, const float *d_xyz, const flo
     scene->packed = true;
     return PNR_OK;
 }
+
+extern "C" int pnr_points_pack_rows(pnr_scene_t *scene, const float *d_xyz, const float *d_embedding,
+                                    const float *d_conf, const float *d_dir, const float *d_color, int64_t N,
+                                    const int32_t *d_index, int64_t n_index, const int64_t *d_n_index, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    PNR_REQUIRE(scene && d_xyz && d_embedding && d_dir && d_color && d_index, "pnr_points_pack_rows: null argument");
+    if (!scene->packed || scene->packed_N != N) {
+        set_error("pnr_points_pack_rows: the scene holds no packed rows of a %lld-point cloud (call pnr_points_pack once)",
+                  (long long)N);
+        return PNR_ERR_STATE;
+    }
+    PNR_REQUIRE(n_index >= 0 && n_index < (int64_t)0x7FFFFFFF, "pnr_points_pack_rows: n_index=%lld out of range",
+                (long long)n_index);
+    if (n_index == 0) return PNR_OK;
+    // a grid-stride launch: the list may be much shorter than n_index when its length lives on the device
+    const unsigned blocks = (unsigned)std::min<int64_t>((n_index * 12 + TPB - 1) / TPB, 4096);
+    hipLaunchKernelGGL(k_pack_point_rows, dim3(blocks), dim3(TPB), 0, stream, d_xyz, d_embedding, d_conf, d_dir, d_color, N,
+                       d_index, n_index, reinterpret_cast<const long long *>(d_n_index), (const int *)nullptr,
+                       scene->point_rows);
+    PNR_HIP_CHECK(hipGetLastError());
+    return PNR_OK;
+}
+
+extern "C" int pnr_points_bind(pnr_scene_t *scene, const float *d_xyz, const float *d_embedding, const float *d_conf,
+                               const float *d_dir, const float *d_color, int64_t N)
+{
+    PNR_REQUIRE(scene != nullptr, "pnr_points_bind: null argument");
+    if (!d_xyz && !d_embedding && !d_dir && !d_color) {   // unbind
+        for (auto &p : scene->live) p = nullptr;
+        scene->live_N = 0;
+        return PNR_OK;
+    }
+    PNR_REQUIRE(d_xyz && d_embedding && d_dir && d_color, "pnr_points_bind: null tensor (pass all null to unbind)");
+    if (!scene->packed || scene->packed_N != N) {
+        set_error("pnr_points_bind: the scene holds no packed rows of a %lld-point cloud (call pnr_points_pack once)",
+                  (long long)N);
+        return PNR_ERR_STATE;
+    }
+    scene->live[0] = d_xyz;
+    scene->live[1] = d_embedding;
+    scene->live[2] = d_conf;
+    scene->live[3] = d_dir;
+    scene->live[4] = d_color;
+    scene->live_N = N;
+    return PNR_OK;
+}
+
+namespace pnr {
+// bound tensors (pnr_points_bind): the rows of the call's distinct neighbour points are re-packed from them
+int launch_refresh_rows(const pnr_scene *scene, const int *pt_list, const int *n_unique, int64_t u_cap, hipStream_t stream)
+{
+    if (!scene->live[0] || scene->live_N != scene->N || u_cap < 1) return PNR_OK;
+    const unsigned blocks = (unsigned)std::min<int64_t>((u_cap * 12 + TPB - 1) / TPB, 2048);
+    hipLaunchKernelGGL(k_pack_point_rows, dim3(blocks), dim3(TPB), 0, stream, scene->live[0], scene->live[1],
+                       scene->live[2], scene->live[3], scene->live[4], scene->N, pt_list, u_cap,
+                       (const long long *)nullptr, n_unique, scene->point_rows);
+    PNR_HIP_CHECK(hipGetLastError());
+    return PNR_OK;
+}
+}  // namespace pnr

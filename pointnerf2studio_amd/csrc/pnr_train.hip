@@ -1601,6 +1601,45 @@ static void gemm_weight(hipStream_t st, bool bf, const float *dZ, int lda, const
 
 using namespace pnr;
 
+namespace pnr {
+__global__ void __launch_bounds__(256) k_clear_point_rows(float *__restrict__ d_emb, float *__restrict__ d_color,
+                                                          float *__restrict__ d_dir, int64_t N,
+                                                          const int *__restrict__ index, int64_t n_index,
+                                                          const long long *__restrict__ n_dev)
+{
+    int64_t n = n_index;
+    if (n_dev) n = min((int64_t)*n_dev, n_index);
+    // 38 floats per listed point: one thread per (entry, float)
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n * 64; t += (int64_t)gridDim.x * 256) {
+        const int64_t e = t >> 6;
+        const int c = (int)(t & 63);
+        const int64_t i = index[e];
+        if (i < 0 || i >= N || c >= 38) continue;
+        if (c < 32) {
+            if (d_emb) d_emb[i * 32 + c] = 0.f;
+        } else if (c < 35) {
+            if (d_color) d_color[i * 3 + (c - 32)] = 0.f;
+        } else if (d_dir) {
+            d_dir[i * 3 + (c - 35)] = 0.f;
+        }
+    }
+}
+}  // namespace pnr
+
+extern "C" int pnr_point_grads_clear(float *d_embedding, float *d_color, float *d_dir, int64_t N, const int32_t *d_index,
+                                     int64_t n_index, const int64_t *d_n_index, void *stream_)
+{
+    PNR_REQUIRE(d_index != nullptr && N >= 1, "pnr_point_grads_clear: null index / N=%lld", (long long)N);
+    PNR_REQUIRE(n_index >= 0 && n_index < (int64_t)0x7FFFFFFF, "pnr_point_grads_clear: n_index=%lld out of range",
+                (long long)n_index);
+    if (n_index == 0) return PNR_OK;
+    const unsigned blocks = (unsigned)std::min<int64_t>((n_index * 64 + 255) / 256, 2048);
+    hipLaunchKernelGGL(pnr::k_clear_point_rows, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, d_embedding, d_color,
+                       d_dir, N, d_index, n_index, reinterpret_cast<const long long *>(d_n_index));
+    PNR_HIP_CHECK(hipGetLastError());
+    return PNR_OK;
+}
+
 extern "C" size_t pnr_backward_workspace_bytes(int64_t cap_samples, int32_t K)
 {
     if (cap_samples < 1) cap_samples = 1;

@@ -208,6 +208,30 @@ def _index_from_f32_halves(lo: torch.Tensor, hi: torch.Tensor) -> torch.Tensor:
     return lo.to(torch.long) + hi.to(torch.long) * 16777216
 
 
+POINT_TENSORS_EXCHANGED_SPARSELY = ("neural_points.points_embeding", "neural_points.points_color",
+                                    "neural_points.points_dir")
+
+
+def wrap_data_parallel(model, device_ids=None, average: bool = True, **ddp_kwargs):
+    """The DDP wrap of studio_pipeline.py:48-53 for the fused training step.  The reference hands EVERY parameter to
+    DDP: 768 MB of `points_embeding.grad` all-reduced per step at 6 M points, of which a 4096-ray batch touches ~60 k
+    rows.  Here the three point tensors whose gradients the fused backward writes itself are excluded from DDP
+    (`_set_params_and_buffers_to_ignore_for_model`) and exchanged as ROWS inside the backward
+    (`GradExchange.exchange_dense_rows`, ~10 MB per rank); DDP keeps all-reducing the rest: the nine Linear layers
+    (1.4 MB, one bucket) and `points_conf` (its gradient comes from torch autograd, dense [1,N,1]).  Needs
+    hip_fused_training and hip_sparse_point_grads (the defaults); otherwise the plain wrap of the reference is returned.
+    Returns the DDP module; `model.grad_exchange` is set."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    cfg = getattr(model, "config", None)
+    fused = (getattr(cfg, "hip_fused_training", True) and getattr(cfg, "hip_sparse_point_grads", True)
+             and model._fusable())
+    ddp_kwargs.setdefault("find_unused_parameters", True)
+    if fused:
+        DDP._set_params_and_buffers_to_ignore_for_model(model, list(POINT_TENSORS_EXCHANGED_SPARSELY))
+        model.grad_exchange = GradExchange(average=average)
+    return DDP(model, device_ids=device_ids, **ddp_kwargs)
+
+
 class GradExchange:
     """MLP gradients: ONE all_reduce of a flat 1.4-MB buffer.  Point gradients: SPARSE -- only the rows of the
     neighbour points this rank's rays touched travel: one all_gather of the row counts, one of the padded
@@ -218,6 +242,17 @@ class GradExchange:
     def __init__(self, world: Optional[int] = None, average: bool = True):
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.average = average
+
+    @staticmethod
+    def _all_gather(out: torch.Tensor, inp: torch.Tensor) -> None:
+        """all_gather_into_tensor; staged through host memory on a backend that moves host memory only (gloo: the CPU
+        rehearsals of this module, and two ranks sharing one GPU in tests/test_gpu_dp_training.py)."""
+        if inp.is_cuda and dist.get_backend() == "gloo":
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(o, inp.cpu())
+            out.copy_(o)
+        else:
+            dist.all_gather_into_tensor(out, inp)
 
     def reduce_mlp(self, tensors: List[torch.Tensor]) -> None:
         """In place.  `tensors` are the weight / bias gradients; views of one flat buffer are reduced without a copy."""
@@ -239,7 +274,8 @@ class GradExchange:
         """The sparse form end to end: this rank's rows as pnr_render_backward emits them (`point_index` [U] int64
         ascending, `point_grads` [U, 40] = [d_embedding 32 | d_color 3 | d_dir 3 | 0 0]; RendererHIP.backward(...,
         sparse_points=True)) in, the union over all ranks out: (index [U_all] ascending, rows [U_all, 40]), rows of a
-        point several ranks touched summed in rank order (deterministic).  No dense [N, .] tensor exists on the way:
+        point several ranks touched summed in rank order (one index_add_ per rank: bitwise repeatable on a GPU too).  No
+        dense [N, .] tensor exists on the way:
         the optimiser (or an index_add_ into .grad) consumes the rows."""
         dev = point_grads.device
         idx = point_index.to(device=dev, dtype=torch.long).reshape(-1)
@@ -247,7 +283,7 @@ class GradExchange:
             return idx, point_grads
         u = torch.tensor([idx.numel()], dtype=torch.long, device=dev)
         counts = torch.empty(self.world, dtype=torch.long, device=dev)
-        dist.all_gather_into_tensor(counts, u)
+        self._all_gather(counts, u)
         counts_h = counts.tolist()
         u_max = max(max(counts_h), 1)
         block = torch.zeros((u_max, 40), dtype=torch.float32, device=dev)
@@ -255,14 +291,20 @@ class GradExchange:
         block[:n, :38] = point_grads[:, :38]
         block[:n, 38], block[:n, 39] = _index_to_f32_halves(idx)     # the two pad columns carry the index
         gathered = torch.empty((self.world * u_max, 40), dtype=torch.float32, device=dev)
-        dist.all_gather_into_tensor(gathered, block)
-        rows = torch.cat([gathered[r * u_max: r * u_max + counts_h[r]] for r in range(self.world)])
-        all_idx = _index_from_f32_halves(rows[:, 38], rows[:, 39])
+        self._all_gather(gathered, block)
+        per_rank = [gathered[r * u_max: r * u_max + counts_h[r]] for r in range(self.world)]
+        all_idx = torch.cat([_index_from_f32_halves(rows[:, 38], rows[:, 39]) for rows in per_rank])
         uniq, inv = torch.unique(all_idx, sorted=True, return_inverse=True)
         out = torch.zeros((uniq.numel(), 40), dtype=torch.float32, device=dev)
-        # rank order inside every point: index_add_ over a stable sort by (point, rank) position
-        order = torch.argsort(inv, stable=True)
-        out.index_add_(0, inv[order], torch.cat([rows[order, :38], torch.zeros((rows.shape[0], 2), device=dev)], dim=1))
+        # rank order inside every point: ONE index_add_ per rank, in rank order.  A point appears at most once in a
+        # rank's rows, so no two adds of one call meet in a row (on a GPU index_add_ is made of float atomics: a single
+        # call over all ranks' rows would leave the order of a point's adds to the scheduler)
+        off = 0
+        for rows in per_rank:
+            n_r = rows.shape[0]
+            if n_r:
+                out[:, :38].index_add_(0, inv[off:off + n_r], rows[:, :38])
+            off += n_r
         if self.average:
             out.div_(self.world)
         return uniq, out
@@ -277,7 +319,7 @@ class GradExchange:
         touched = touched.to(device=dev, dtype=torch.long).reshape(-1)
         u = torch.tensor([touched.numel()], dtype=torch.long, device=dev)
         counts = torch.empty(self.world, dtype=torch.long, device=dev)
-        dist.all_gather_into_tensor(counts, u)
+        self._all_gather(counts, u)
         counts_h = counts.tolist()
         u_max = max(max(counts_h), 1)
         # one fixed-width block per rank: [index low 24 bits | index high bits | d_embedding 32 | d_color 3 | d_dir 3]
@@ -289,24 +331,55 @@ class GradExchange:
         block[:n, 34:37] = d_color[touched]
         block[:n, 37:40] = d_dir[touched]
         gathered = torch.empty((self.world * u_max, 40), dtype=torch.float32, device=dev)
-        dist.all_gather_into_tensor(gathered, block)
+        self._all_gather(gathered, block)
         me = dist.get_rank()
         received = 0
         seen = [touched]
+        # the rows of a point are summed in RANK order on every rank (own rows taken out first, then every rank's rows
+        # added back one index_add_ per rank: a point appears at most once per rank, so no call adds twice into a row):
+        # all ranks end up with the same bits
+        mine = (d_embedding[touched].clone(), d_color[touched].clone(), d_dir[touched].clone())
+        d_embedding[touched] = 0
+        d_color[touched] = 0
+        d_dir[touched] = 0
         for r in range(self.world):
-            if r == me or counts_h[r] == 0:
+            if counts_h[r] == 0:
                 continue
-            rows = gathered[r * u_max: r * u_max + counts_h[r]]
-            idx = _index_from_f32_halves(rows[:, 0], rows[:, 1])
-            d_embedding.index_add_(0, idx, rows[:, 2:34])
-            d_color.index_add_(0, idx, rows[:, 34:37])
-            d_dir.index_add_(0, idx, rows[:, 37:40])
-            seen.append(idx)
-            received += counts_h[r]
+            if r == me:
+                idx, e, c, d = touched, mine[0], mine[1], mine[2]
+            else:
+                rows = gathered[r * u_max: r * u_max + counts_h[r]]
+                idx = _index_from_f32_halves(rows[:, 0], rows[:, 1])
+                e, c, d = rows[:, 2:34], rows[:, 34:37], rows[:, 37:40]
+                seen.append(idx)
+                received += counts_h[r]
+            d_embedding.index_add_(0, idx, e)
+            d_color.index_add_(0, idx, c)
+            d_dir.index_add_(0, idx, d)
+        self.last_union = torch.cat(seen).unique()
         if self.average:
             # only rows some rank touched are non-zero: scale those
-            all_idx = torch.cat(seen).unique()
+            all_idx = self.last_union
             d_embedding[all_idx] /= self.world
             d_color[all_idx] /= self.world
             d_dir[all_idx] /= self.world
         return received
+
+    def exchange_dense_rows(self, index: torch.Tensor, count: torch.Tensor, targets):
+        """The fused training step's point-gradient exchange (model._after_point_backward): this rank's backward has
+        accumulated its rows into the dense tensors `targets` = {'embedding' [.., N, 32], 'color' [.., N, 3], 'dir'
+        [.., N, 3]} (None = not trainable); `index` (int32, padded) / `count` (int64 [1], device) are the rows it touched
+        (RendererHIP.touched).  Only those rows travel (reduce_points); returns the union of all ranks' rows in the same
+        padded form, which is what the caller has to clean before the tensors are reused.  One host read (the count)."""
+        n = int(count.item())
+        touched = index[:n].to(torch.long)
+        ref = next(t for t in targets.values() if t is not None)
+        N = ref.numel() // ref.shape[-1]
+        dense = {}
+        for key, width in (("embedding", 32), ("color", 3), ("dir", 3)):
+            t = targets.get(key)
+            dense[key] = t.view(N, width) if t is not None else torch.zeros((N, width), dtype=torch.float32,
+                                                                            device=ref.device)
+        self.reduce_points(touched, dense["embedding"], dense["color"], dense["dir"])
+        union = self.last_union.to(torch.int32)
+        return union, torch.tensor([union.numel()], dtype=torch.int64, device=union.device)

@@ -3,18 +3,25 @@
 dicts and optimiser groups carry over), `get_outputs` / `get_param_groups` / `get_loss_dict` /
 `get_training_callbacks` / `fill_invalid` / `linear`.
 
-get_outputs has two bodies:
-  * outside training (the path the metric times, `get_outputs_for_camera_ray_bundle`): ONE call into the
-    fused HIP renderer (pnr_render) -- query, gather, MLPs on fp32 MFMA, composite;
-  * in training mode: the reference's own op sequence on PyTorch-ROCm tensors (autograd needs it until the
-    backward kernels of SURVEY.md 8f-1 exist), with the HIP drop-in op doing the query.
-There is no CPU path in either.
+Every body of get_outputs is the fused HIP path (include/pnr.h):
+  * without autograd (the path the metric times): `get_outputs_for_camera_ray_bundle` renders the whole [H, W] camera
+    bundle in ONE pnr_render_views call (nerfstudio's inherited loop would make 278 calls of 2304 rays per 800 x 800
+    image, studio_config.py:25); `get_outputs` renders a ray bundle in one call;
+  * with autograd (training steps, and eval-mode calls with gradients enabled): pnr_render_views forwards and
+    pnr_render_backward backwards behind one torch.autograd.Function; the point gradients are accumulated straight
+    into persistent dense buffers handed out as `.grad` (no 768-MB zero fill per step), the packed point rows are
+    refreshed by the render itself from the bound parameters (no O(N) re-pack per step), and a step contains ONE
+    device-to-host read (the bundle's camera, near and far).
+The reference's own op sequence under torch autograd survives as `_get_outputs_autograd`, reachable only with
+`hip_allow_torch_fallback=True` (the fused-vs-autograd comparison test); a configuration the fused path does not cover
+raises instead of landing on rocBLAS silently.  There is no CPU path anywhere.
 """
 from __future__ import annotations
 
 import dataclasses
 import glob
 import os
+import weakref
 from dataclasses import dataclass
 from pathlib import Path
 from typing import Any, Dict, List, Optional, Tuple
@@ -103,6 +110,17 @@ class PointNerfConfig(ModelConfig):
     # the `aggregator.*` tensors of the legacy checkpoint (same layer shapes; the legacy net was trained with
     # LeakyReLU slope 0.01 and a Softplus density, so this is a warm start, not an equivalence)
     hip_load_aggregator_weights: bool = False
+    # get_outputs_for_camera_ray_bundle: the whole camera bundle in ONE fused call (False = nerfstudio's chunk loop over
+    # eval_num_rays_per_chunk rays, kept for the equality test)
+    hip_eval_one_call: bool = True
+    # training: point gradients accumulated by the backward kernels straight into persistent dense buffers that are
+    # handed out as `.grad` and cleaned row-wise (False = a fresh zero-filled dense tensor per step through autograd)
+    hip_sparse_point_grads: bool = True
+    # training: a render workspace sized for the worst case (every ray selects SR samples) cannot overflow, so a step
+    # needs no host read of the counters; used while render + backward workspaces stay below this many GiB
+    hip_train_workspace_gb: float = 48.0
+    # the reference's op sequence under torch autograd (rocBLAS GEMMs) instead of the fused kernels: only when asked
+    hip_allow_torch_fallback: bool = False
 
     def __post_init__(self):
         if self.path_point_cloud is not None:
@@ -111,14 +129,16 @@ class PointNerfConfig(ModelConfig):
 
 
 class _FusedRenderFn(torch.autograd.Function):
-    """pnr_render_views forwards, pnr_render_backward backwards (include/pnr.h).  Inputs after `ray_cam`: points_embeding,
-    points_color, points_dir and the nine (weight, bias) pairs in MLP_TENSOR_ORDER."""
+    """pnr_render_views forwards, pnr_render_backward backwards (include/pnr.h).  Inputs after `cap`: points_embeding,
+    points_color, points_dir and the nine (weight, bias) pairs in MLP_TENSOR_ORDER.  cap: capacity of the render
+    workspace in selected samples -- the worst case R * SR (no overflow possible, no host read) or None (grown on
+    demand behind a read of the counters)."""
 
     @staticmethod
-    def forward(ctx, rnd, dirs, cams, ray_cam, emb, color, pdir, *mlp):
-        out = rnd.render_views(dirs, cams, dirs.reshape(-1, 3).shape[0], ray_cam=ray_cam)
-        rnd.last_counters = out["counters"]
-        ctx.rnd = rnd
+    def forward(ctx, model, rnd, dirs, cams, ray_cam, cap, emb, color, pdir, *mlp):
+        R = dirs.shape[0]
+        out = rnd.render_views(dirs, cams, R, ray_cam=ray_cam, cap_samples=cap, sync_counters=cap is None)
+        ctx.model, ctx.rnd = model, rnd
         ctx.shapes = (emb.shape, color.shape, pdir.shape)
         ctx.state = {name + suf: mlp[2 * i + j] for i, name in enumerate(MLP_TENSOR_ORDER)
                      for j, suf in enumerate((".weight", ".bias"))}
@@ -128,16 +148,24 @@ class _FusedRenderFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rgb, _g_mask):
-        rnd = ctx.rnd
+        rnd, model = ctx.rnd, ctx.model
         if rnd.calls != ctx.call:
             raise RuntimeError("fused training: the renderer ran another render before backward(); its workspace "
                                "no longer holds this step's sample lists")
         es, cs, ds = ctx.shapes
-        g = rnd.backward(g_rgb, ctx.state, es[-2])
-        grads = [g["embedding"].view(es), g["color"].view(cs), g["dir"].view(ds)]
+        targets = model._point_grad_targets() if model.config.hip_sparse_point_grads else None
+        if targets is not None:
+            # the kernels add the touched rows into the tensors that ARE (or become) the parameters' .grad: autograd
+            # is told "no gradient" for the three point tensors
+            g = rnd.backward(g_rgb, ctx.state, es[-2], into=targets)
+            model._after_point_backward(rnd, targets)
+            grads = [None, None, None]
+        else:
+            g = rnd.backward(g_rgb, ctx.state, es[-2])
+            grads = [g["embedding"].view(es), g["color"].view(cs), g["dir"].view(ds)]
         for name in MLP_TENSOR_ORDER:
             grads += [g[name + ".weight"], g[name + ".bias"]]
-        return (None, None, None, None, *grads)
+        return (None, None, None, None, None, None, *grads)
 
 
 class PointNerf(Model):
@@ -151,11 +179,15 @@ class PointNerf(Model):
         self._point_initialized = False
         self.cameras = cameras
         self._device = "cuda"
-        self._renderer: Optional[RendererHIP] = None
-        self._renderer_train: Optional[RendererHIP] = None
+        self._renderers: Dict[bool, RendererHIP] = {}     # by eval_clamp
         self._weights: Optional[WeightsHIP] = None
         self._weights_key = None
         self._render_calls = 0
+        self._cam_memo = None       # (weakref of the last bundle, versions, cameras): see _bundle_cameras
+        self._gbuf: Dict[str, torch.Tensor] = {}          # persistent dense point-gradient buffers, by tensor
+        self._gdirty: Dict[str, list] = {}                # rows written into them since they were last all-zero
+        self.grad_exchange = None   # distributed.GradExchange when the training step is data-parallel
+        self.host_reads = 0         # device-to-host reads issued by the fused paths (tests hold the count per step)
         self._init_pointnerf()
 
     def _init_pointnerf(self):
@@ -276,8 +308,10 @@ class PointNerf(Model):
             sd[name + ".weight"], sd[name + ".bias"] = mod.weight, mod.bias
         return sd
 
-    def _fused_renderer(self, train: bool = False) -> RendererHIP:
-        scene = self.neural_points.fused_scene()
+    def _fused_renderer(self, clamp: bool = True, live: bool = False) -> RendererHIP:
+        """The renderer for eval_clamp = `clamp` (nerfstudio's RGBRenderer clamps outside training only); each owns its
+        workspace.  live: the parameter tensors are bound to the scene (training steps, see NeuralPoints.fused_scene)."""
+        scene = self.neural_points.fused_scene(live=live)
         sd = self._mlp_state()
         key = tuple((t.data_ptr(), t._version) for t in sd.values()) + (self.neural_points.points_Rw2c._version,)
         if self._weights is None or key != self._weights_key:
@@ -286,89 +320,248 @@ class PointNerf(Model):
             self._weights.pack(sd, self.neural_points.points_Rw2c.detach(), self.neural_points.points_xyz.device)
             self._weights_key = key
         c = self.config
-        if train:
-            # the training renderer has its own workspace and never clamps (nerfstudio's RGBRenderer in training)
-            if self._renderer_train is None or self._renderer_train.scene is not scene:
-                self._renderer_train = RendererHIP(scene, self._weights, SR=c.SR, K=c.K, D=c.z_depth_dim,
-                                                   radius_limit=float(self.neural_points.radius_limit_np),
-                                                   vsize_z=c.vsize[2], eval_clamp=False,
-                                                   bg=self._background_color.tolist(),
-                                                   precision=getattr(c, "hip_mlp_mode", "fp32"))
-            self._renderer_train.mlp_state = sd
-            return self._renderer_train
-        if self._renderer is None or self._renderer.scene is not scene:
-            self._renderer = RendererHIP(scene, self._weights, SR=c.SR, K=c.K, D=c.z_depth_dim,
-                                         radius_limit=float(self.neural_points.radius_limit_np),
-                                         vsize_z=c.vsize[2], eval_clamp=True, bg=self._background_color.tolist(),
-                                         precision=getattr(c, "hip_mlp_mode", "fp32"),
-                                         early_stop_eps=float(getattr(c, "hip_early_stop_eps", 0.0)))
-        return self._renderer
+        rnd = self._renderers.get(clamp)
+        if rnd is None or rnd.scene is not scene:
+            rnd = RendererHIP(scene, self._weights, SR=c.SR, K=c.K, D=c.z_depth_dim,
+                              radius_limit=float(self.neural_points.radius_limit_np), vsize_z=c.vsize[2],
+                              eval_clamp=clamp, bg=self._background_color.tolist(),
+                              precision=getattr(c, "hip_mlp_mode", "fp32"))
+            self._renderers[clamp] = rnd
+        rnd.mlp_state = sd
+        return rnd
 
-    def _bundle_cameras(self, ray_bundle):
-        """The cameras of a bundle.  The reference assumes ONE per bundle and reads origins[0] / camrotc2w[0]
-        (studio_utils.py:148-155); so does this for such bundles (one cheap all-equal test).  Bundles that mix cameras
-        -- nerfstudio's usual random-pixel batches over several images -- are rendered in
-        ONE pnr_render_views call with a per-ray camera index, up to PNR_MAX_CAMS cameras.
-        Returns (cams [(pos, rot3x3, near, far)], ray_cam int32 [R] or None)."""
-        rot, pos = self.neural_points._camera(ray_bundle)
-        near, far = ray_bundle.nears[0].item(), ray_bundle.fars[0].item()
+    # (kept names: the two renderers the tests and tools look at)
+    @property
+    def _renderer(self) -> Optional[RendererHIP]:
+        return self._renderers.get(True)
+
+    @property
+    def _renderer_train(self) -> Optional[RendererHIP]:
+        return self._renderers.get(False)
+
+    def forward(self, ray_bundle):
+        """nerfstudio's Model.forward (collider, then get_outputs) [ns-mem]; it also remembers WHICH bundle just got its
+        nears / fars from the collider, so that _bundle_cameras may take the planes from the collider's memo instead of
+        reading them back from the device."""
+        collider = getattr(self, "collider", None)
+        if collider is not None:
+            ray_bundle = collider(ray_bundle)
+            self._note_collided(ray_bundle)
+        return self.get_outputs(ray_bundle)
+
+    def _note_collided(self, ray_bundle) -> None:
+        try:
+            self._collided = weakref.ref(ray_bundle)
+        except TypeError:
+            self._collided = None
+
+    def _collider_planes(self, ray_bundle):
+        """(key, (near, far) or None): a NearFarCollider writes ones * plane, a function of its attributes and mode only
+        -- once the planes of such a collider state have been read they are known for every later bundle it fills.
+        Other colliders (no near_plane / far_plane attributes) and bundles that did not come through forward(): no key."""
+        collider = getattr(self, "collider", None)
+        ref = getattr(self, "_collided", None)
+        if collider is None or ref is None or ref() is not ray_bundle or not hasattr(collider, "near_plane") \
+                or not hasattr(collider, "far_plane"):
+            return None, None
+        key = (id(collider), bool(getattr(collider, "training", False)), float(collider.near_plane),
+               float(collider.far_plane), bool(getattr(collider, "reset_near_plane", True)))
+        return key, getattr(self, "_plane_memo", {}).get(key)
+
+    def _bundle_cameras(self, ray_bundle, one_camera: bool = False, owner=None):
+        """The cameras of a bundle.  The reference assumes ONE per bundle and reads origins[0] / camrotc2w[0] / nears[0]
+        / fars[0] with three host reads (studio_utils.py:148-155); here everything the host needs -- position, rotation,
+        near, far and an "all rays share them" flag computed on the device -- arrives in ONE 15-float read; a bundle
+        OBJECT seen before (`owner`, default the bundle itself: same tensors, same versions) costs none, and the planes
+        a NearFarCollider wrote are read once per collider state.  one_camera: the caller vouches for a single camera
+        (a camera ray bundle: nerfstudio generates it from one camera), the flag is not even computed.
+        Bundles that mix cameras -- nerfstudio's random-pixel batches over several images
+        -- are rendered in ONE pnr_render_views call with a per-ray camera index, up to PNR_MAX_CAMS cameras.
+        Returns (cams [(pos[3], rot[9], near, far)] as host floats, ray_cam int32 [R] or None)."""
         meta = ray_bundle.metadata["camrotc2w"]
+        plane_key, planes = self._collider_planes(ray_bundle)
+        owner = ray_bundle if owner is None else owner
+        tensors = (ray_bundle.origins, meta) + (() if plane_key is not None else (ray_bundle.nears, ray_bundle.fars))
+        versions = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors) + (one_camera, plane_key)
+        memo = self._cam_memo
+        if memo is not None and memo[0]() is owner and memo[1] == versions and (plane_key is None or planes is not None):
+            cams, ray_cam = memo[2]
+            if planes is not None:
+                cams = [(c[0], c[1], planes[0], planes[1]) for c in cams]
+            return cams, ray_cam
+        dev = self._device
         o = ray_bundle.origins.reshape(-1, 3)
-        if meta.shape[0] == 3 or o.shape[0] <= 1:
-            return [(pos[0], rot[0], near, far)], None
-        key = torch.cat([o, meta.reshape(o.shape[0], 9)], dim=1).to(self._device)
-        if bool((key == key[0]).all()):
-            return [(pos[0], rot[0], near, far)], None
-        uniq, inv = torch.unique(key, dim=0, return_inverse=True)
-        if uniq.shape[0] > MAX_CAMS:
-            raise RuntimeError(f"a ray bundle may mix at most {MAX_CAMS} cameras, got {uniq.shape[0]}")
-        uniq = uniq.cpu()
-        cams = [(uniq[i, :3], uniq[i, 3:].view(3, 3), near, far) for i in range(uniq.shape[0])]
-        return cams, inv.to(torch.int32)
+        per_ray = tuple(meta.shape) != (3, 3)
+        m = meta.reshape(-1, 9) if per_ray else meta.reshape(1, 9)
+        mixed_possible = per_ray and not one_camera and o.shape[0] > 1
+        same = ((o == o[0]).all() & (m == m[0]).all()).reshape(1) if mixed_possible else o.new_ones(1, dtype=torch.bool)
+        head = torch.cat([o[0].reshape(3).to(dev, torch.float32), m[0].reshape(9).to(dev, torch.float32),
+                          ray_bundle.nears.reshape(-1)[:1].to(dev, torch.float32),
+                          ray_bundle.fars.reshape(-1)[:1].to(dev, torch.float32),
+                          same.to(dev, torch.float32)]).cpu().tolist()      # the ONE host read
+        self.host_reads += 1
+        near, far = head[12], head[13]
+        if plane_key is not None:
+            if not hasattr(self, "_plane_memo"):
+                self._plane_memo = {}
+            self._plane_memo[plane_key] = (near, far)
+        if head[14] != 0.0:
+            result = ([(head[0:3], head[3:12], near, far)], None)
+        else:
+            key = torch.cat([o, m], dim=1).to(dev)
+            uniq, inv = torch.unique(key, dim=0, return_inverse=True)
+            if uniq.shape[0] > MAX_CAMS:
+                raise RuntimeError(f"a ray bundle may mix at most {MAX_CAMS} cameras, got {uniq.shape[0]}")
+            uniq = uniq.cpu().tolist()
+            self.host_reads += 1
+            result = ([(u[:3], u[3:], near, far) for u in uniq], inv.to(torch.int32))
+        try:
+            self._cam_memo = (weakref.ref(owner), versions, result)
+        except TypeError:      # a bundle type that cannot be weakly referenced: no memo
+            self._cam_memo = None
+        return result
 
-    def _get_outputs_fused(self, ray_bundle):
-        """Jitter: the reference draws torch.rand jitter even at eval (studio_utils.py:166, hard-coded 0.3); the
-        fused path uses the same fraction (`neural_points.jitter`) with the library's counter-based uniforms and
-        a fresh seed per call.  Set `neural_points.jitter = 0` for deterministic mid-point renders."""
-        cams, ray_cam = self._bundle_cameras(ray_bundle)
-        rnd = self._fused_renderer()
-        rnd.opts.jitter = float(self.neural_points.jitter)
-        rnd.opts.seed = self._render_calls & 0xFFFFFFFF
+    def _next_seed(self) -> int:
+        seed = self._render_calls & 0xFFFFFFFF
         self._render_calls += 1
-        dirs = ray_bundle.directions.to(self._device)
-        out = rnd.render_views(dirs, cams, dirs.reshape(-1, 3).shape[0], ray_cam=ray_cam)
+        return seed
+
+    def _get_outputs_fused(self, ray_bundle, one_camera: bool = False, owner=None):
+        """No autograd: one pnr_render_views call.  Jitter: the reference draws torch.rand jitter even at eval
+        (studio_utils.py:166, hard-coded 0.3); the fused path uses the same fraction (`neural_points.jitter`) with the
+        library's counter-based uniforms and a fresh seed per call.  Set `neural_points.jitter = 0` for deterministic
+        mid-point renders.  The clamp follows the module's mode as nerfstudio's RGBRenderer does."""
+        cams, ray_cam = self._bundle_cameras(ray_bundle, one_camera, owner)
+        rnd = self._fused_renderer(clamp=not self.training)
+        rnd.opts.jitter = float(self.neural_points.jitter)
+        rnd.opts.seed = self._next_seed()
+        rnd.opts.early_stop_eps = 0.0 if self.training else float(getattr(self.config, "hip_early_stop_eps", 0.0))
+        dirs = ray_bundle.directions.to(self._device).reshape(-1, 3)
+        # a small bundle (eval batches, chunks) gets a workspace that cannot overflow: no counters to read back; a whole
+        # frame keeps the capacity earlier frames needed and checks the overflow counter at the end of the call
+        cap = self._worst_case_cap(rnd, dirs.shape[0], backward=False)
+        out = rnd.render_views(dirs, cams, dirs.shape[0], ray_cam=ray_cam, cap_samples=cap, sync_counters=cap is None)
+        if cap is None:
+            self.host_reads += 1
         return {"coarse_raycolor": out["rgb"], "ray_mask": out["ray_mask"], "depth": out["depth"],
                 "accumulation": out["acc"]}
 
-    def _get_outputs_fused_train(self, ray_bundle):
-        """Training step on the fused path: pnr_render forwards (no clamp, the reference's 0.3 jitter with a fresh
-        seed per call), pnr_render_backward behind a torch.autograd.Function for d loss / d {points_embeding,
-        points_color, points_dir, MLP weights} -- what autograd derives for studio_model.py:263-399.
-        `conf_coefficient` (studio_model.py:288-292) is gathered here with torch ops so that its loss term reaches
-        points_conf: the reference's tensor is [1,R'',SR,K] with unfilled slots reading point 0
-        (studio_utils.py:193-199, clamp(pidx, 0)); the same multiset of values is returned flat, which is all the
-        loss (a mean) looks at."""
+    @torch.no_grad()
+    def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle) -> Dict[str, torch.Tensor]:
+        """The whole [H, W] camera bundle (studio_datamanager.py:104-110) in ONE fused call.  nerfstudio's inherited
+        method cuts it into eval_num_rays_per_chunk = 2304 rays (studio_config.py:25) and calls forward per chunk: 278
+        calls per 800 x 800 image, each of which -- in the reference -- rebuilds the voxel grid.  Same outputs, viewed
+        as [H, W, -1]; at jitter 0 bit-identical to the chunk loop (rays are independent), with jitter the one call
+        draws one seed for the image instead of one per chunk."""
+        if not (self._fusable() and getattr(self.config, "hip_eval_one_call", True)):
+            return super().get_outputs_for_camera_ray_bundle(camera_ray_bundle)
+        image_height, image_width = camera_ray_bundle.origins.shape[:2]
+        num_rays = image_height * image_width
+        ray_bundle = camera_ray_bundle.get_row_major_sliced_ray_bundle(0, num_rays)     # flat views, no copy
+        if getattr(self, "collider", None) is not None:
+            ray_bundle = self.collider(ray_bundle)
+            self._note_collided(ray_bundle)
+        out = self._get_outputs_fused(ray_bundle, one_camera=True, owner=camera_ray_bundle)
+        return {k: v.view(image_height, image_width, -1) for k, v in out.items() if torch.is_tensor(v)}
+
+    # ---- autograd on the fused path -----------------------------------------------------------------------
+    def _worst_case_cap(self, rnd: RendererHIP, R: int, backward: bool) -> Optional[int]:
+        """Worst-case capacity R * SR when the render (+ backward) workspaces of that size fit hip_train_workspace_gb:
+        the render cannot overflow then and nothing has to be read back.  None: grow on demand (one read per call)."""
+        worst = R * self.config.SR
+        memo = getattr(self, "_cap_memo", {})
+        key = (id(rnd.scene), R, backward)
+        if key not in memo:
+            need = rnd.lib.pnr_render_workspace_bytes_for(rnd.scene.handle, rnd.opts, R, worst)
+            if backward:
+                need += rnd.lib.pnr_backward_workspace_bytes(worst, self.config.K)
+            memo[key] = worst if need <= float(getattr(self.config, "hip_train_workspace_gb", 48.0)) * 2 ** 30 else None
+            self._cap_memo = memo
+        return memo[key]
+
+    def _point_grad_targets(self) -> Dict[str, Optional[torch.Tensor]]:
+        """Where pnr_render_backward accumulates the point gradients: for every trainable point tensor its existing
+        `.grad` if it has one, otherwise this model's persistent zero buffer, which BECOMES `.grad`.  The buffer is kept
+        all-zero outside the rows written since it was last handed out; those rows are cleared (pnr_point_grads_clear,
+        O(rows)) when a `zero_grad(set_to_none=True)` has detached it -- torch's autograd would allocate and fill a dense
+        768-MB gradient per step for the reference's index_select (studio_utils.py:199-207)."""
+        npts = self.neural_points
+        N = npts.points_xyz.shape[0]
+        rnd = self._renderers.get(not self.training) or next(iter(self._renderers.values()))
+        out: Dict[str, Optional[torch.Tensor]] = {}
+        for key, p in (("embedding", npts.points_embeding), ("color", npts.points_color), ("dir", npts.points_dir)):
+            if not p.requires_grad:
+                out[key] = None
+                continue
+            buf = self._gbuf.get(key)
+            if buf is None or buf.shape != p.shape or buf.device != p.device:
+                buf = self._gbuf[key] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                self._gdirty[key] = []
+            if p.grad is None:
+                for index, count in self._gdirty[key]:
+                    rnd.clear_point_grads(buf if key == "embedding" else None, buf if key == "color" else None,
+                                          buf if key == "dir" else None, N, index, count)
+                self._gdirty[key] = []
+                p.grad = buf
+            elif p.grad.data_ptr() != buf.data_ptr() and not (p.grad.is_contiguous() and p.grad.dtype == torch.float32):
+                raise RuntimeError(f"points_{key}.grad is not a contiguous float32 tensor")
+            out[key] = p.grad
+        return out
+
+    def _after_point_backward(self, rnd: RendererHIP, targets) -> None:
+        """Book-keeping behind a backward that accumulated into the dense buffers: the rows it touched (device list +
+        device count, no host read) are remembered for the next clean-up; a data-parallel step exchanges them here."""
+        index, count = rnd.touched()
+        if self.grad_exchange is not None and self.grad_exchange.world > 1:
+            index, count = self.grad_exchange.exchange_dense_rows(index, count, targets)
+            self.host_reads += 1
+        for key, t in targets.items():
+            buf = self._gbuf.get(key)
+            if t is not None and buf is not None and t.data_ptr() == buf.data_ptr():
+                self._gdirty[key].append((index, count))
+
+    def _get_outputs_fused_grad(self, ray_bundle):
+        """With autograd: pnr_render_views forwards (the reference's 0.3 jitter with a fresh seed per call; clamped only
+        outside training, as nerfstudio's RGBRenderer), pnr_render_backward behind a torch.autograd.Function for d loss /
+        d {points_embeding, points_color, points_dir, MLP weights} -- what autograd derives for studio_model.py:263-399.
+        In training mode `conf_coefficient` (studio_model.py:288-292) is gathered here with torch ops so that its loss
+        term reaches points_conf: the reference's tensor is [1,R'',SR,K] with unfilled slots reading point 0
+        (studio_utils.py:193-199, clamp(pidx, 0)); the same MULTISET of values is returned in a fixed-size form --
+        values [cap*K + 1] with integer multiplicities `conf_coefficient_weights` (1 for a filled slot, 0 for a slot of
+        the workspace that holds nothing, and the number of unfilled slots of kept rays for the single entry of point
+        0) -- so that no count has to reach the host; get_loss_dict takes the weighted mean, which is all the loss (a
+        mean) looks at."""
         cams, ray_cam = self._bundle_cameras(ray_bundle)
-        rnd = self._fused_renderer(train=True)
+        rnd = self._fused_renderer(clamp=not self.training, live=True)
         rnd.opts.jitter = float(self.neural_points.jitter)
-        rnd.opts.seed = self._render_calls & 0xFFFFFFFF
-        self._render_calls += 1
+        rnd.opts.seed = self._next_seed()
+        rnd.opts.early_stop_eps = 0.0
         npts = self.neural_points
         mlp = []
         for name in MLP_TENSOR_ORDER:
             mod = self.get_submodule(name)
             mlp += [mod.weight, mod.bias]
-        rgb, ray_mask = _FusedRenderFn.apply(rnd, ray_bundle.directions.to(self._device), cams, ray_cam,
-                                             npts.points_embeding, npts.points_color, npts.points_dir, *mlp)
-        cnt = rnd.last_counters
-        R = ray_bundle.directions.reshape(-1, 3).shape[0]
-        pidx = rnd.taps(R)["smp_pidx"][:cnt["samples_selected"]].reshape(-1).long()
-        conf = npts.points_conf[0, :, 0]
-        cv = conf[pidx[pidx >= 0]]
-        n_slots = cnt["rays_kept"] * self.config.SR * self.config.K
-        conf_all = torch.cat([cv, conf[0:1].expand(max(n_slots - cv.numel(), 0))])
-        conf_coefficient = conf_all - (conf_all - torch.clamp(conf_all, min=0.0001, max=1)).detach()
-        return {"coarse_raycolor": rgb, "ray_mask": ray_mask, "conf_coefficient": conf_coefficient}
+        dirs = ray_bundle.directions.to(self._device).reshape(-1, 3)
+        R = dirs.shape[0]
+        cap = self._worst_case_cap(rnd, R, backward=True)
+        if cap is None:
+            self.host_reads += 1
+        rgb, ray_mask = _FusedRenderFn.apply(self, rnd, dirs, cams, ray_cam, cap, npts.points_embeding,
+                                             npts.points_color, npts.points_dir, *mlp)
+        out = {"coarse_raycolor": rgb, "ray_mask": ray_mask}
+        if self.training:
+            cnt = rnd._counters_dev                                    # int64 [PNR_NUM_COUNTERS] on the device
+            pidx = rnd.taps(R)["smp_pidx"]                             # [cap, K] view of the render workspace
+            rows = torch.arange(pidx.shape[0], device=pidx.device)[:, None] < cnt[2]       # selected samples
+            filled = (pidx >= 0) & rows
+            conf = npts.points_conf[0, :, 0]
+            values = torch.cat([conf[pidx.clamp(min=0).reshape(-1).long()], conf[0:1]])
+            n_slots = cnt[1] * (self.config.SR * self.config.K)        # rays kept x SR x K: the reference's tensor
+            w = torch.cat([filled.reshape(-1).to(torch.float32),
+                           (n_slots - filled.sum()).to(torch.float32).reshape(1)])
+            out["conf_coefficient"] = values - (values - torch.clamp(values, min=0.0001, max=1)).detach()
+            out["conf_coefficient_weights"] = w
+        return out
 
     # ---- point growing / pruning (SURVEY.md section 8f rank 3; absent from the reference's plugin, present in its
     # legacy trainer: run/train_studio.py:335-444,676-735) -------------------------------------------------------------
@@ -401,16 +594,24 @@ class PointNerf(Model):
     def get_outputs(self, ray_bundle):
         if self.mlp_base is None:
             raise ValueError("populate_fields() must be called before get_outputs")
-        if not self.training and not torch.is_grad_enabled() and self._fusable():
+        c = self.config
+        if self._fusable() and not torch.is_grad_enabled():
             return self._get_outputs_fused(ray_bundle)
-        if self.training and torch.is_grad_enabled() and self._fusable() and \
-                getattr(self.config, "hip_fused_training", True):
-            return self._get_outputs_fused_train(ray_bundle)
+        if self._fusable() and (getattr(c, "hip_fused_training", True) or not self.training):
+            return self._get_outputs_fused_grad(ray_bundle)
+        if not getattr(c, "hip_allow_torch_fallback", False):
+            why = ("hip_fused_training is off" if self._fusable() else
+                   "the fused kernels cover the default network shape only (32 features, 3/5/4 frequencies, "
+                   "agg_dist_pers 20, 256/128 hidden units, 2+2+3 layers, colour and dir inputs, unit axis weights)")
+            raise RuntimeError(f"PointNerf.get_outputs: {why}; the reference's op sequence under torch autograd runs only "
+                               f"with hip_allow_torch_fallback=True")
         return self._get_outputs_autograd(ray_bundle)
 
-    # ---- the reference's op sequence (training) -----------------------------------------------------------
+    # ---- the reference's op sequence under torch autograd (hip_allow_torch_fallback only) -----------------------
     def _get_outputs_autograd(self, ray_bundle):
-        """studio_model.py:263-399 on device tensors; the query inside neural_points() is the HIP op."""
+        """studio_model.py:263-399 on device tensors; the query inside neural_points() is the HIP op.  Not a product
+        path: the cross-check of the fused training step (tests/test_gpu_plugin.py) and the only way to run a network
+        shape the fused kernels do not cover."""
         (sampled_color, sampled_Rw2c, sampled_dir, sampled_embedding, sampled_xyz_pers, sampled_xyz, sampled_conf,
          sample_loc_tensor, sample_loc_w_tensor, sample_pnt_mask, sample_ray_dirs_tensor, vsize_np,
          ray_mask_tensor) = self.neural_points(ray_bundle)
@@ -492,11 +693,12 @@ class PointNerf(Model):
                 "fields": [p for n, p in named if not n.startswith("neural_points.points")]}
 
     def get_training_callbacks(self, training_callback_attributes: TrainingCallbackAttributes) -> List[TrainingCallback]:
-        """The reference inherits nerfstudio's empty list.  Here one callback runs after every optimiser step:
-        point features and MLP weights changed, so the PACKED copies (point rows, MFMA-ordered weights) are marked
-        stale and re-packed lazily by the next render.  The voxel structure, the SceneHIP / RendererHIP objects and
-        their workspaces stay: points_xyz is frozen (studio_utils.py:84), and a real change of it is caught by the
-        (data_ptr, _version) key of NeuralPoints.fused_scene."""
+        """The reference inherits nerfstudio's empty list.  Here one callback runs after every optimiser step: the MLP
+        weights changed, so their PACKED copy (2.9 MB, MFMA operand order) is re-packed by the next render; the packed
+        point rows are only marked stale for the next EVAL render -- training renders refresh the rows they read from
+        the bound parameters (NeuralPoints.fused_scene(live=True)), so a step is followed by no O(N) work.  The voxel
+        structure, the SceneHIP / RendererHIP objects and their workspaces stay: points_xyz is frozen
+        (studio_utils.py:84), and a real change of it is caught by the (data_ptr, _version) key of fused_scene."""
         def _invalidate(step: int = 0):
             self.neural_points.invalidate_packed()
             self._weights_key = None
@@ -512,8 +714,12 @@ class PointNerf(Model):
         loss_dict = {"ray_masked_coarse_raycolor_loss": self.mask_loss(masked_gt, masked_output) + 1e-6}
         if self.training:
             val = torch.clamp(outputs["conf_coefficient"], self.config.zero_epsilon, 1 - self.config.zero_epsilon)
-            loss_dict["conf_coefficient_loss"] = \
-                torch.mean(torch.log(val) + torch.log(1 - val)) * self.config.zero_one_loss_weights
+            term = torch.log(val) + torch.log(1 - val)
+            w = outputs.get("conf_coefficient_weights")
+            # (the fused path returns the reference's values with multiplicities instead of repeating them: see
+            # _get_outputs_fused_grad; the weighted mean IS the reference's torch.mean over its [1,R'',SR,K] tensor)
+            mean = torch.mean(term) if w is None else torch.sum(term * w) / torch.sum(w)
+            loss_dict["conf_coefficient_loss"] = mean * self.config.zero_one_loss_weights
         coeff = getattr(self.config, "loss_coefficients", None) or {}
         return {k: v * coeff.get(k, 1.0) for k, v in loss_dict.items()}
 

@@ -8,10 +8,17 @@ Shim semantics restated from the public nerfstudio code (un-vendored, un-pinned 
       activation after all but the last, `out_activation` after the last; parameters under `layers.<i>`.
   FieldHead(in_dim, out_dim, activation): one Linear under `net` followed by the activation.
   RGBRenderer(background_color): sum(w * rgb) + bg * (1 - sum(w)); clamped to [0, 1] outside training.
-  Model: nn.Module holding `config`, calling populate_modules() from __init__, forward -> get_outputs.
+  Model: nn.Module holding `config`, calling populate_modules() from __init__ (which builds the collider),
+      forward = collider, then get_outputs; get_outputs_for_camera_ray_bundle = the [H, W] bundle in row-major chunks of
+      config.eval_num_rays_per_chunk rays through forward, outputs concatenated and viewed as [H, W, -1] (under no_grad).
+  NearFarCollider(near_plane, far_plane, reset_near_plane=True): nears / fars = ones_like(origins[..., :1]) * plane;
+      outside training the near plane is 0 unless reset_near_plane is False.
+  RayBundle: a dataclass of tensors sharing their leading dims; len() = number of rays; flatten();
+      get_row_major_sliced_ray_bundle(start, end) = the flattened bundle's rays [start, end).
 """
 from __future__ import annotations
 
+from collections import defaultdict
 from dataclasses import dataclass, field
 from typing import Any, Callable, Dict, List, Optional, Type
 
@@ -40,8 +47,28 @@ except Exception:  # ModuleNotFoundError in the build image
         metadata: Dict[str, torch.Tensor] = field(default_factory=dict)
         camera_indices: Optional[torch.Tensor] = None
 
+        @property
+        def shape(self):
+            return tuple(self.origins.shape[:-1])
+
         def __len__(self):
-            return self.origins.shape[0]
+            return self.origins.numel() // self.origins.shape[-1]
+
+        def _map(self, fn) -> "RayBundle":
+            f = lambda t: None if t is None else fn(t)
+            return RayBundle(origins=fn(self.origins), directions=fn(self.directions), nears=f(self.nears),
+                             fars=f(self.fars), metadata={k: fn(v) for k, v in self.metadata.items()},
+                             camera_indices=f(self.camera_indices))
+
+        def flatten(self) -> "RayBundle":
+            lead = len(self.origins.shape) - 1
+            return self._map(lambda t: t.reshape((-1,) + tuple(t.shape[lead:])))
+
+        def __getitem__(self, idx) -> "RayBundle":
+            return self._map(lambda t: t[idx])
+
+        def get_row_major_sliced_ray_bundle(self, start_idx: int, end_idx: int) -> "RayBundle":
+            return self.flatten()[start_idx:end_idx]
 
     class TrainingCallbackLocation:
         BEFORE_TRAIN_ITERATION = "before_train_iteration"
@@ -135,9 +162,23 @@ except Exception:  # ModuleNotFoundError in the build image
 
     MSELoss = nn.MSELoss
 
+    class NearFarCollider(nn.Module):
+        def __init__(self, near_plane: float, far_plane: float, reset_near_plane: bool = True) -> None:
+            super().__init__()
+            self.near_plane, self.far_plane, self.reset_near_plane = near_plane, far_plane, reset_near_plane
+
+        def forward(self, ray_bundle):
+            ones = torch.ones_like(ray_bundle.origins[..., 0:1])
+            near_plane = self.near_plane if (self.training or not self.reset_near_plane) else 0
+            ray_bundle.nears = ones * near_plane
+            ray_bundle.fars = ones * self.far_plane
+            return ray_bundle
+
     @dataclass
     class ModelConfig:
         _target: Type = field(default_factory=lambda: Model)
+        enable_collider: bool = True
+        collider_params: Optional[Dict[str, float]] = field(default_factory=lambda: {"near_plane": 2.0, "far_plane": 6.0})
         loss_coefficients: Dict[str, float] = field(default_factory=dict)
         eval_num_rays_per_chunk: int = 4096
 
@@ -161,12 +202,32 @@ except Exception:  # ModuleNotFoundError in the build image
             return self.device_indicator_param.device
 
         def populate_modules(self):
-            pass
+            self.collider = None
+            if getattr(self.config, "enable_collider", False):
+                assert self.config.collider_params is not None
+                self.collider = NearFarCollider(near_plane=self.config.collider_params["near_plane"],
+                                                far_plane=self.config.collider_params["far_plane"])
 
         def get_training_callbacks(self, training_callback_attributes) -> List[TrainingCallback]:
             return []
 
         def forward(self, ray_bundle):
+            if self.collider is not None:
+                ray_bundle = self.collider(ray_bundle)
             return self.get_outputs(ray_bundle)
+
+        @torch.no_grad()
+        def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle) -> Dict[str, torch.Tensor]:
+            num_rays_per_chunk = self.config.eval_num_rays_per_chunk
+            image_height, image_width = camera_ray_bundle.origins.shape[:2]
+            num_rays = len(camera_ray_bundle)
+            outputs_lists = defaultdict(list)
+            for i in range(0, num_rays, num_rays_per_chunk):
+                ray_bundle = camera_ray_bundle.get_row_major_sliced_ray_bundle(i, i + num_rays_per_chunk)
+                outputs = self.forward(ray_bundle=ray_bundle)
+                for output_name, output in outputs.items():
+                    if torch.is_tensor(output):
+                        outputs_lists[output_name].append(output)
+            return {name: torch.cat(chunks).view(image_height, image_width, -1) for name, chunks in outputs_lists.items()}
 
 WHITE = torch.tensor([1.0, 1.0, 1.0])

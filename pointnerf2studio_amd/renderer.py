@@ -129,6 +129,9 @@ def camera_rays(views: Sequence[View], H: int, W: int, device, pixels: Optional[
     (view-major; `pixels` int32 flat ids on the device, None = every pixel of the frame row-major)."""
     lib = _lib.load()
     px = None if pixels is None else pixels.to(device=device, dtype=torch.int32).contiguous()
+    if px is not None and px.dim() != 1:
+        raise ValueError("camera_rays takes ONE flat pixel list for all views (pnr_camera_rays has no per-view form); "
+                         "call it per view for per-view lists")
     n = H * W if px is None else px.numel()
     out = torch.empty((len(views) * n, 3), dtype=torch.float32, device=device)
     with torch.cuda.device(device):
@@ -173,6 +176,7 @@ class SceneHIP:
         gp.query_size[:] = [int(v) for v in query_size]
         gp.P, gp.max_o, gp.compat_drop_voxel0 = int(P), int(max_o), int(bool(compat_drop_voxel0))
         self.params = gp
+        self._bound = None       # (the library drops bound tensors on a build / update)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.pnr_scene_build(self.handle, _ptr(pts), self.N, C.byref(gp),
                                                 _stream_ptr(self.device)), "pnr_scene_build")
@@ -197,6 +201,7 @@ class SceneHIP:
         gp.kernel_size[:] = [int(v) for v in kernel_size]
         gp.query_size[:] = [int(v) for v in query_size]
         gp.P, gp.max_o, gp.compat_drop_voxel0 = int(P), int(max_o), int(bool(compat_drop_voxel0))
+        self._bound = None
         with torch.cuda.device(self.device):
             _lib.check(self.lib.pnr_scene_update(self.handle, _ptr(pts), pts.shape[0], C.byref(gp), _ptr(oi),
                                                  _stream_ptr(self.device)), "pnr_scene_update")
@@ -235,6 +240,52 @@ class SceneHIP:
                                                 _stream_ptr(dev)), "pnr_points_pack")
         # no synchronisation: converted temporaries return to torch's caching allocator, which hands a block out
         # again only to work queued behind this launch on the same stream
+
+    @staticmethod
+    def _raw(xyz, embedding, conf, direction, color, dev):
+        """The five tensors as the C ABI wants them (float32, contiguous, leading singleton dims dropped).  For
+        Parameters in the reference's layouts these are VIEWS of the same storage, not copies."""
+        x = _f32c(xyz.reshape(-1, 3), dev)
+        N = x.shape[0]
+        e = _f32c(embedding.reshape(N, -1), dev)
+        if e.shape[1] != 32:
+            raise ValueError(f"point_features_dim must be 32, got {e.shape[1]}")
+        c = None if conf is None else _f32c(conf.reshape(N), dev)
+        return x, e, c, _f32c(direction.reshape(N, 3), dev), _f32c(color.reshape(N, 3), dev), N
+
+    def pack_point_rows(self, xyz, embedding, conf, direction, color, index: torch.Tensor,
+                        count: Optional[torch.Tensor] = None) -> None:
+        """pnr_points_pack_rows: re-packs only the rows `index` (int32, device); `count` (int64 device scalar) limits the
+        list to its first min(count, len(index)) entries without a host read."""
+        dev = self.device
+        x, e, c, d, col, N = self._raw(xyz, embedding, conf, direction, color, dev)
+        idx = index.to(device=dev, dtype=torch.int32).contiguous()
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.pnr_points_pack_rows(self.handle, _ptr(x), _ptr(e), _ptr(c), _ptr(d), _ptr(col), N,
+                                                     _ptr(idx), idx.numel(), _ptr(count), _stream_ptr(dev)),
+                       "pnr_points_pack_rows")
+
+    def bind_points(self, xyz, embedding, conf, direction, color) -> None:
+        """pnr_points_bind: every following render re-packs the rows of its distinct neighbour points from these LIVE
+        tensors (a training loop: no O(N) re-pack after an optimiser step).  The tensors must be float32 and
+        contiguous -- views of them are bound, not copies -- and are kept alive by this object."""
+        dev = self.device
+        x, e, c, d, col, N = self._raw(xyz, embedding, conf, direction, color, dev)
+        for t, src in ((x, xyz), (e, embedding), (d, direction), (col, color)) + (() if conf is None else ((c, conf),)):
+            if t.data_ptr() != src.data_ptr():
+                raise ValueError("bind_points needs float32 contiguous GPU tensors (a copy would go stale)")
+        _lib.check(self.lib.pnr_points_bind(self.handle, _ptr(x), _ptr(e), _ptr(c), _ptr(d), _ptr(col), N),
+                   "pnr_points_bind")
+        self._bound = (x, e, c, d, col)
+
+    def unbind_points(self) -> None:
+        if getattr(self, "_bound", None) is not None:
+            _lib.check(self.lib.pnr_points_bind(self.handle, None, None, None, None, None, 0), "pnr_points_bind")
+            self._bound = None
+
+    @property
+    def bound(self) -> bool:
+        return getattr(self, "_bound", None) is not None
 
 
 class WeightsHIP:
@@ -328,17 +379,19 @@ class RendererHIP:
         self.calls = 0          # render calls so far (a backward must follow ITS render directly)
         self._last = None
         self.last_counters = None
+        self._counters_dev = None
 
     def _workspace(self, R: int, cap: int, dev):
         key = (R, cap, self.opts.K)
         nbytes = self.lib.pnr_render_workspace_bytes_for(self.scene.handle, C.byref(self.opts), R, cap)
         if nbytes == 0:
             raise RuntimeError("pnr_render_workspace_bytes_for: " + self.lib.pnr_last_error().decode())
-        if self._ws is None or self._ws_key != key or self._ws.numel() < nbytes:
+        if self._ws is None or self._ws.numel() < nbytes:
             self._ws = None
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            self._ws_key = key
-            self.cap_samples = cap
+        # (a larger buffer serves a smaller call: the carving depends on (R, cap, K) only)
+        self._ws_key = key
+        self.cap_samples = cap
         return self._ws
 
     def tmid(self, near: float, far: float, dev) -> torch.Tensor:
@@ -401,7 +454,9 @@ class RendererHIP:
                     self.scene.handle, self.weights.handle, _ptr(d), R, arr, n, _ptr(rc), int(rays_per_cam), _ptr(tm),
                     C.byref(self.opts), _ptr(out["rgb"]), _ptr(out["depth"]), _ptr(out["acc"]), _ptr(out["ray_mask"]),
                     _ptr(out["counters_dev"]), _ptr(ws), ws.numel(), cap, _stream_ptr(dev)), "pnr_render_views")
+            self._counters_dev = out["counters_dev"]
             if not sync_counters:
+                self.last_counters = None      # (stale counters of an earlier call must not size anything)
                 return out
             cnt = out["counters_dev"].cpu().tolist()
             out["counters"] = dict(zip(_lib.COUNTER_NAMES, cnt))
@@ -431,7 +486,9 @@ class RendererHIP:
                    else (self.lib.pnr_render_camera, "pnr_render_camera"))
         key = ("views",) + tuple(id(v) for v in views)
         cached = self._cam_cache.get(key)
-        sig = [(v.fx, v.fy, v.cx, v.cy, v.near, v.far) for v in views]   # (a View is a value: not mutated in place)
+        # the whole value of every view: a View mutated in place (pose included) is packed again
+        sig = [(v.fx, v.fy, v.cx, v.cy, v.near, v.far, tuple(torch.as_tensor(v.campos).reshape(3).tolist()),
+                tuple(torch.as_tensor(v.camrotc2w).reshape(9).tolist())) for v in views]
         if cached is None or cached[3] != sig:
             arr = _views_c(views)
             tm = torch.stack([self.tmid(v.near, v.far, dev) for v in views]).contiguous()
@@ -464,7 +521,9 @@ class RendererHIP:
                     self.scene.handle, self.weights.handle, arr, n, int(H), int(W), _ptr(px), n_px, _ptr(tm),
                     C.byref(self.opts), _ptr(out["rgb"]), _ptr(out["depth"]), _ptr(out["acc"]), _ptr(out["ray_mask"]),
                     _ptr(out["counters_dev"]), _ptr(ws), ws.numel(), cap, _stream_ptr(dev)), who)
+            self._counters_dev = out["counters_dev"]
             if not sync_counters:
+                self.last_counters = None
                 return out
             cnt = out["counters_dev"].cpu().tolist()
             out["counters"] = dict(zip(_lib.COUNTER_NAMES, cnt))
@@ -474,8 +533,8 @@ class RendererHIP:
             cap = int(cnt[2] * 1.125) + 1024
 
     def backward(self, grad_rgb: torch.Tensor, state: Dict[str, torch.Tensor], num_points: int,
-                 point_grads: bool = True, weight_grads: bool = True, sparse_points: bool = False
-                 ) -> Dict[str, torch.Tensor]:
+                 point_grads: bool = True, weight_grads: bool = True, sparse_points: bool = False,
+                 into: Optional[Dict[str, Optional[torch.Tensor]]] = None) -> Dict[str, torch.Tensor]:
         """Gradients of the LAST render / render_views call (pnr_render_backward): d loss / d {embedding [N,32],
         color [N,3], dir [N,3], '<module>.weight', '<module>.bias'} for grad_rgb = d loss / d rgb [R,3].  `state` holds
         the raw MLP tensors the weights were packed from.  What torch autograd derives for studio_model.py:263-399;
@@ -483,6 +542,9 @@ class RendererHIP:
         gradients agree with fp32 autograd to ~1e-6, bf16x3: the GEMMs on bf16 hi/lo splits).
         sparse_points: instead of the three dense [N, .] tensors, 'point_index' [U] (int64, ascending) and 'point_grads'
         [U, 40] = [d embedding | d color | d dir | 0 0] for the U distinct neighbour points of the render.
+        into: {'embedding': [N*32], 'color': [N*3], 'dir': [N*3]} float32 contiguous tensors (any of them None) the point
+        gradients are ACCUMULATED into (+= on the rows of the touched points only, nothing is allocated or zero-filled:
+        what a training loop hands over, its .grad tensors or persistent buffers).
         The point gradients are summed in a fixed order: repeated calls return the same bits."""
         if getattr(self, "_last", None) is None:
             raise RuntimeError("RendererHIP.backward: no render call to differentiate")
@@ -499,10 +561,21 @@ class RendererHIP:
         bp = (C.c_void_p * 9)(*[b.data_ptr() for b in bs_t])
         out: Dict[str, torch.Tensor] = {"rgb": torch.empty((R, 3), dtype=torch.float32, device=dev)}
         grads = _lib.GradsC()
-        if point_grads and sparse_points:
-            if self.last_counters is None:
-                raise RuntimeError("sparse point gradients need the counters of the render (sync_counters=True)")
-            U = int(self.last_counters["points_unique"])
+        if point_grads and into is not None:
+            for key, width, field in (("embedding", 32, "d_embedding"), ("color", 3, "d_color"), ("dir", 3, "d_dir")):
+                t = into.get(key)
+                if t is None:
+                    continue
+                if (t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != num_points * width
+                        or t.device != dev):
+                    raise ValueError(f"backward(into=...): '{key}' must be a contiguous float32 tensor of "
+                                     f"{num_points * width} elements on {dev}")
+                setattr(grads, field, t.data_ptr())
+        elif point_grads and sparse_points:
+            # U of THIS render: from its synced counters, else read from the device (one host read; a stale count of
+            # an earlier call would silently drop rows)
+            U = (int(self.last_counters["points_unique"]) if self.last_counters is not None
+                 else int(self._counters_dev[7].item()))
             out["point_grads"] = torch.empty((max(U, 1), 40), dtype=torch.float32, device=dev)
             sp_index = torch.empty((max(U, 1),), dtype=torch.int32, device=dev)
             grads.d_point_grads, grads.d_point_index, grads.point_cap = (out["point_grads"].data_ptr(),
@@ -536,10 +609,39 @@ class RendererHIP:
                 rays_per_cam, C.byref(self.opts), _ptr(g), _ptr(ws), ws.numel(), cap, _ptr(self._tws),
                 self._tws.numel(), C.byref(grads), _ptr(out["rgb"]), _stream_ptr(dev)), "pnr_render_backward")
         # no synchronisation (see pack_points): everything is queued on torch's current stream
-        if point_grads and sparse_points:
+        if point_grads and sparse_points and into is None:
             out["point_grads"] = out["point_grads"][:U]
             out["point_index"] = sp_index[:U].to(torch.long)
         return out
+
+    def touched(self, index: Optional[torch.Tensor] = None, count: Optional[torch.Tensor] = None):
+        """pnr_render_touched: the distinct neighbour points of the LAST render (ascending), without a host read:
+        (index int32 [cap] -- entries beyond the count repeat the first one --, count int64 [1] on the device).  cap =
+        min(points in voxel lists, cap_samples * K) unless a buffer is passed in."""
+        if self._last is None:
+            raise RuntimeError("RendererHIP.touched: no render call yet")
+        R, cap = self._last[1], self._last[6]
+        dev = self.scene.device
+        if index is None:
+            u_cap = max(1, min(int(self.scene.info()["points_in_lists"]), cap * self.opts.K))
+            index = torch.empty((u_cap,), dtype=torch.int32, device=dev)
+        if count is None:
+            count = torch.empty((1,), dtype=torch.int64, device=dev)
+        ws = self._ws
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.pnr_render_touched(self.scene.handle, C.byref(self.opts), R, _ptr(ws), ws.numel(), cap,
+                                                   _ptr(index), index.numel(), _ptr(count), _stream_ptr(dev)),
+                       "pnr_render_touched")
+        return index, count
+
+    def clear_point_grads(self, embedding, color, direction, num_points: int, index: torch.Tensor,
+                          count: Optional[torch.Tensor] = None) -> None:
+        """pnr_point_grads_clear: zeroes the listed rows of dense point-gradient tensors (any may be None)."""
+        dev = index.device
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.pnr_point_grads_clear(_ptr(embedding), _ptr(color), _ptr(direction), int(num_points),
+                                                      _ptr(index), index.numel(), _ptr(count), _stream_ptr(dev)),
+                       "pnr_point_grads_clear")
 
     PROBE_KEYS = {"ray_max_shading_opacity": ("d_max_opacity", ()), "ray_max_sample_loc_w": ("d_max_loc", (3,)),
                   "ray_max_far_dist": ("d_far_dist", ()), "shading_avg_color": ("d_avg_color", (3,)),

@@ -129,7 +129,11 @@ if HAVE_NERFSTUDIO:  # pragma: no cover - nerfstudio is not installable in the b
             self.model.to(device)
             self.world_size = world_size
             if world_size > 1:
-                self._model = typing.cast(Model, DDP(self._model, device_ids=[local_rank], find_unused_parameters=True))
+                # the reference's wrap (studio_pipeline.py:48-53) with the point tensors taken out of DDP's dense
+                # all-reduce: the fused backward exchanges their touched rows itself (distributed.wrap_data_parallel)
+                from .distributed import wrap_data_parallel
+                self._model = typing.cast(Model, wrap_data_parallel(self._model, device_ids=[local_rank],
+                                                                    find_unused_parameters=True))
                 dist.barrier(device_ids=[local_rank])
 
     def _opt(lr):

@@ -40,7 +40,7 @@ def test_checkpoint_pair_loads_and_renders_like_the_oracle(oracle, gpu_device, t
     _write_checkpoint(d, new, w, 200000)          # the newest *_states.pth decides (studio_model.py:55-59,156)
     (d / "opt.txt").write_text("not a checkpoint")
 
-    cfg = PointNerfConfig(path_point_cloud=d, ranges=list(synthetic.CHAIR_RANGES), max_o=410000,
+    cfg = PointNerfConfig(path_point_cloud=d, ranges=list(synthetic.CHAIR_RANGES), max_o=410000, enable_collider=False,
                           hip_load_aggregator_weights=True)
     model = PointNerf(cfg).to(gpu_device)
     model.eval()
@@ -62,7 +62,7 @@ def test_checkpoint_pair_loads_and_renders_like_the_oracle(oracle, gpu_device, t
     torch.save(model.state_dict(), tmp_path / "step-000000001.ckpt")
     sd = torch.load(tmp_path / "step-000000001.ckpt", map_location="cpu")
     assert not [k for k in sd if "lpips" in k]
-    cfg2 = PointNerfConfig(path_point_cloud=d, ranges=list(synthetic.CHAIR_RANGES), max_o=410000)
+    cfg2 = PointNerfConfig(path_point_cloud=d, ranges=list(synthetic.CHAIR_RANGES), max_o=410000, enable_collider=False)
     model2 = PointNerf(cfg2).to(gpu_device)        # fresh MLPs (no warm start) ...
     model2.load_state_dict(sd, strict=True)        # ... then the saved weights and features
     model2.eval()
@@ -79,7 +79,7 @@ def test_checkpoint_without_aggregator_keeps_fresh_mlps(oracle, gpu_device, tmp_
     d.mkdir()
     pts = small_scene(20000, seed=7)
     _write_checkpoint(d, pts, None, 500, with_aggregator=False)
-    base = dict(path_point_cloud=d, ranges=list(synthetic.CHAIR_RANGES), max_o=410000)
+    base = dict(path_point_cloud=d, ranges=list(synthetic.CHAIR_RANGES), max_o=410000, enable_collider=False)
     model = PointNerf(PointNerfConfig(**base)).to(gpu_device)
     campos, camrot, dirs = camera_rays(16, 16, az=100.0)
     model.eval()

@@ -95,3 +95,93 @@ def test_two_rank_training_step_equals_single_process(gpu_device):
         ref = whole[k].cpu()
         scale = ref.abs().max().item()
         assert (torch.from_numpy(v) - ref).abs().max().item() <= 2e-3 * scale, k
+
+
+# ---- the same step through the PLUGIN: PointNerf under wrap_data_parallel (studio_pipeline.py:48-53) ----------------
+def _plugin_model(device):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from helpers import camera_rays, small_scene
+    from pointnerf2studio_amd import synthetic
+    from pointnerf2studio_amd.model import PointNerf, PointNerfConfig
+    from pointnerf2studio_amd.ns_compat import RayBundle
+    pts = small_scene(N)
+    sd = {"neural_points.xyz": pts["xyz"], "neural_points.points_embeding": pts["embedding"],
+          "neural_points.points_conf": pts["conf"], "neural_points.points_dir": pts["dir"],
+          "neural_points.points_color": pts["color"], "neural_points.Rw2c": pts["Rw2c"]}
+    cfg = PointNerfConfig(ranges=list(synthetic.CHAIR_RANGES), max_o=410000, SR=SR, K=K, P=P, enable_collider=False)
+    model = PointNerf(cfg, point_state_dict=sd).to(device)
+    model.load_state_dict(synthetic.make_weights(0, sigma_scale=300.0, bias_scale=0.1), strict=False)
+    model.train()
+    model.neural_points.jitter = 0.0
+    campos, camrot, dirs = camera_rays(32, 32, az=35.0)
+    G = torch.randn(dirs.shape[0], 3, generator=torch.Generator().manual_seed(4)).to(device)
+
+    def bundle(sel):
+        n = sel.numel()
+        return RayBundle(origins=campos[None].expand(n, 3).to(device), directions=dirs.to(device)[sel].contiguous(),
+                         nears=torch.full((n, 1), 2.0, device=device), fars=torch.full((n, 1), 6.0, device=device),
+                         metadata={"camrotc2w": camrot.to(device)})
+    return model, bundle, G, dirs.shape[0]
+
+
+def _plugin_loss(model_or_ddp, model, bundle, G, sel):
+    out = model_or_ddp(bundle(sel))
+    # a sum over rays (per-rank losses add up to the whole batch's) + the conf regulariser's own term
+    val = torch.clamp(out["conf_coefficient"], 1e-3, 1 - 1e-3)
+    conf = torch.sum((torch.log(val) + torch.log(1 - val)) * out["conf_coefficient_weights"]) * 1e-6
+    return (out["coarse_raycolor"] * G[sel]).sum() + conf
+
+
+def _plugin_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pointnerf2studio_amd.distributed import POINT_TENSORS_EXCHANGED_SPARSELY, wrap_data_parallel
+        dev = torch.device("cuda:0")
+        model, bundle, G, R = _plugin_model(dev)
+        ddp = wrap_data_parallel(model, average=False)          # sums, to compare with the single-process gradients
+        assert model.grad_exchange is not None and model.grad_exchange.world == world
+        sel = torch.arange(rank, R, world, device=dev)
+        _plugin_loss(ddp, model, bundle, G, sel).backward()
+        grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+        # DDP averaged what it reduced (MLP, points_conf): undo, the exchange summed the point rows
+        out = {n: (g if n in POINT_TENSORS_EXCHANGED_SPARSELY else g * world).cpu().numpy() for n, g in grads.items()}
+        if rank == 0:
+            q.put(out)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_plugin_step_equals_single_process(gpu_device):
+    """PointNerf under wrap_data_parallel, two ranks on one GPU over gloo: DDP all-reduces the MLP (and points_conf),
+    the three big point tensors are kept out of DDP and their touched rows exchanged inside the fused backward.  The
+    result equals one process differentiating the whole batch."""
+    model, bundle, G, R = _plugin_model(gpu_device)
+    _plugin_loss(model, model, bundle, G, torch.arange(R, device=gpu_device)).backward()
+    whole = {n: p.grad.clone().cpu() for n, p in model.named_parameters() if p.grad is not None}
+    assert {"neural_points.points_embeding", "neural_points.points_conf", "mlp_base.layers.0.weight"} <= set(whole)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [ctx.Process(target=_plugin_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert set(got) == set(whole)
+    for k, v in got.items():
+        ref = whole[k]
+        scale = ref.abs().max().item()
+        assert (torch.from_numpy(v) - ref).abs().max().item() <= 2e-3 * scale + 1e-12, k

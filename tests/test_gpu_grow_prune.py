@@ -122,7 +122,7 @@ def test_model_prune_grow_probe(oracle, gpu_device):
     sd = {"neural_points.xyz": pts["xyz"], "neural_points.points_embeding": pts["embedding"],
           "neural_points.points_conf": pts["conf"], "neural_points.points_dir": pts["dir"],
           "neural_points.points_color": pts["color"], "neural_points.Rw2c": pts["Rw2c"]}
-    model = PointNerf(PointNerfConfig(ranges=list(synthetic.CHAIR_RANGES), max_o=410000), point_state_dict=sd).to(gpu_device)
+    model = PointNerf(PointNerfConfig(ranges=list(synthetic.CHAIR_RANGES), max_o=410000, enable_collider=False), point_state_dict=sd).to(gpu_device)
     w = synthetic.make_weights(0, sigma_scale=300.0, bias_scale=0.1)
     model.load_state_dict(w, strict=False)
     model.eval()
@@ -175,3 +175,101 @@ def test_model_prune_grow_probe(oracle, gpu_device):
     out = model(bundle)
     sum(model.get_loss_dict(out, {"image": torch.rand(R, 3, device=dev)}).values()).backward()
     assert model.neural_points.points_embeding.grad.shape[1] == n
+
+
+def test_prune_after_an_in_place_edit_of_the_cloud_rebuilds_instead_of_updating(oracle, gpu_device):
+    """pnr_scene_update reuses the cell codes of surviving points, so it is only valid on a scene built from the cloud
+    old_index refers to.  A cloud edited in place since the last render (load_state_dict / copy_ with the same N) with
+    an unchanged grid (the config box clamps the ranges) must NOT be updated: the mirror notices the stale key and lets
+    the next render build from nothing."""
+    pts = small_scene(60000)
+    sd = {"neural_points.xyz": pts["xyz"], "neural_points.points_embeding": pts["embedding"],
+          "neural_points.points_conf": pts["conf"], "neural_points.points_dir": pts["dir"],
+          "neural_points.points_color": pts["color"], "neural_points.Rw2c": pts["Rw2c"]}
+    # a box well inside the cloud: the grid is the (clamped) box whatever the points do
+    box = [-0.3, -0.3, -0.3, 0.3, 0.3, 0.3]
+    model = PointNerf(PointNerfConfig(ranges=box, max_o=410000, enable_collider=False), point_state_dict=sd).to(gpu_device)
+    w = synthetic.make_weights(0, sigma_scale=300.0, bias_scale=0.1)
+    model.load_state_dict(w, strict=False)
+    model.eval()
+    model.neural_points.jitter = 0.0
+    campos, camrot, dirs = camera_rays(32, 32, az=35.0)
+    R = dirs.shape[0]
+    dev = gpu_device
+    bundle = RayBundle(origins=campos[None].expand(R, 3).to(dev), directions=dirs.to(dev),
+                       nears=torch.full((R, 1), 2.0, device=dev), fars=torch.full((R, 1), 6.0, device=dev),
+                       metadata={"camrotc2w": camrot.reshape(1, 9).expand(R, 9).to(dev)})
+    ocfg = oracle_cfg(oracle, ranges=box)
+    with torch.no_grad():
+        model(bundle)
+    scene = model.neural_points._fused_scene
+    # the cloud moves in place (same N, same box => same grid), no render in between
+    moved = dict(pts)
+    moved["xyz"] = (pts["xyz"] * torch.tensor([1.0, -1.0, 1.0]) + torch.tensor([0.01, 0.0, -0.02])).contiguous()
+    with torch.no_grad():
+        model.neural_points.points_xyz.copy_(moved["xyz"].to(dev))
+    removed = model.prune_points(0.3)
+    assert removed > 5000
+    assert scene.update_info()["updates"] == 0, "a scene built on another cloud was updated"
+    pr, _ = oracle.prune_points(moved, 0.3)
+    with torch.no_grad():
+        out = model(bundle)
+    ref = oracle.render(pr, w, ocfg, campos[None].expand(R, 3), dirs, 2.0, 6.0, camrot)
+    assert ref["stats"]["rays_kept"] > 50
+    assert torch.equal(out["ray_mask"].cpu(), ref["ray_mask"])
+    assert (out["coarse_raycolor"].cpu() - ref["coarse_raycolor"]).abs().max().item() <= NORTH_STAR["rgb"]
+
+
+def test_pack_rows_and_bound_rows_equal_a_full_pack(oracle, gpu_device):
+    """pnr_points_pack_rows (a list of rows, its length on the host or on the device) and pnr_points_bind (every render
+    refreshes the rows of its own neighbour points from the live tensors) against pnr_points_pack of everything."""
+    pts = small_scene(60000)
+    cfg = oracle_cfg(oracle, SR=32)
+    w = synthetic.make_weights(0, sigma_scale=300.0, bias_scale=0.1)
+    campos, camrot, dirs = camera_rays(32, 32, az=35.0)
+    scene, wh, hyp, info = build_hip(pts, cfg, gpu_device, weights=w)
+    dev = gpu_device
+    t = {k: pts[k].to(dev).contiguous() for k in ("xyz", "embedding", "conf", "dir", "color")}
+    rnd = RendererHIP(scene, wh, SR=32)
+    base = rnd.render(dirs.to(dev), campos, camrot, 2.0, 6.0)["rgb"].clone()
+    touched, count = rnd.touched()
+    U = int(count.item())
+    assert U == rnd.last_counters["points_unique"] and U > 1000
+    idx = touched[:U].long()
+    assert torch.equal(idx, rnd.touched_points()) and bool((touched[U:] == touched[0]).all())
+    # new features everywhere; the reference image = full pack of the new tensors
+    g = torch.Generator().manual_seed(9)
+    new = dict(t)
+    new["embedding"] = (t["embedding"] + 0.2 * torch.randn(t["embedding"].shape, generator=g).to(dev)).contiguous()
+    new["color"] = torch.rand(t["color"].shape, generator=g).to(dev)
+    scene.pack_points(new["xyz"], new["embedding"], new["conf"], new["dir"], new["color"])
+    want = rnd.render(dirs.to(dev), campos, camrot, 2.0, 6.0)["rgb"].clone()
+    assert (want - base).abs().max().item() > 1e-2
+    # (1) back to the old rows, then ONLY the touched rows re-packed: host-side length, then device-side length
+    for kw in ({"index": touched[:U]}, {"index": touched, "count": count}):
+        scene.pack_points(t["xyz"], t["embedding"], t["conf"], t["dir"], t["color"])
+        scene.pack_point_rows(new["xyz"], new["embedding"], new["conf"], new["dir"], new["color"], **kw)
+        got = rnd.render(dirs.to(dev), campos, camrot, 2.0, 6.0)["rgb"]
+        assert torch.equal(got, want)
+    # (2) old rows packed, the NEW tensors bound: the render refreshes what it reads
+    scene.pack_points(t["xyz"], t["embedding"], t["conf"], t["dir"], t["color"])
+    scene.bind_points(new["xyz"], new["embedding"], new["conf"], new["dir"], new["color"])
+    got = rnd.render(dirs.to(dev), campos, camrot, 2.0, 6.0)["rgb"].clone()
+    assert torch.equal(got, want)
+    # ... in place edits of the bound tensors are seen by the next render without any call
+    new["color"].mul_(0.5)
+    scene.unbind_points()
+    scene.pack_points(new["xyz"], new["embedding"], new["conf"], new["dir"], new["color"])
+    want2 = rnd.render(dirs.to(dev), campos, camrot, 2.0, 6.0)["rgb"].clone()
+    new["color"].mul_(2.0)
+    scene.bind_points(new["xyz"], new["embedding"], new["conf"], new["dir"], new["color"])
+    rnd.render(dirs.to(dev), campos, camrot, 2.0, 6.0)
+    new["color"].mul_(0.5)
+    assert torch.equal(rnd.render(dirs.to(dev), campos, camrot, 2.0, 6.0)["rgb"], want2)
+    scene.unbind_points()
+    # clear_point_grads: listed rows zeroed, others untouched
+    G = torch.ones((60000, 32), device=dev)
+    C = torch.ones((60000, 3), device=dev)
+    rnd.clear_point_grads(G, C, None, 60000, touched, count)
+    assert float(G[idx].abs().sum()) == 0 and float(C[idx].abs().sum()) == 0
+    assert int((G.sum(1) == 0).sum()) == U and int((C.sum(1) == 0).sum()) == U

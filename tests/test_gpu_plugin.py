@@ -18,7 +18,7 @@ def _model_and_bundle(oracle, device, N=60000, H=32, W=32, az=35.0):
     sd = {"neural_points.xyz": pts["xyz"], "neural_points.points_embeding": pts["embedding"],
           "neural_points.points_conf": pts["conf"], "neural_points.points_dir": pts["dir"],
           "neural_points.points_color": pts["color"], "neural_points.Rw2c": pts["Rw2c"]}
-    cfg = PointNerfConfig(ranges=list(synthetic.CHAIR_RANGES), max_o=410000)
+    cfg = PointNerfConfig(ranges=list(synthetic.CHAIR_RANGES), max_o=410000, enable_collider=False)
     model = PointNerf(cfg, point_state_dict=sd).to(device)
     w = synthetic.make_weights(0, sigma_scale=300.0, bias_scale=0.1)
     missing = model.load_state_dict(w, strict=False)
@@ -91,6 +91,7 @@ def test_fused_training_step_equals_autograd_path(oracle, gpu_device):
     model.train()
     model.neural_points.jitter = 0.0
     model.config.hip_mlp_mode = "fp32"
+    model.config.hip_allow_torch_fallback = True     # the autograd side of this comparison IS the fenced fallback
     torch.manual_seed(3)
     image = torch.rand(bundle.directions.shape[0], 3, device=gpu_device)
 
@@ -149,6 +150,120 @@ def test_consecutive_fused_training_steps_reuse_scene_and_workspace(oracle, gpu_
     model.train()
     tr = model(bundle)["coarse_raycolor"].detach()
     assert (ev["coarse_raycolor"] - tr)[inside].abs().max().item() <= 1e-5
+
+
+def _bundle(device, H, W, az, el=30.0):
+    campos, camrot, dirs = camera_rays(H, W, az=az)
+    R = dirs.shape[0]
+    return RayBundle(origins=campos[None].expand(R, 3).to(device), directions=dirs.to(device),
+                     nears=torch.full((R, 1), 2.0, device=device), fars=torch.full((R, 1), 6.0, device=device),
+                     metadata={"camrotc2w": camrot.reshape(1, 9).expand(R, 9).to(device)})
+
+
+def test_point_gradients_without_the_dense_zero_fill(oracle, gpu_device):
+    """hip_sparse_point_grads (default): the backward kernels add the touched rows straight into persistent dense
+    buffers that ARE the parameters' .grad; a zero_grad(set_to_none=True) detaches them and the next backward clears
+    only the rows written before (pnr_point_grads_clear).  Against the plain path (a fresh zero-filled dense tensor per
+    step through autograd): bitwise the same gradients -- over consecutive steps on DIFFERENT rays (rows of the first
+    step that the second does not touch must be zero again), under accumulation (two backwards, no zero_grad), and with
+    zero_grad(set_to_none=False)."""
+    model, b0, _ = _model_and_bundle(oracle, gpu_device, N=40000, H=24, W=24)
+    bundles = [b0, _bundle(gpu_device, 24, 24, 150.0), _bundle(gpu_device, 20, 28, 260.0)]
+    model.train()
+    model.neural_points.jitter = 0.0
+    names = ("points_embeding", "points_color", "points_dir")
+    torch.manual_seed(5)
+    images = [torch.rand(b.directions.shape[0], 3, device=gpu_device) for b in bundles]
+
+    def backward(b, im):
+        out = model(b)
+        sum(model.get_loss_dict(out, {"image": im}).values()).backward()
+
+    def grads():
+        return {n: getattr(model.neural_points, n).grad.clone() for n in names}
+
+    # reference: the dense path, one fresh gradient per bundle
+    model.config.hip_sparse_point_grads = False
+    dense = []
+    for b, im in zip(bundles, images):
+        model.zero_grad(set_to_none=True)
+        backward(b, im)
+        dense.append(grads())
+    touched = [(d["points_embeding"].abs().sum(-1) > 0).reshape(-1) for d in dense]
+    assert int((touched[0] & ~touched[1]).sum()) > 50       # rows the second step must find cleared
+    # the buffer path over the same sequence
+    model.config.hip_sparse_point_grads = True
+    for i, (b, im) in enumerate(zip(bundles, images)):
+        model.zero_grad(set_to_none=True)
+        backward(b, im)
+        g = grads()
+        for n in names:
+            assert torch.equal(g[n], dense[i][n]), f"step {i}: {n}"
+            p = getattr(model.neural_points, n)
+            assert p.grad.data_ptr() == model._gbuf[{"points_embeding": "embedding", "points_color": "color",
+                                                     "points_dir": "dir"}[n]].data_ptr()
+    # accumulation: no zero_grad between two backwards
+    model.zero_grad(set_to_none=True)
+    backward(bundles[0], images[0])
+    backward(bundles[1], images[1])
+    g = grads()
+    for n in names:
+        want = dense[0][n] + dense[1][n]
+        assert (g[n] - want).abs().max().item() <= 1e-6 * want.abs().max().item()
+    # zero_grad(set_to_none=False): torch zero-fills the attached buffer itself
+    model.zero_grad(set_to_none=False)
+    backward(bundles[2], images[2])
+    g = grads()
+    for n in names:
+        assert torch.equal(g[n], dense[2][n]), n
+    # a trainable flag switched off: no buffer, no gradient
+    model.zero_grad(set_to_none=True)
+    model.neural_points.points_dir.requires_grad_(False)
+    backward(bundles[0], images[0])
+    assert model.neural_points.points_dir.grad is None
+    assert torch.equal(model.neural_points.points_embeding.grad, dense[0]["points_embeding"])
+
+
+def test_training_steps_issue_one_host_read_and_no_full_repack(oracle, gpu_device):
+    """A training step on the fused path: ONE device-to-host read (the bundle's camera, near, far), a workspace that
+    cannot overflow (no counters read), and -- with the parameters bound to the scene -- no full re-pack of the point
+    rows after the optimiser step: the renders refresh the rows they read, and read the UPDATED features."""
+    model, bundle, _ = _model_and_bundle(oracle, gpu_device, N=40000, H=24, W=24)
+    bundles = [bundle, _bundle(gpu_device, 24, 24, 150.0)]
+    model.train()
+    model.neural_points.jitter = 0.0
+    opt = torch.optim.Adam([{"params": g} for g in model.get_param_groups().values()], lr=1e-2)
+    image = torch.rand(bundle.directions.shape[0], 3, device=gpu_device)
+    full_packs = []
+    scene = None
+    for it in range(4):
+        reads = model.host_reads
+        opt.zero_grad(set_to_none=True)
+        out = model(bundles[it % 2])
+        sum(model.get_loss_dict(out, {"image": image}).values()).backward()
+        opt.step()
+        for cb in model.get_training_callbacks(None):
+            cb.run_callback(step=it)
+        assert model.host_reads - reads == 1, f"step {it}: {model.host_reads - reads} host reads"
+        scene = model.neural_points._fused_scene
+        assert scene.bound
+        full_packs.append(model.neural_points._packed_key)
+    assert all(k == full_packs[0] for k in full_packs), "a training step re-packed every row"
+    # Adam moved every row that ever had a gradient (momentum), also rows the last steps did not touch: a bound render
+    # must read the CURRENT values of all its rows.  Reference: the same parameters packed in full from scratch.
+    bound = model(bundles[0])["coarse_raycolor"].detach().clone()
+    assert model.neural_points._fused_scene.bound and model.neural_points._packed_key == full_packs[0]
+    model.neural_points.invalidate()                       # next render: structure rebuilt, every row packed
+    with torch.no_grad():
+        fresh = model(bundles[0])["coarse_raycolor"]       # training mode (no clamp), unbound, after the full pack
+    assert not model.neural_points._fused_scene.bound
+    assert (bound - fresh).abs().max().item() <= 1e-6
+    # ... and the eval renderer (clamped) agrees where the clamp is inactive
+    model.eval()
+    with torch.no_grad():
+        ev = model(bundles[0])["coarse_raycolor"]
+    inside = (ev > 0) & (ev < 1)
+    assert (ev - fresh)[inside].abs().max().item() <= 1e-6
 
 
 def test_dropin_query_op_signature(oracle, gpu_device):

@@ -104,11 +104,77 @@ def test_training_callbacks_invalidate_packed_copies():
     assert len(cbs) == 1
     m.neural_points._fused_key, m.neural_points._packed_key, m._weights_key = "a", "b", "c"
     cbs[0].run_callback(step=3)
-    # the packed copies (point rows, MFMA-ordered weights) go stale; the voxel structure stays (points_xyz is frozen)
-    assert m.neural_points._packed_key is None and m._weights_key is None
-    assert m.neural_points._fused_key == "a"
+    # the packed copies go stale -- the MFMA-ordered weights for every render, the point rows for the next EVAL render
+    # (training renders refresh the rows they read from the bound parameters); the voxel structure stays (points_xyz is
+    # frozen) and so does the fact that rows of this cloud exist
+    assert m.neural_points._packed_stale and m._weights_key is None
+    assert m.neural_points._fused_key == "a" and m.neural_points._packed_key == "b"
     m.neural_points.invalidate()          # a real change of the cloud (grow / prune) drops the structure too
     assert m.neural_points._fused_key is None
+
+
+def test_unfusable_configuration_raises_instead_of_falling_back_to_torch():
+    """No run lands on the PyTorch-op restatement silently: a network shape the fused kernels do not cover, or
+    hip_fused_training = False, raises unless hip_allow_torch_fallback is set (checked before any device work)."""
+    from pointnerf2studio_amd.ns_compat import RayBundle
+    m = _cpu_model()
+    b = RayBundle(origins=torch.zeros(4, 3), directions=torch.zeros(4, 3), nears=torch.full((4, 1), 2.0),
+                  fars=torch.full((4, 1), 6.0), metadata={"camrotc2w": torch.eye(3)})
+    m.train()
+    m.config.hip_fused_training = False
+    with pytest.raises(RuntimeError, match="hip_allow_torch_fallback"):
+        m.get_outputs(b)
+    m.config.hip_fused_training = True
+    m.config.num_dist_freqs = 4          # not the shape the kernels are built for
+    with pytest.raises(RuntimeError, match="hip_allow_torch_fallback"):
+        m.get_outputs(b)
+    assert PointNerfConfig().hip_allow_torch_fallback is False
+
+
+def test_weighted_conf_loss_equals_the_references_mean():
+    """The fused training path returns the reference's conf_coefficient values with multiplicities
+    (conf_coefficient_weights) instead of the [1,R'',SR,K] tensor; get_loss_dict's weighted mean is the same number."""
+    m = _cpu_model()
+    m.train()
+    g = torch.Generator().manual_seed(0)
+    vals = torch.rand(37, generator=g)
+    mult = torch.randint(0, 5, (37,), generator=g).float()
+    full = torch.repeat_interleave(vals, mult.long())
+    out = {"coarse_raycolor": torch.rand(6, 3), "ray_mask": torch.ones(6, dtype=torch.int8)}
+    batch = {"image": torch.rand(6, 3)}
+    a = m.get_loss_dict({**out, "conf_coefficient": full}, batch)["conf_coefficient_loss"]
+    b = m.get_loss_dict({**out, "conf_coefficient": vals, "conf_coefficient_weights": mult}, batch)["conf_coefficient_loss"]
+    assert torch.allclose(a, b, rtol=1e-6, atol=1e-9)
+
+
+def test_shim_chunk_loop_and_collider():
+    """ns_compat (no nerfstudio in the image): get_outputs_for_camera_ray_bundle cuts the [H, W] bundle into row-major
+    chunks of eval_num_rays_per_chunk rays through forward() and views the concatenation as [H, W, -1]; forward applies
+    the collider."""
+    from pointnerf2studio_amd import ns_compat as ns
+    if ns.HAVE_NERFSTUDIO:
+        pytest.skip("the real nerfstudio classes are in use")
+
+    class Probe(ns.Model):
+        def get_outputs(self, rb):
+            self.seen.append((len(rb), float(rb.nears.flatten()[0]), float(rb.fars.flatten()[0])))
+            return {"x": rb.origins[..., :1] * 2.0, "n": 3}
+
+    cfg = ns.ModelConfig(eval_num_rays_per_chunk=7)
+    mod = Probe(cfg)
+    mod.seen = []
+    H, W = 4, 5
+    o = torch.arange(H * W * 3, dtype=torch.float32).reshape(H, W, 3)
+    cam = ns.RayBundle(origins=o, directions=torch.zeros(H, W, 3), metadata={"camrotc2w": torch.zeros(H, W, 9)})
+    mod.eval()
+    out = mod.get_outputs_for_camera_ray_bundle(cam)
+    assert [s[0] for s in mod.seen] == [7, 7, 6] and set(out) == {"x"}
+    assert out["x"].shape == (H, W, 1) and torch.equal(out["x"], o[..., :1] * 2.0)
+    assert all(s[1] == 0.0 and s[2] == 6.0 for s in mod.seen)       # eval: near plane reset to 0 [ns-mem]
+    mod.train()
+    mod.seen = []
+    mod(cam.get_row_major_sliced_ray_bundle(0, 3))
+    assert mod.seen == [(3, 2.0, 6.0)]
 
 
 def test_loss_dict_keys_and_values():
