@@ -195,7 +195,7 @@ def plugin_legs(args, cfgd, points, weights, cams, dev, near, far):
 
     # ---- training step: 4096 random pixels of view 0, a NEW bundle object per step as the datamanager hands them over
     model.train()
-    gen = torch.Generator().manual_seed(12)
+    torch.manual_seed(12)
     full = bundles[0].directions.reshape(-1, 3)
     campos0, camrot0 = cams[0]
     opt = torch.optim.Adam([{"params": g, "lr": lr} for g, lr in
@@ -204,7 +204,7 @@ def plugin_legs(args, cfgd, points, weights, cams, dev, near, far):
     n_rays = 4096
 
     def one_step(with_adam):
-        pick = torch.randperm(full.shape[0], generator=gen)[:n_rays].to(dev)
+        pick = torch.randint(0, full.shape[0], (n_rays,), device=dev)      # (drawn on the device: no host work)
         b = RayBundle(origins=campos0.to(dev)[None].expand(n_rays, 3), directions=full.index_select(0, pick),
                       nears=torch.full((n_rays, 1), float(near), device=dev),
                       fars=torch.full((n_rays, 1), float(far), device=dev), metadata={"camrotc2w": camrot0.to(dev)})

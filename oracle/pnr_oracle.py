@@ -344,10 +344,13 @@ def w2pers_loc(point_xyz_w, camrotc2w, campos):
 
 def neural_points_forward(points: Dict[str, torch.Tensor], cfg: OracleConfig, origins, directions,
                           near: float, far: float, camrotc2w, jitter: float = 0.0,
-                          u: Optional[torch.Tensor] = None, compat_drop0: bool = True):
+                          u: Optional[torch.Tensor] = None, compat_drop0: bool = True, dtype=torch.float32):
     """studio_utils.py:147-209.  ``points`` holds xyz [N,3], embedding [1,N,32], conf [1,N,1],
     dir [1,N,3], color [1,N,3], Rw2c [3,3].  Returns the reference's 13-tuple plus (stats, t_mid
-    of the selected samples [1,R'',SR] with 0 in unfilled slots)."""
+    of the selected samples [1,R'',SR] with 0 in unfilled slots).
+    dtype: float32 is the reference's arithmetic.  float64 (tests only: the yardstick for how far ANY float32
+    evaluation of the MLP chain sits from the exact value) keeps the float32 query -- same samples, same neighbours --
+    and evaluates everything behind it in double."""
     cam_rot = camrotc2w.reshape(-1, 3, 3)[:1] if camrotc2w.shape[0] != 3 else camrotc2w[None]
     cam_rot = cam_rot.reshape(1, 3, 3).float()
     cam_pos = origins[0][None].float()
@@ -359,19 +362,21 @@ def neural_points_forward(points: Dict[str, torch.Tensor], cfg: OracleConfig, or
         raypos, xyz[None], cfg.kernel_size, cfg.query_size, cfg.SR, cfg.K, scaled_vdim, cfg.max_o,
         cfg.P, radius_limit(cfg), ranges, scaled_vsize, compat_drop0)
     keep = ray_mask[0] > 0
+    if dtype != torch.float32:
+        cam_rot, cam_pos, ray_dirs, xyz, loc_w = (t.to(dtype) for t in (cam_rot, cam_pos, ray_dirs, xyz, loc_w))
     sample_ray_dirs = ray_dirs[:, keep][..., None, :].expand(-1, -1, cfg.SR, -1).contiguous()
     pnt_mask = pidx >= 0
     B, R, SR, K = pidx.shape
     flat = torch.clamp(pidx, min=0).view(-1).long()
     loc = w2pers_loc(loc_w, cam_rot, cam_pos)
     pers = w2pers(xyz, cam_rot, cam_pos)
-    emb = points["embedding"]
+    emb = points["embedding"].to(dtype)
     table = torch.cat([xyz[None], pers, emb], dim=-1)
     sampled = torch.index_select(table, 1, flat).view(B, R, SR, K, emb.shape[2] + 6)
-    s_color = torch.index_select(points["color"], 1, flat).view(B, R, SR, K, 3)
-    s_dir = torch.index_select(points["dir"], 1, flat).view(B, R, SR, K, 3)
-    s_conf = torch.index_select(points["conf"], 1, flat).view(B, R, SR, K, 1)
-    return (s_color, points["Rw2c"], s_dir, sampled[..., 6:], sampled[..., 3:6], sampled[..., :3], s_conf,
+    s_color = torch.index_select(points["color"].to(dtype), 1, flat).view(B, R, SR, K, 3)
+    s_dir = torch.index_select(points["dir"].to(dtype), 1, flat).view(B, R, SR, K, 3)
+    s_conf = torch.index_select(points["conf"].to(dtype), 1, flat).view(B, R, SR, K, 1)
+    return (s_color, points["Rw2c"].to(dtype), s_dir, sampled[..., 6:], sampled[..., 3:6], sampled[..., :3], s_conf,
             loc, loc_w, pnt_mask, sample_ray_dirs, cfg.vsize, ray_mask), stats
 
 
@@ -455,10 +460,10 @@ def decode_features(w: Dict[str, torch.Tensor], cfg: OracleConfig, s_color, Rw2c
     feat = _mlp(feat, w, "mlp_head", 2, slope)
 
     alpha = F.relu(F.linear(feat, w["field_output_density.net.weight"], w["field_output_density.net.bias"]))
-    holder = torch.zeros([B * R * SR * K, 1])
+    holder = torch.zeros([B * R * SR * K, 1], dtype=feat.dtype)
     holder[flat, :] = alpha
     alpha = torch.sum(holder.view(B * R * SR, K, 1) * weight, dim=-2).view(-1, 1)[sample_valid, :]
-    holder = torch.zeros([B * R * SR * K, feat.shape[-1]])
+    holder = torch.zeros([B * R * SR * K, feat.shape[-1]], dtype=feat.dtype)
     holder[flat, :] = feat
     agg = torch.sum(holder.view(B * R * SR, K, -1) * weight, dim=-2).view(-1, feat.shape[-1])[sample_valid, :]
 
@@ -466,7 +471,7 @@ def decode_features(w: Dict[str, torch.Tensor], cfg: OracleConfig, s_color, Rw2c
     c = _mlp(c, w, "mlp_color", 3, slope)
     c = torch.sigmoid(F.linear(c, w["field_output_color.net.weight"], w["field_output_color.net.bias"]))
     c = c * (1 + 2 * 0.001) - 0.001
-    out = torch.zeros([total_len, 4])
+    out = torch.zeros([total_len, 4], dtype=c.dtype)
     out[sample_valid] = torch.cat([alpha, c], dim=-1)
     return out.view(in_shape[:-1] + (4,)), sample_valid.view(in_shape[:-1]), norm_weight.view(B, R, SR, K)
 
@@ -525,13 +530,21 @@ def fill_invalid(rgb_hit, ray_mask):
 
 
 def render(points, w, cfg: OracleConfig, origins, directions, near, far, camrotc2w,
-           jitter: float = 0.0, u=None, training: bool = False, compat_drop0: bool = True, probe: bool = False):
+           jitter: float = 0.0, u=None, training: bool = False, compat_drop0: bool = True, probe: bool = False,
+           dtype=torch.float32):
     """NeuralPoints.forward + PointNerf.get_outputs for one ray bundle.  Returns a dict with
     the plugin's outputs (coarse_raycolor [R,3], ray_mask [R] int8) plus the build's extra
     outputs (depth [R], acc [R]) and intermediate tensors used by the parity tests."""
     (s_color, Rw2c, s_dir, s_emb, s_pers, s_xyz, s_conf, loc, loc_w, pnt_mask, ray_dirs, vsize,
      ray_mask), stats = neural_points_forward(points, cfg, origins, directions, near, far, camrotc2w,
-                                              jitter, u, compat_drop0)
+                                              jitter, u, compat_drop0, dtype)
+    if dtype != torch.float32:
+        # the yardstick (tests): the per-sample decode in `dtype` behind the float32 query; no composite
+        w = {k: v.to(dtype) for k, v in w.items()}
+        decoded, sample_valid, weight = decode_features(w, cfg, s_color, Rw2c, s_dir, s_emb, s_pers, s_xyz, loc, loc_w,
+                                                        pnt_mask, ray_dirs)
+        return {"ray_mask": ray_mask.squeeze(0), "stats": stats, "decoded": decoded, "sample_valid": sample_valid,
+                "pnt_mask": pnt_mask}
     R = directions.shape[0]
     out = {"ray_mask": ray_mask.squeeze(0), "stats": stats}
     if loc_w.shape[1] == 0:

@@ -555,7 +555,12 @@ class PointNerf(Model):
             rows = torch.arange(pidx.shape[0], device=pidx.device)[:, None] < cnt[2]       # selected samples
             filled = (pidx >= 0) & rows
             conf = npts.points_conf[0, :, 0]
-            values = torch.cat([conf[pidx.clamp(min=0).reshape(-1).long()], conf[0:1]])
+            # (rows of the workspace beyond the selected samples hold whatever was there: mask BEFORE indexing.  The
+            # masked slots carry weight 0; they read DISTINCT rows -- slot j reads point j mod N -- because autograd's
+            # index backward adds into the row of every slot, zero or not: two million atomic adds on ONE row take 30 ms)
+            spread = torch.arange(pidx.numel(), device=pidx.device, dtype=torch.int32).remainder_(conf.shape[0])
+            index = torch.where(filled.reshape(-1), pidx.reshape(-1), spread).long()
+            values = torch.cat([conf[index], conf[0:1]])
             n_slots = cnt[1] * (self.config.SR * self.config.K)        # rays kept x SR x K: the reference's tensor
             w = torch.cat([filled.reshape(-1).to(torch.float32),
                            (n_slots - filled.sum()).to(torch.float32).reshape(1)])
@@ -708,10 +713,11 @@ class PointNerf(Model):
         """studio_model.py:415-431."""
         device = outputs["coarse_raycolor"].device
         image = batch["image"].to(device)
-        keep = (outputs["ray_mask"] > 0)[..., None].expand(-1, 3)
-        masked_output = torch.masked_select(outputs["coarse_raycolor"], keep).reshape(-1, 3)
-        masked_gt = torch.masked_select(image, keep).reshape(-1, 3)
-        loss_dict = {"ray_masked_coarse_raycolor_loss": self.mask_loss(masked_gt, masked_output) + 1e-6}
+        # the reference compacts both tensors with masked_select (a device-to-host read each: the sizes) and takes
+        # MSELoss over what is left; the same mean as a masked sum, nothing read back
+        keep = (outputs["ray_mask"] > 0)[..., None].to(outputs["coarse_raycolor"].dtype)
+        diff = (image - outputs["coarse_raycolor"]) * keep
+        loss_dict = {"ray_masked_coarse_raycolor_loss": torch.sum(diff * diff) / (3.0 * torch.sum(keep)) + 1e-6}
         if self.training:
             val = torch.clamp(outputs["conf_coefficient"], self.config.zero_epsilon, 1 - self.config.zero_epsilon)
             term = torch.log(val) + torch.log(1 - val)

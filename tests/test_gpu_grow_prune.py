@@ -215,7 +215,7 @@ def test_prune_after_an_in_place_edit_of_the_cloud_rebuilds_instead_of_updating(
     with torch.no_grad():
         out = model(bundle)
     ref = oracle.render(pr, w, ocfg, campos[None].expand(R, 3), dirs, 2.0, 6.0, camrot)
-    assert ref["stats"]["rays_kept"] > 50
+    assert ref["stats"]["rays_kept"] > 20
     assert torch.equal(out["ray_mask"].cpu(), ref["ray_mask"])
     assert (out["coarse_raycolor"].cpu() - ref["coarse_raycolor"]).abs().max().item() <= NORTH_STAR["rgb"]
 

@@ -232,7 +232,7 @@ def test_training_steps_issue_one_host_read_and_no_full_repack(oracle, gpu_devic
     bundles = [bundle, _bundle(gpu_device, 24, 24, 150.0)]
     model.train()
     model.neural_points.jitter = 0.0
-    opt = torch.optim.Adam([{"params": g} for g in model.get_param_groups().values()], lr=1e-2)
+    opt = torch.optim.Adam([{"params": g} for g in model.get_param_groups().values()], lr=1e-3)
     image = torch.rand(bundle.directions.shape[0], 3, device=gpu_device)
     full_packs = []
     scene = None
@@ -263,7 +263,7 @@ def test_training_steps_issue_one_host_read_and_no_full_repack(oracle, gpu_devic
     with torch.no_grad():
         ev = model(bundles[0])["coarse_raycolor"]
     inside = (ev > 0) & (ev < 1)
-    assert (ev - fresh)[inside].abs().max().item() <= 1e-6
+    assert int(inside.sum()) > 100 and (ev - fresh)[inside].abs().max().item() <= 1e-6
 
 
 def test_dropin_query_op_signature(oracle, gpu_device):
