@@ -210,8 +210,10 @@ int pnr_render(const pnr_scene_t *scene, const pnr_weights_t *weights, const flo
                float *d_rgb, float *d_depth, float *d_acc, int8_t *d_ray_mask, int64_t *d_counters,
                void *d_workspace, size_t workspace_bytes, int64_t cap_samples, void *stream);
 
-/* The counter-based uniform in [0,1) (24 random bits) the kernels draw for coarse sample `sample` of ray `ray`
- * (ray = index of the ray inside the call) when jitter > 0; host-callable so a caller can reproduce a frame. */
+/* The counter-based uniform in [0,1) (24 random bits) the kernels draw for coarse sample `sample` of ray `ray` when
+ * jitter > 0; host-callable so a caller can reproduce a frame.  `ray` is the index of the ray inside the call for
+ * pnr_render / pnr_render_views / pnr_query_raypos, and view * H * W + pixel id for pnr_render_camera(_lists): a frame
+ * rendered from cameras draws the same uniforms for a pixel however it is cut into calls, tile shards or ranks. */
 float pnr_jitter_uniform(uint32_t seed, uint32_t ray, uint32_t sample);
 
 /* Several ray bundles (cameras) in ONE call: ray r belongs to camera d_ray_cam[r] or, when d_ray_cam is NULL,

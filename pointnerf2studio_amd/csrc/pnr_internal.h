@@ -105,6 +105,7 @@ struct CamRef {
     const int *pixels;
     long long n_pixels;
     int pix_per_view;   // pixels holds one list of n_pixels entries PER VIEW (pnr_render_camera_lists)
+    long long frame_pixels;   // H * W of the frame (pnr_render_camera): the jitter stream of a ray is keyed on it
 };
 
 // Direction of pixel (x, y) of a pinhole view: the arithmetic include/pnr.h states for pnr_view_t, fp32, unfused (the
@@ -139,6 +140,18 @@ __host__ __device__ __forceinline__ float pnr_uniform(unsigned seed, unsigned ra
 struct CamSet {
     Camera c[PNR_MAX_CAMS];
 };
+// The key of ray r's jitter stream u(seed, key, sample).  From a direction tensor: the ray's index inside the call.
+// From cameras (pnr_render_camera): view * H * W + pixel id, whatever pixel list the call was given -- a frame rendered
+// as one call, as tile shards on 1 / 2 / 4 / 8 ranks, or with the owners rotated per view draws the SAME uniforms for a
+// pixel (for a whole frame without a pixel list the two coincide).
+__device__ __forceinline__ unsigned jitter_key(const CamRef &cr, long long r)
+{
+    if (!cr.gen_rays) return (unsigned)r;
+    const unsigned long long v = (unsigned long long)r / (unsigned long long)cr.n_pixels;
+    const unsigned long long i = (unsigned long long)r - v * (unsigned long long)cr.n_pixels;
+    const unsigned p = cr.pixels ? (unsigned)cr.pixels[cr.pix_per_view ? (unsigned long long)r : i] : (unsigned)i;
+    return (unsigned)(v * (unsigned long long)cr.frame_pixels + p);
+}
 __device__ __forceinline__ int cam_id(const CamRef &cr, long long r)
 {
     if (cr.n_cams <= 1) return 0;
@@ -299,6 +312,8 @@ struct RenderWs {
     float *ray_cm;     // [R] running maximum of the camera-space depth (ray_dist state of the composite)
     int *ray_alive;    // [R]
     float *ray_dirs;   // [R,3] pnr_render_camera: directions of the rays that have samples (written by k_expand)
+    float *smp_wgt;    // [cap, K] normalised inverse-distance weight of every neighbour slot (k_pair_weights; the pair
+                       // kernel on dense units reads its row's weight instead of summing over the sample's rows)
     int *n_sel;        // device ints: [0]=S_sel (clamped to cap), [1]=S_valid, [2]=R, [3]=U unique neighbour points,
                        // [4],[5] = first / one-past-last position of the current shading pass in vs_all, [6] = 0
     unsigned long long *shards;  // statistics counters, SHARDS x 128-byte lines per counter (see shard_add)

@@ -54,6 +54,7 @@ RenderWs carve_render_ws(void *base, int64_t R, int64_t cap, int K, int64_t N, i
     ws.ray_cm = (float *)take((size_t)R * sizeof(float));
     ws.ray_alive = (int *)take((size_t)R * sizeof(int));
     ws.ray_dirs = (float *)take((size_t)R * 3 * sizeof(float));
+    ws.smp_wgt = (float *)take((size_t)cap * K * sizeof(float));
     ws.total = off;
     if (N > 0) {
         ws.u_cap = std::max<int64_t>(1, std::min<int64_t>(n_list, cap * (int64_t)K));
@@ -82,7 +83,7 @@ __device__ __forceinline__ float sample_t(const CamRef &cr, const float *__restr
     if (cr.jitter == 0.0f) return j < D ? tab[j] : 0.f;
     float seg = 0.f;
     if (j < D) {
-        const float u = pnr_uniform(cr.seed, (unsigned)r, (unsigned)j);
+        const float u = pnr_uniform(cr.seed, jitter_key(cr, r), (unsigned)j);
         seg = tab[D + j] * (1.0f + cr.jitter * (u - 0.5f));
     }
     double s = (double)seg;

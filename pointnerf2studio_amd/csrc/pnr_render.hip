@@ -286,6 +286,7 @@ extern "C" size_t pnr_render_workspace_bytes_for(const pnr_scene_t *scene, const
 // rays from cameras (pnr_render_camera): frame width, pixel list, pixels per view
 struct RayGen {
     int W = 0;
+    int H = 0;
     const int *pixels = nullptr;
     int64_t n_pixels = 0;
     int per_view = 0;
@@ -346,6 +347,7 @@ static int render_views(const pnr_scene_t *scene, const pnr_weights_t *weights, 
     if (gen) {
         cr.gen_rays = 1;
         cr.W = gen->W;
+        cr.frame_pixels = (long long)gen->W * gen->H;
         cr.pixels = gen->pixels;
         cr.pix_per_view = gen->per_view;
         cr.n_pixels = gen->n_pixels;
@@ -461,6 +463,7 @@ static int render_camera_impl(const pnr_scene_t *scene, const pnr_weights_t *wei
     }
     RayGen gen;
     gen.W = W;
+    gen.H = H;
     gen.pixels = d_pixels;
     gen.n_pixels = n_pixels;
     gen.per_view = per_view;

@@ -1,5 +1,7 @@
 // Shade stage, host side: weight packing (PyTorch [out,in] -> MFMA operand order), the early-termination passes and
 // launch_shade.  Kernels: pnr_shade_fp32.hip, pnr_shade_bf16.hip; overview: pnr_shade_common.h.
+#include <stdlib.h>
+
 #include "pnr_shade_common.h"
 
 namespace pnr {
@@ -240,6 +242,39 @@ __global__ void __launch_bounds__(TPB) k_pass_update(CamRef cr, pnr_render_opts_
     ray_alive[r] = (T > opts.early_stop_eps && hi < cnt) ? 1 : 0;
 }
 
+// Normalised inverse-distance weights of every neighbour slot of the samples [n_sel[i0], n_sel[i1]) of `list`
+// (studio_model.py:285-286,467-475): w_k = mask_k / clamp(||p_k - s||, 1e-6), divided by clamp(sum_k w_k, 1e-8).  One
+// thread per sample, the K slots in order.  For the pair kernel on dense units, whose rows of a sample may sit in
+// two tiles: it reads its row's weight instead of summing over the sample's rows.
+__global__ void __launch_bounds__(256) k_pair_weights(const int *__restrict__ n_sel, int i0, int i1,
+                                                      const int *__restrict__ list, const int *__restrict__ smp_pidx,
+                                                      const float4 *__restrict__ smp_loc,
+                                                      const float4 *__restrict__ point_rows, int K,
+                                                      float *__restrict__ smp_wgt)
+{
+    const int v0 = n_sel[i0], v1 = n_sel[i1];
+    for (int v = v0 + blockIdx.x * 256 + threadIdx.x; v < v1; v += gridDim.x * 256) {
+        const int s = list[v];
+        const float4 loc = smp_loc[s];
+        const int *pid = smp_pidx + (int64_t)s * K;
+        float *out = smp_wgt + (int64_t)s * K;
+        float wsum = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const int p = pid[k];
+            float w = 0.f;
+            if (p >= 0) {
+                const float4 a0 = point_rows[(int64_t)p * 12];
+                const float dx = a0.x - loc.x, dy = a0.y - loc.y, dz = a0.z - loc.z;
+                w = 1.0f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-6f);
+            }
+            out[k] = w;
+            wsum += w;
+        }
+        const float den = fmaxf(wsum, 1e-8f);
+        for (int k = 0; k < K; ++k) out[k] = out[k] / den;
+    }
+}
+
 __global__ void k_publish_shaded(const int *__restrict__ n_sel, int idx, int64_t *__restrict__ counters)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) counters[PNR_CNT_SAMPLES_SHADED] = n_sel[idx];
@@ -267,6 +302,7 @@ int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr,
     P.smp_ray = ws.smp_ray;
     P.smp_pidx = ws.smp_pidx;
     P.vs_list = early ? ws.vs_all : ws.vs_list;
+    P.smp_wgt = ws.smp_wgt;
     P.n_sel = ws.n_sel;
     P.i_v0 = early ? 4 : 6;  // n_sel[6] == 0
     P.i_v1 = early ? 5 : 1;
@@ -291,10 +327,36 @@ int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr,
     // decoded features of samples without neighbours (or not shaded) are zero (studio_model.py:361-362)
     PNR_HIP_CHECK(hipMemsetAsync(ws.smp_out, 0, (size_t)cap * sizeof(float4), stream));
     const int seg = K <= 8 ? 8 : (K <= 16 ? 16 : 0);   // lanes per sample segment (0: exactly K)
-    const int spt = (32 / (seg ? seg : K)) * WAVES;
+    const bool bf = precision == PNR_PRECISION_BF16X3;
+    // fp32, K that does not fill its segment: dense units -- su samples fill tu tiles of a wave (K = 12: 8 samples in 3
+    // tiles, no padding); the best fill among 1..3 tiles, at most 16 samples per unit
+    int su = 0, tu = 0;
+#ifndef PNR_NO_DENSE_UNITS
+    // (PNR_DENSE_UNITS=0 in the environment: the segment form, for A/B runs on one device)
+    static const int dense_mode = [] {
+        const char *e = getenv("PNR_DENSE_UNITS");
+        return e ? atoi(e) : 1;     // 0: never, 1: where it fills more rows, 2: also for K = 8 and 16
+    }();
+    const bool dense_all = dense_mode == 2 && (K == 8 || K == 16);
+    if (!bf && ((K >= 11 && K != 16 && dense_mode != 0) || dense_all)) {   // (K >= 11, or K = 8 / 16 aligned to the
+        // tiles: at most four samples touch a tile, see the kernel)
+        double best = (double)K / (seg ? seg : K * (32 / K)) * 1.0001;   // what the segment form fills
+        if (!seg) best = (double)(32 / K) * K / 32.0 * 1.0001;
+        if (dense_all) best = 0.0;
+        for (int t = 1; t <= (dense_all ? 1 : 3); ++t) {
+            const int s_ = std::min(32 * t / K, 16);
+            const double fill = (double)s_ * K / (32.0 * t);
+            if (s_ >= 1 && fill > best) {
+                best = fill;
+                su = s_;
+                tu = t;
+            }
+        }
+    }
+#endif
+    const int spt = su ? su * WAVES : (32 / (seg ? seg : K)) * WAVES;
     const int64_t max_tiles = (cap + spt - 1) / spt;
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cus, max_tiles));
-    const bool bf = precision == PNR_PRECISION_BF16X3;
     {
         if (!ws.pt_table) {
             set_error("launch_shade: the workspace lacks the point-part buffers (pnr_render_workspace_bytes_for)");
@@ -311,6 +373,12 @@ int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr,
     auto launch_pairs = [&]() {
         if (bf)
             launch_pairs_bf16(seg, dim3(grid), stream, P);
+        else if (su) {
+            hipLaunchKernelGGL(k_pair_weights, dim3((unsigned)std::min<int64_t>((cap + 255) / 256, 256 * 16)), dim3(256), 0,
+                               stream, ws.n_sel, P.i_v0, P.i_v1, P.vs_list, ws.smp_pidx, ws.smp_loc, P.point_rows, K,
+                               ws.smp_wgt);
+            launch_pairs_fp32_dense(su, tu, dim3(grid), stream, P);
+        }
         else
             launch_pairs_fp32(seg, dim3(grid), stream, P);
     };

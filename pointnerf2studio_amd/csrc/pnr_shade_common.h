@@ -86,6 +86,7 @@ struct ShadeParams {
     const int *smp_ray;
     const int *smp_pidx;
     const int *vs_list;
+    float *smp_wgt;    // [S_sel, K] normalised inverse-distance weights (dense units only)
     const int *n_sel;  // [1] = S_valid
     float *smp_sigma;  // [S_valid]
     float *agg;        // [S_valid, 256]
@@ -278,6 +279,7 @@ struct RowFetch {
     bool row_ok, smp_ok;
     float4 a0, c0, c1, loc;
     float dirx, diry, dirz;
+    float wgt;   // dense units: the row's normalised weight (smp_wgt)
 };
 
 template <int SEG>
@@ -428,8 +430,12 @@ __device__ __forceinline__ void pair_inputs(const ShadeParams &P, const RowFetch
     const float dwx = a0.x - loc.x, dwy = a0.y - loc.y, dwz = a0.z - loc.z;
     const float nrm = sqrtf(dwx * dwx + dwy * dwy + dwz * dwz);
     float wgt = valid ? 1.0f / fmaxf(nrm, 1e-6f) : 0.f;
-    const float wsum = seg_sum<SEG>(wgt, K, lane);
-    ctx.wgt = wgt / fmaxf(wsum, 1e-8f);
+    if constexpr (SEG < 0) {
+        ctx.wgt = valid ? f.wgt : 0.f;   // dense units (k_shade_pairs_dense): normalised by k_pair_weights
+    } else {
+        const float wsum = seg_sum<SEG>(wgt, K, lane);
+        ctx.wgt = wgt / fmaxf(wsum, 1e-8f);
+    }
 
     float dd[3];
     if (h == 0) {
@@ -674,6 +680,8 @@ __device__ __forceinline__ void color_head_lds(const float (&b8)[3], const u32x4
 // seg = lanes per sample segment (8, 16, or 0 for exactly K)
 void launch_point_part_fp32(dim3 grid, hipStream_t stream, const ShadeParams &P);
 void launch_pairs_fp32(int seg, dim3 grid, hipStream_t stream, const ShadeParams &P);
+// dense units (any K): su consecutive samples fill tu 32-row tiles of a wave, see k_shade_pairs_dense
+void launch_pairs_fp32_dense(int su, int tu, dim3 grid, hipStream_t stream, const ShadeParams &P);
 void launch_color_fp32(dim3 grid, hipStream_t stream, const ShadeParams &P);
 void launch_point_part_bf16(dim3 grid, hipStream_t stream, const ShadeParams &P);
 void launch_pairs_bf16(int seg, dim3 grid, hipStream_t stream, const ShadeParams &P);

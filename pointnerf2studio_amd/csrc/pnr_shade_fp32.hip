@@ -410,6 +410,378 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
     }
 }
 
+
+// ================================================================================================
+// Dense units: the pair kernel for K that does not divide a 32-row tile.
+//
+// k_shade_pairs<16> gives a sample with 9..16 neighbours a 16-lane segment: at K = 12 (BASELINE cfg[4], the reference's
+// ScanNet scripts) a quarter of every MFMA multiplies padding (0.66 of the peak).  Here SU consecutive samples fill TU
+// consecutive tiles of ONE wave with no gap between them -- K = 12: 8 samples x 12 rows = 96 rows = 3 tiles exactly -- so
+// a sample's rows sit at any multiple-of-K offset and may straddle two tiles.  Sums over a sample's rows therefore
+// leave the register file, in two steps that cost the vector ALU next to nothing (a SIMD does not overlap VALU and
+// MFMA work, but LDS instructions between two MFMAs are as free as loads; the 16-lane segment spends four DPP adds per
+// value, 512 per tile):
+//   1. every finished layer-4 value, times its row's normalised weight (k_pair_weights), goes into a wave-private
+//      ROW BUFFER in LDS: 32 rows x 256 features, one ds_write_b128 per four values (rows 1040 bytes apart: conflict-free);
+//   2. during the NEXT tile's layers 2 and 3 the wave reads the buffer back TRANSPOSED -- lane l takes features
+//      4l .. 4l+3 of row r -- and adds them into the slot of row r's sample with four ds_add_f32: every lane owns its
+//      addresses (no conflict, a fixed order row after row), one address add per row is all the VALU does;
+//   3. a sample whose last row was in that tile is complete: its slot is read, stored in the colour kernel's layout and
+//      cleared (four candidates per tile, predicated: no branch inside the stream).  A slot is reused every fourth
+//      sample, which is safe for K >= 11 (the rows of samples s and s + 4 never share a tile).
+// The first version added every value straight into the sample's slot (rows of a sample meet in one address): twelve-way
+// same-address float atomics cost ~450 cycles per instruction, 0.71 of the peak.
+// ================================================================================================
+constexpr int DENSE_NS = 4;                      // sample slots per wave
+constexpr int DENSE_ROW_B = 1040;                // bytes between rows of the row buffer (1024 + 16: bank skew)
+constexpr int DENSE_ROWBUF_B = 32 * DENSE_ROW_B;
+constexpr int DENSE_SLOTS_B = DENSE_NS * 1024;
+constexpr int DENSE_SIG_B = 64;                  // density sums of the slots
+constexpr int DENSE_DUMMY_B = 1024 + 64;         // where predicated-off LDS writes go
+constexpr int DENSE_WAVE_B = DENSE_ROWBUF_B + DENSE_SLOTS_B + DENSE_SIG_B + DENSE_DUMMY_B;   // 38 528
+
+// off: a constant once the caller is unrolled and inlined (an immediate of the instruction)
+__device__ __forceinline__ void lds_add(unsigned addr, float v, int off)
+{
+    asm volatile("ds_add_f32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(off));
+}
+__device__ __forceinline__ void lds_write4(unsigned addr, f32x4 v, int off)
+{
+    asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(off));
+}
+__device__ __forceinline__ f32x4 lds_read4(unsigned addr, int off)
+{
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(off));
+    return v;
+}
+__device__ __forceinline__ void lds_wait()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+__global__ void __launch_bounds__(TPB, 1) k_shade_pairs_dense(ShadeParams P, int SU, int TU)
+{
+    extern __shared__ float dense_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    const int K = P.K;
+    const int V0 = P.n_sel[P.i_v0], S_valid = P.n_sel[P.i_v1];
+    const int SPU = SU * WAVES;                        // samples per workgroup unit
+    const int nunits = (S_valid - V0 + SPU - 1) / SPU;
+    const TileWalk walk((int)blockIdx.x, (int)gridDim.x, nunits);   // XCD-aware order of the units
+    const unsigned rowbuf = (unsigned)(uintptr_t)dense_lds + (unsigned)(wave * DENSE_WAVE_B);
+    const unsigned slots = rowbuf + DENSE_ROWBUF_B, sig = slots + DENSE_SLOTS_B, dummy = sig + DENSE_SIG_B;
+    const unsigned wr_base = rowbuf + (unsigned)(j * DENSE_ROW_B + 16 * h);   // + 128 t4 + 32 q: features 32 t4 + 8 q + 4 h
+    const unsigned rd_base = rowbuf + 16u * lane;                             // + 1040 r: features 4 l .. 4 l + 3 of row r
+    const unsigned lane16 = 16u * lane;
+
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wbuf), 0, (int)P.wbytes, 0x00020000);
+    const int voff = lane * 16;
+    const WBase wb_ = {(int)(P.w32b_off * 4), (int)(P.w_off[1] * 4), (int)(P.w_off[2] * 4), (int)(P.w_off[3] * 4)};
+    const float *b1 = P.wbuf + P.b_off[1], *b2 = P.wbuf + P.b_off[2], *b3 = P.wbuf + P.b_off[3];
+    const float *w4t = P.wbuf + P.w4acc_off;
+    const float b4 = P.wbuf[P.b_off[4]];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    // slots, density sums and the dummy area start at zero (the row buffer is rewritten completely by every tile)
+    for (int s = 0; s < DENSE_NS; ++s) asm volatile("ds_write_b128 %0, %1" ::"v"(slots + 1024u * s + lane16), "v"(zero4));
+    asm volatile("ds_write_b128 %0, %1" ::"v"(dummy + lane16), "v"(zero4));
+    if (lane < 8) asm volatile("ds_write_b128 %0, %1" ::"v"(sig + lane16), "v"(zero4));   // sig (64 B) + dummy tail (64 B)
+    lds_wait();
+
+    // rows of tile t of workgroup unit wu: row u = 32 t + j of the wave's unit = slot (u mod K) of its sample u / K
+    auto fetch_a_dense = [&](int wu, int t, RowFetch &f, int &sl) {
+        const int u = 32 * t + j;
+        sl = u / K;
+        f.slot = u - sl * K;
+        f.v_idx = V0 + (wu * WAVES + wave) * SU + sl;
+        f.smp_ok = sl < SU && f.v_idx < S_valid;
+        f.row_ok = f.smp_ok;
+        f.s = P.vs_list[f.row_ok ? f.v_idx : 0];
+    };
+    auto fetch_b_dense = [&](RowFetch &f) {
+        fetch_b<-1>(P, f);
+        f.wgt = P.smp_wgt[(int64_t)f.s * K + (f.row_ok ? f.slot : 0)];
+    };
+
+    // ---- the previous tile's rows -> sample slots (steps 2 and 3 of the header) ---------------------------------------
+    // uniform state of the tile whose rows are in the row buffer
+    int p_have = 0, p_si0 = 0, p_rem0 = 0, p_end = 0, p_vfirst = 0;
+    f32x4 pend[2];
+    // slot base of row r of the previous tile (wave-uniform: scalar ALU)
+    auto row_slot_base = [&](int r) -> unsigned {
+        const int x = p_rem0 + r;
+        const int si = p_si0 + (x >= K ? 1 : 0) + (x >= 2 * K ? 1 : 0) + (x >= 3 * K ? 1 : 0);
+        return p_have ? slots + 1024u * (unsigned)(si & (DENSE_NS - 1)) : dummy;
+    };
+    auto reduce_issue = [&](int r0) {   // reads of rows r0, r0 + 1
+        pend[0] = lds_read4(rd_base, r0 * DENSE_ROW_B);
+        pend[1] = lds_read4(rd_base, (r0 + 1) * DENSE_ROW_B);
+    };
+    auto reduce_add = [&](int r0) {     // adds of rows r0, r0 + 1 (read one step earlier)
+        lds_wait();
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const unsigned a = lane16 + row_slot_base(r0 + e);
+            lds_add(a, pend[e].x, 0);
+            lds_add(a, pend[e].y, 4);
+            lds_add(a, pend[e].z, 8);
+            lds_add(a, pend[e].w, 12);
+        }
+    };
+    float sg_carry[4] = {0.f, 0.f, 0.f, 0.f};
+    int sg_v[4] = {-1, -1, -1, -1};
+    // samples whose last row was in the previous tile: out and cleared.  Four candidates, everything predicated.
+    auto complete_prev = [&]() {
+        lds_wait();
+        const int fk = 2 * (lane >> 3) + (((lane >> 1) & 3) >> 1), fhp = lane & 1, fh = (lane >> 1) & 1;
+        f32x4 sum[4];
+        float sg[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int sc = p_si0 + c;
+            const unsigned sb = slots + 1024u * (unsigned)(sc & (DENSE_NS - 1));
+            sum[c] = lds_read4(sb + lane16, 0);
+            asm volatile("ds_read_b32 %0, %1" : "=v"(sg[c]) : "v"(sig + 4u * (unsigned)(sc & (DENSE_NS - 1))));
+        }
+        lds_wait();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int sc = p_si0 + c;
+            const int v = p_vfirst + sc;
+            const bool done = p_have && (sc + 1) * K <= p_end && sc < SU && v < S_valid;
+            const unsigned sb = slots + 1024u * (unsigned)(sc & (DENSE_NS - 1));
+            lds_write4((done ? sb : dummy) + lane16, zero4, 0);
+            asm volatile("ds_write_b32 %0, %1" ::"v"(done ? sig + 4u * (unsigned)(sc & (DENSE_NS - 1)) : dummy + 1024u),
+                         "v"(0.f));
+            // the sample's block of 32 in the colour kernel's layout (agg_idx4); lanes of a sample that is not complete
+            // carry an offset beyond the descriptor's range: the hardware drops the store
+            const int vb = done ? v : 0;
+            const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+                P.agg + (int64_t)(vb >> 5) * 8192, 0, 32768, 0x00020000);
+            const int ooff = done ? 2048 * fk + 1024 * fhp + 512 * fh + 16 * (vb & 31) : 0x40000000;
+            u32x4 o;
+            o.x = __float_as_uint(sum[c].x);
+            o.y = __float_as_uint(sum[c].y);
+            o.z = __float_as_uint(sum[c].z);
+            o.w = __float_as_uint(sum[c].w);
+            __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, ooff, 0, 0);
+            sg_carry[c] = sg[c];
+            sg_v[c] = done ? v : -1;
+        }
+    };
+    // the densities of the samples completed by complete_prev() (plain stores: called where branches cost nothing)
+    auto store_sigmas = [&]() {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (sg_v[c] >= 0 && lane == 0) {
+                P.smp_sigma[sg_v[c]] = sg_carry[c];
+                if (P.smp_sig_s) P.smp_sig_s[P.vs_list[sg_v[c]]] = sg_carry[c];
+            }
+            sg_v[c] = -1;
+        }
+    };
+
+    int n_unit = 0, t_cur = 0;
+    int wu_cur = walk.at(0);
+    float4 wq[PFS];
+    RowFetch cur, nxt;
+    int sl_cur = 0, sl_nxt = 0;
+    if (wu_cur < nunits) {
+#pragma unroll
+        for (int p = 0; p < PFS; ++p) wq[p] = load_w(rsrc, voff, group_off(wb_, p));
+        fetch_a_dense(wu_cur, 0, cur, sl_cur);
+        fetch_b_dense(cur);
+        fetch_c_pair(P, cur);
+    }
+    while (wu_cur < nunits) {
+        WBase wb = wb_;
+        asm volatile("" : "+s"(wb.l1), "+s"(wb.l2), "+s"(wb.l3), "+s"(wb.l4));
+        const auto goff = [&](int G) { return group_off(wb, G); };
+        // the tile after this one: the unit's next tile, or tile 0 of the workgroup's next unit
+        int t_nxt = t_cur + 1, n_nxt = n_unit, wu_nxt = wu_cur;
+        if (t_nxt == TU) {
+            t_nxt = 0;
+            n_nxt = n_unit + 1;
+            wu_nxt = walk.at(n_nxt);
+        }
+        float xq[32];
+        RowCtx ctx;
+        const float4 *trow = P.pt_table + (int64_t)cur.urow * 64 + 4 * h;
+        {
+            const Camera cam = load_cam_wave(P.cr, cur.cid);
+            pair_inputs<-1, true, false>(P, cur, cam, lane, xq, ctx);
+        }
+        fetch_a_dense(wu_nxt, t_nxt, nxt, sl_nxt);            // a unit past the end loads entry 0: harmless
+        f32x16 acc[8];
+        float X[128], Y[132];
+        // ---- layer 1 -----------------------------------------------------------------------------------------------
+        {
+            Ini r0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r0.v[q] = trow[q];
+            acc[0] = acc_from(r0);
+        }
+        layer_stream<32, 8, 0, PFS>(
+            rsrc, voff, goff, wq, xq, acc,
+            [&](int m) {
+                Ini r;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) r.v[q] = trow[8 * m + q];
+                return r;
+            },
+            [&](int m, int i) {
+                if (m > 0 && i < 16 / FPM) {
+#pragma unroll
+                    for (int q = 0; q < FPM; q += 2) {
+                        float u, v;
+                        leaky2(acc[m - 1][FPM * i + q], acc[m - 1][FPM * i + q + 1], u, v);
+                        X[16 * (m - 1) + FPM * i + q] = to_a(u);
+                        X[16 * (m - 1) + FPM * i + q + 1] = to_a(v);
+                    }
+                }
+                if (m == 7 && i == 0) reduce_issue(0);   // the previous tile's rows 0, 1
+            });
+        // ---- layer 2: + rows 0..15 of the previous tile into their slots -------------------------------------------
+        {
+            const f32x16 last = acc[7];
+            acc[0] = acc_from(bias_ini(b1, 0, h));
+            layer_stream<128, 8, NG_L1, PFS>(
+                rsrc, voff, goff, wq, X, acc, [&](int m) { return bias_ini(b1, m, h); },
+                [&](int m, int i) {
+                    if (i < 16 / FPM) {
+#pragma unroll
+                        for (int q = 0; q < FPM; q += 2) {
+                            const int r = FPM * i + q;
+                            float u, v;
+                            if (m == 0) {
+                                leaky2(last[r], last[r + 1], u, v);
+                                X[112 + r] = to_a(u);
+                                X[113 + r] = to_a(v);
+                            } else {
+                                leaky2(acc[m - 1][r], acc[m - 1][r + 1], Y[16 * (m - 1) + r], Y[16 * (m - 1) + r + 1]);
+                            }
+                        }
+                    }
+                    if (i == 0) {
+                        reduce_add(2 * m);
+                        reduce_issue(2 * m + 2);
+                    }
+                });
+        }
+        fetch_b_dense(nxt);
+        // ---- layer 3: + rows 16..31 ----------------------------------------------------------------------------------
+        {
+            const f32x16 last = acc[7];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Y[128 + i] = ctx.ex[i];
+            acc[0] = acc_from(bias_ini(b2, 0, h));
+            layer_stream<132, 8, NG_L1 + NG_L2, PFS>(
+                rsrc, voff, goff, wq, Y, acc, [&](int m) { return bias_ini(b2, m, h); },
+                [&](int m, int i) {
+                    if (i < 16 / FPM) {
+#pragma unroll
+                        for (int q = 0; q < FPM; q += 2) {
+                            const int r = FPM * i + q;
+                            float u, v;
+                            if (m == 0) {
+                                leaky2(last[r], last[r + 1], Y[112 + r], Y[113 + r]);
+                            } else {
+                                leaky2(acc[m - 1][r], acc[m - 1][r + 1], u, v);
+                                X[16 * (m - 1) + r] = to_a(u);
+                                X[16 * (m - 1) + r + 1] = to_a(v);
+                            }
+                        }
+                    }
+                    if (i == 0) {
+                        reduce_add(16 + 2 * m);
+                        if (m < 7) reduce_issue(16 + 2 * m + 2);
+                    }
+                });
+        }
+        fetch_c_pair(P, nxt);
+        complete_prev();   // the row buffer is free again, the completed samples are on their way out
+        // ---- layer 4: every finished value -> LeakyReLU, density product, weight; four values -> one ds_write_b128 --
+        float part = 0.f;
+        float4 hw[4], hw_nx[4];
+        f32x4 o4;
+        // value r of output tile t4 is feature 32 t4 + 8 (r >> 2) + 4 h + (r & 3) of the row
+        auto sink = [&](int t4, int r, float a) {
+            const float v = leaky(a);
+            const float4 w = hw[r >> 2];
+            part += v * ((r & 3) == 0 ? w.x : (r & 3) == 1 ? w.y : (r & 3) == 2 ? w.z : w.w);
+            o4[r & 3] = v * ctx.wgt;
+            if ((r & 3) == 3) lds_write4(wr_base, o4, 128 * t4 + 32 * (r >> 2));
+        };
+        {
+            const f32x16 last = acc[7];
+            acc[0] = acc_from(bias_ini(b3, 0, h));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hw_nx[q] = *reinterpret_cast<const float4 *>(w4t + (0 * 2 + h) * 16 + 4 * q);
+            layer_stream<128, 8, NG_L1 + NG_L2 + NG_L3, PFS>(
+                rsrc, voff, goff, wq, X, acc, [&](int m) { return bias_ini(b3, m, h); },
+                [&](int m, int i) {
+                    if (m == 0 && i < 16 / FPM) {
+#pragma unroll
+                        for (int q = 0; q < FPM; q += 2) {
+                            float u, v;
+                            leaky2(last[FPM * i + q], last[FPM * i + q + 1], u, v);
+                            X[112 + FPM * i + q] = to_a(u);
+                            X[113 + FPM * i + q] = to_a(v);
+                        }
+                    }
+                    if (m > 0 && i == 0) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) hw[q] = hw_nx[q];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            hw_nx[q] = *reinterpret_cast<const float4 *>(w4t + (m * 2 + h) * 16 + 4 * q);
+                    }
+                    // the 16 values of output tile m - 1 in one block behind MFMA 4 of tile m
+                    if (m > 0 && i == 4) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sink(m - 1, r, acc[m - 1][r]);
+                    }
+                });
+        }
+        // behind the tile's last MFMA: output tile 7, the row's density, the densities of the samples completed above
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hw[q] = hw_nx[q];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sink(7, r, acc[7][r]);
+        part += __shfl_xor(part, 32, 64);
+        const float alpha = fmaxf(part + b4, 0.f);
+        // (rows of one sample meet in one address here: one instruction per tile)
+        lds_add(sig + 4u * (unsigned)(sl_cur & (DENSE_NS - 1)), h ? 0.f : alpha * ctx.wgt, 0);
+        store_sigmas();
+        // this tile becomes the previous one
+        p_have = 1;
+        p_si0 = (32 * t_cur) / K;
+        p_rem0 = 32 * t_cur - p_si0 * K;
+        p_end = 32 * (t_cur + 1);
+        p_vfirst = V0 + (wu_cur * WAVES + wave) * SU;
+        cur = nxt;
+        sl_cur = sl_nxt;
+        t_cur = t_nxt;
+        n_unit = n_nxt;
+        wu_cur = wu_nxt;
+    }
+    // the last tile's rows
+    if (p_have) {
+        lds_wait();
+#pragma unroll
+        for (int r0 = 0; r0 < 32; r0 += 2) {
+            reduce_issue(r0);
+            reduce_add(r0);
+        }
+        complete_prev();
+        store_sigmas();
+    }
+}
+
 // Colour MLP: one lane-column per valid sample, 32 samples per wavefront.
 // input 280 = [agg(256) | sin(view*2^f) (12) | cos(...) (12)] -> 128 -> 128 -> 128 -> 3, sigmoid, widen.
 // The same stream structure as the pair kernel: the 268 weight groups of a tile (140 + 64 + 64) behind one rolling
@@ -696,6 +1068,15 @@ void launch_pairs_fp32(int seg, dim3 grid, hipStream_t stream, const ShadeParams
         hipLaunchKernelGGL(k_shade_pairs<16>, grid, dim3(TPB), 0, stream, P);
     else
         hipLaunchKernelGGL(k_shade_pairs<0>, grid, dim3(TPB), 0, stream, P);
+}
+
+void launch_pairs_fp32_dense(int su, int tu, dim3 grid, hipStream_t stream, const ShadeParams &P)
+{
+    const size_t lds = (size_t)WAVES * DENSE_WAVE_B;    // 154 KB of the CU's 160
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(k_shade_pairs_dense),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)attr;
+    hipLaunchKernelGGL(k_shade_pairs_dense, grid, dim3(TPB), lds, stream, P, su, tu);
 }
 
 void launch_color_fp32(dim3 grid, hipStream_t stream, const ShadeParams &P)

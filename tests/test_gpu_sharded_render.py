@@ -3,7 +3,9 @@ one GPU of the test box over gloo (RCCL refuses several ranks on one device; the
 torch.distributed calls).  Every rank renders its 16x16-pixel tiles of two views in one pnr_render_camera_lists call (views =
 pose + intrinsics, rays = the pixel ids of its shard, the tile owner rotated per view) in the lego-like configuration of BASELINE.json configs[2] at
 reduced size, the ranks all_gather their tiles (distributed.gather_views), and every rank must hold the two full
-images bit-identical to the single-process render of the whole frames -- RGB and depth."""
+images bit-identical to the single-process render of the whole frames -- RGB and depth -- at jitter 0 and at the
+reference's coarse-sample jitter of 0.3 (the jitter stream of a ray from a camera is keyed on its view and pixel, not on
+its position in a rank's call: a frame does not depend on the number of ranks or on the rotation of the tile owners)."""
 import os
 import socket
 
@@ -16,7 +18,7 @@ pytestmark = pytest.mark.gpu
 H, W, N_PTS, WORLD = 80, 96, 150_000, 3
 
 
-def _setup(device):
+def _setup(device, jitter=0.0):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "tests")):
@@ -35,7 +37,7 @@ def _setup(device):
                       pts["color"].to(device))
     wh = WeightsHIP()
     wh.pack(w, pts["Rw2c"], device)
-    rnd = RendererHIP(scene, wh, SR=c["SR"], K=c["K"])
+    rnd = RendererHIP(scene, wh, SR=c["SR"], K=c["K"], jitter=jitter, seed=11)
     views = []
     for v in (1, 6):
         campos, camrot = synthetic.make_scene_camera(c, v)
@@ -43,7 +45,7 @@ def _setup(device):
     return rnd, views
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, jitter):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -52,7 +54,7 @@ def _worker(rank, world, port, q):
     try:
         from pointnerf2studio_amd.distributed import gather_views, make_shard
         dev = torch.device("cuda:0")
-        rnd, views = _setup(dev)
+        rnd, views = _setup(dev, jitter)
         # bench.py's shard: the tile owner rotates with the view's position in the step, every view has its own pixel
         # list (pnr_render_camera_lists)
         shard = make_shard(H, W, world, rank, rotate=True)
@@ -66,8 +68,9 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_three_rank_tile_shard_equals_single_process_frames(gpu_device):
-    rnd, views = _setup(gpu_device)
+@pytest.mark.parametrize("jitter", [0.0, 0.3])
+def test_three_rank_tile_shard_equals_single_process_frames(gpu_device, jitter):
+    rnd, views = _setup(gpu_device, jitter)
     whole = rnd.render_camera(views, H, W)
     want = torch.cat([whole["rgb"], whole["depth"][:, None]], dim=1).view(2, H * W, 4).cpu()
     assert whole["counters"]["rays_kept"] > 2000
@@ -76,7 +79,7 @@ def test_three_rank_tile_shard_equals_single_process_frames(gpu_device):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = [ctx.Process(target=_worker, args=(r, WORLD, port, q)) for r in range(WORLD)]
+    procs = [ctx.Process(target=_worker, args=(r, WORLD, port, q, jitter)) for r in range(WORLD)]
     for p in procs:
         p.start()
     got = [q.get(timeout=240) for _ in range(WORLD)]
