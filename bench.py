@@ -125,21 +125,20 @@ def pmc_traffic(kernel, workload_key):
     """HBM bytes per launch of the dominant kernel from the newest committed PMC pass (bench.py cannot collect PMC
     counters itself: they need rocprofv3 --pmc passes, tools/pmc_hbm.sh).  Returned only when that pass was collected
     on THIS workload (config, N, K, SR, precision, jitter, world size); otherwise None."""
-    best = None
+    import glob
     for rnd in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
-        path = os.path.join(ROOT, "profiles", rnd, "pmc_hbm_traffic.json")
-        try:
-            with open(path) as f:
-                d = json.load(f)
-            if d.get("workload_key") != workload_key:
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", rnd, "pmc_hbm_traffic*.json"))):
+            try:
+                with open(path) as f:
+                    d = json.load(f)
+                if d.get("workload_key") != workload_key:
+                    continue
+                k = next((v for n, v in d["kernels"].items() if n.split("<")[0].endswith("::" + kernel)), None)
+                if k is not None:
+                    return (k["hbm_bytes_per_launch_corrected"], os.path.relpath(path, ROOT), d.get("collected_at", ""))
+            except (OSError, KeyError, ValueError):
                 continue
-            k = next((v for n, v in d["kernels"].items() if n.split("<")[0].endswith("::" + kernel)), None)
-            if k is not None:
-                best = (k["hbm_bytes_per_launch_corrected"], os.path.relpath(path, ROOT), d.get("collected_at", ""))
-                break
-        except (OSError, KeyError, ValueError):
-            continue
-    return best
+    return None
 
 
 def plugin_legs(args, cfgd, points, weights, cams, dev, near, far):
@@ -426,7 +425,8 @@ def main():
         per_pair = FLOPS_PER_PAIR_KERNEL   # both modes run the factorised first layer
         achieved = pairs * per_pair / t_pairs / 1e12 if t_pairs > 0 else 0.0
         peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
-        kernel = "k_shade_pairs_bf16" if bf else "k_shade_pairs"
+        # (fp32, K that does not fill a DPP segment -- cfg[4]'s K = 12 --: the pair kernel on dense units)
+        kernel = "k_shade_pairs_bf16" if bf else ("k_shade_pairs_dense" if K >= 11 and K != 16 else "k_shade_pairs")
         executed = pairs * MFMA_FLOPS_PER_PAIR_BF16 / t_pairs / 1e12 if (bf and t_pairs > 0) else achieved
         alg_bytes = pairs * 8 + upoints * 1072 + samples * 1064
         key = workload_key.replace(f":{args.precision}:", f":{mode}:")

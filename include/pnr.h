@@ -178,6 +178,13 @@ int pnr_weights_destroy(pnr_weights_t *w);
 int pnr_weights_pack(pnr_weights_t *w, const float *const d_w[9], const float *const d_b[9],
                      const float *d_Rw2c, void *stream);
 
+/* The nine Linear layers changed (an optimiser step), points_Rw2c did not: re-packs the forms the given arithmetic mode
+ * reads (precision = PNR_PRECISION_FP32 / PNR_PRECISION_BF16X3, or -1 for both) in ONE kernel launch, without the host
+ * copy of Rw2c and without synchronising -- pnr_weights_pack synchronises the stream and takes about thirty launches,
+ * which a 3-ms training step would pay every step.  Needs one pnr_weights_pack before (layout, padding, Rw2c). */
+int pnr_weights_update(pnr_weights_t *w, const float *const d_w[9], const float *const d_b[9], int32_t precision,
+                       void *stream);
+
 /* ---- the drop-in op ----------------------------------------------------------------------------- */
 size_t pnr_query_workspace_bytes(int64_t R, int32_t D, int32_t SR, int32_t K);
 /* woord_query_grid_point_index with explicit ray positions d_raypos [R,D,3].

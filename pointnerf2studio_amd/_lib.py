@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "pnr_last_error", "pnr_version", "pnr_jitter_uniform",
     "pnr_scene_create", "pnr_scene_destroy", "pnr_scene_build", "pnr_scene_info", "pnr_points_pack",
     "pnr_scene_update", "pnr_scene_update_info", "pnr_render_probe", "pnr_points_pack_rows", "pnr_render_touched", "pnr_points_bind", "pnr_point_grads_clear",
-    "pnr_weights_create", "pnr_weights_destroy", "pnr_weights_pack",
+    "pnr_weights_create", "pnr_weights_destroy", "pnr_weights_pack", "pnr_weights_update",
     "pnr_query_workspace_bytes", "pnr_query_raypos",
     "pnr_render_workspace_bytes", "pnr_render_workspace_bytes_for", "pnr_render", "pnr_render_views",
     "pnr_render_camera", "pnr_render_camera_lists", "pnr_camera_rays", "pnr_pinhole_ray",
@@ -116,6 +116,7 @@ def load() -> C.CDLL:
     lib.pnr_weights_create.argtypes = [C.POINTER(vp)]
     lib.pnr_weights_destroy.argtypes = [vp]
     lib.pnr_weights_pack.argtypes = [vp, C.POINTER(vp * 9), C.POINTER(vp * 9), vp, vp]
+    lib.pnr_weights_update.argtypes = [vp, C.POINTER(vp * 9), C.POINTER(vp * 9), i32, vp]
     lib.pnr_query_workspace_bytes.restype = sz
     lib.pnr_query_workspace_bytes.argtypes = [i64, i32, i32, i32]
     lib.pnr_query_raypos.argtypes = [vp, vp, i64, i32, i32, i32, f32, vp, vp, vp, vp, vp, sz, vp]

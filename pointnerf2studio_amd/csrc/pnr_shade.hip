@@ -73,8 +73,8 @@ __device__ int feat16_of(int kind, int s, int h, int j, int n_in)
     return -1;
 }
 
-__global__ void k_pack_layer(const float *__restrict__ W, int n_out, int n_in, int kind, int ksp, int t0,
-                             float *__restrict__ dst)
+__device__ __forceinline__ void pack_layer_body(const float *__restrict__ W, int n_out, int n_in, int kind, int ksp,
+                                                int t0, float *__restrict__ dst)
 {
     // dst[((m*KG + g)*64 + lane)*4 + q] = W[32m + (lane&31)][feat(t0 + 4g+q, lane>>5)]
     const int kg = ksp / 4, mt = n_out / 32;
@@ -88,8 +88,14 @@ __global__ void k_pack_layer(const float *__restrict__ W, int n_out, int n_in, i
     }
 }
 
-__global__ void k_pack_layer_bf16(const float *__restrict__ W, int n_out, int n_in, int kind, int ks, int kx, int s0,
-                                  unsigned short *__restrict__ dst)
+__global__ void k_pack_layer(const float *__restrict__ W, int n_out, int n_in, int kind, int ksp, int t0,
+                             float *__restrict__ dst)
+{
+    pack_layer_body(W, n_out, n_in, kind, ksp, t0, dst);
+}
+
+__device__ __forceinline__ void pack_layer_bf16_body(const float *__restrict__ W, int n_out, int n_in, int kind, int ks,
+                                                     int kx, int s0, unsigned short *__restrict__ dst)
 {
     // dst[(((m*KS + s)*2 + plane)*64 + lane)*8 + j] = {hi, lo}(W[32 rb + (lane&31)][feat16(s0 + s % kx, lane>>5, j)])
     // a ring tile m holds ks / kx row blocks rb = m * (ks / kx) + s / kx of kx k-steps each (kx == ks: one)
@@ -108,6 +114,12 @@ __global__ void k_pack_layer_bf16(const float *__restrict__ W, int n_out, int n_
         dst[base] = __builtin_bit_cast(unsigned short, hb);
         dst[base + 64 * 8] = __builtin_bit_cast(unsigned short, lb);
     }
+}
+
+__global__ void k_pack_layer_bf16(const float *__restrict__ W, int n_out, int n_in, int kind, int ks, int kx, int s0,
+                                  unsigned short *__restrict__ dst)
+{
+    pack_layer_bf16_body(W, n_out, n_in, kind, ks, kx, s0, dst);
 }
 
 // density head weights in accumulator order: dst[(t * 2 + h) * 16 + r] = w4[32t + 8(r>>2) + 4h + (r&3)]
@@ -130,6 +142,47 @@ __global__ void k_copy(const float *__restrict__ src, int n, float *__restrict__
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[i];
+}
+
+// Every packed form of pnr_weights_update in ONE launch: blockIdx.y selects the job (a training loop re-packs after
+// every optimiser step; thirty small launches cost more than the packing).
+enum { JOB_LAYER = 0, JOB_LAYER16 = 1, JOB_COPY = 2, JOB_HEAD_ACC = 3, JOB_COLOR_ACC = 4 };
+struct PackJob {
+    int type, n_out, n_in, kind, a, b, c;
+    const float *src;
+    void *dst;
+};
+constexpr int MAX_PACK_JOBS = 40;
+struct PackJobs {
+    PackJob j[MAX_PACK_JOBS];
+};
+__global__ void __launch_bounds__(256) k_pack_jobs(PackJobs jobs)
+{
+    const PackJob &J = jobs.j[blockIdx.y];
+    switch (J.type) {
+    case JOB_LAYER:
+        pack_layer_body(J.src, J.n_out, J.n_in, J.kind, J.a, J.b, (float *)J.dst);
+        break;
+    case JOB_LAYER16:
+        pack_layer_bf16_body(J.src, J.n_out, J.n_in, J.kind, J.a, J.b, J.c, (unsigned short *)J.dst);
+        break;
+    case JOB_COPY:
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < J.a; i += gridDim.x * blockDim.x)
+            ((float *)J.dst)[i] = J.src[i];
+        break;
+    case JOB_HEAD_ACC:
+        if (blockIdx.x == 0) {
+            const int i = threadIdx.x, t = i >> 5, h = (i >> 4) & 1, r = i & 15;
+            ((float *)J.dst)[i] = J.src[32 * t + 8 * (r >> 2) + 4 * h + (r & 3)];
+        }
+        break;
+    default:
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 384; i += gridDim.x * blockDim.x) {
+            const int c = i >> 7, t = (i >> 5) & 3, h = (i >> 4) & 1, r = i & 15;
+            ((float *)J.dst)[i] = J.src[c * 128 + 32 * t + 8 * (r >> 2) + 4 * h + (r & 3)];
+        }
+        break;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -516,5 +569,54 @@ extern "C" int pnr_weights_pack(pnr_weights_t *w, const float *const d_w[9], con
     PNR_HIP_CHECK(hipMemcpyAsync(w->Rw2c, d_Rw2c, 9 * sizeof(float), hipMemcpyDeviceToHost, stream));
     PNR_HIP_CHECK(hipStreamSynchronize(stream));
     w->packed = true;
+    return PNR_OK;
+}
+
+extern "C" int pnr_weights_update(pnr_weights_t *w, const float *const d_w[9], const float *const d_b[9],
+                                  int32_t precision, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    PNR_REQUIRE(w && d_w && d_b, "pnr_weights_update: null argument");
+    for (int i = 0; i < 9; ++i) PNR_REQUIRE(d_w[i] && d_b[i], "pnr_weights_update: tensor %d is null", i);
+    if (!w->packed) {
+        set_error("pnr_weights_update: pack once with pnr_weights_pack (layout, padding and Rw2c come from there)");
+        return PNR_ERR_STATE;
+    }
+    PNR_REQUIRE(precision == PNR_PRECISION_FP32 || precision == PNR_PRECISION_BF16X3 || precision < 0,
+                "pnr_weights_update: unknown precision %d", precision);
+    const bool f32 = precision != PNR_PRECISION_BF16X3, b16 = precision != PNR_PRECISION_FP32;
+    static const int n_out[9] = {256, 256, 256, 256, 1, 128, 128, 128, 3};
+    static const int n_in[9] = {284, 256, 263, 256, 256, 280, 128, 128, 128};
+    static const int ksp[9] = {144, 128, 132, 128, 0, 140, 64, 64, 0};
+    static const int ks16[9] = {18, 16, 17, 16, 0, 18, 8, 8, 0};
+    static const int kind[9] = {L_BASE0, L_HIDDEN, L_HEAD0, L_HIDDEN, -1, L_COLOR0, L_HIDDEN, L_HIDDEN, -1};
+    PackJobs jobs{};
+    int n = 0;
+    auto add = [&](int type, const float *src, void *dst, int no, int ni, int kd, int a, int b, int c) {
+        jobs.j[n++] = PackJob{type, no, ni, kd, a, b, c, src, dst};
+    };
+    for (int i = 0; i < 9; ++i) {
+        if (ksp[i]) {
+            if (f32 && i != 0) add(JOB_LAYER, d_w[i], w->buf + w->w_off[i], n_out[i], n_in[i], kind[i], ksp[i], 0, 0);
+            if (b16 && i != 0)
+                add(JOB_LAYER16, d_w[i], w->buf + w->w16_off[i], n_out[i], n_in[i], kind[i], ks16[i], ks16[i], 0);
+        } else {
+            add(JOB_COPY, d_w[i], w->buf + w->w_off[i], 0, 0, 0, n_out[i] * n_in[i], 0, 0);
+        }
+        add(JOB_COPY, d_b[i], w->buf + w->b_off[i], 0, 0, 0, n_out[i], 0, 0);
+    }
+    // mlp_base layer 0 is only read in its two halves (point-only / pair inputs): both modes factorise it
+    if (f32) {
+        add(JOB_LAYER, d_w[0], w->buf + w->w32a_off, 256, 284, L_BASE0, 112, 0, 0);
+        add(JOB_LAYER, d_w[0], w->buf + w->w32b_off, 256, 284, L_BASE0, 32, 112, 0);
+    }
+    if (b16) {
+        add(JOB_LAYER16, d_w[0], w->buf + w->w16a_off, 256, 284, L_BASE0, 14, 14, 0);
+        add(JOB_LAYER16, d_w[0], w->buf + w->w16b_off, 256, 284, L_BASE0, 8, 4, 14);
+    }
+    add(JOB_HEAD_ACC, d_w[4], w->buf + w->w4acc_off, 0, 0, 0, 0, 0, 0);
+    add(JOB_COLOR_ACC, d_w[8], w->buf + w->w8acc_off, 0, 0, 0, 0, 0, 0);
+    hipLaunchKernelGGL(k_pack_jobs, dim3(48, (unsigned)n), dim3(256), 0, stream, jobs);
+    PNR_HIP_CHECK(hipGetLastError());
     return PNR_OK;
 }

@@ -313,12 +313,26 @@ class PointNerf(Model):
         workspace.  live: the parameter tensors are bound to the scene (training steps, see NeuralPoints.fused_scene)."""
         scene = self.neural_points.fused_scene(live=live)
         sd = self._mlp_state()
-        key = tuple((t.data_ptr(), t._version) for t in sd.values()) + (self.neural_points.points_Rw2c._version,)
+        rkey = (self.neural_points.points_Rw2c.data_ptr(), self.neural_points.points_Rw2c._version)
+        key = tuple((t.data_ptr(), t._version) for t in sd.values()) + rkey
         if self._weights is None or key != self._weights_key:
+            dev = self.neural_points.points_xyz.device
             if self._weights is None:
                 self._weights = WeightsHIP()
-            self._weights.pack(sd, self.neural_points.points_Rw2c.detach(), self.neural_points.points_xyz.device)
+                self._weights_rkey = None
+            if self._weights_rkey == rkey and live:
+                # an optimiser step moved the layers, Rw2c is what it was: one launch, no synchronisation, only the
+                # forms this arithmetic mode reads (the other mode's are rebuilt by the next full pack)
+                self._weights.update(sd, dev, getattr(self.config, "hip_mlp_mode", "fp32"))
+                self._weights_partial = True
+            else:
+                self._weights.pack(sd, self.neural_points.points_Rw2c.detach(), dev)
+                self._weights_rkey, self._weights_partial = rkey, False
             self._weights_key = key
+        elif getattr(self, "_weights_partial", False) and not live:
+            # (eval after training steps: bring every form up to date once)
+            self._weights.pack(sd, self.neural_points.points_Rw2c.detach(), self.neural_points.points_xyz.device)
+            self._weights_partial = False
         c = self.config
         rnd = self._renderers.get(clamp)
         if rnd is None or rnd.scene is not scene:

@@ -303,6 +303,22 @@ class WeightsHIP:
         except Exception:
             pass
 
+    def update(self, state: Dict[str, torch.Tensor], device, precision: Optional[str] = None) -> None:
+        """pnr_weights_update: the layers changed, Rw2c did not -- one launch, no synchronisation (a training loop after
+        every optimiser step).  precision: re-pack only the forms that mode reads (None = both)."""
+        ws, bs = [], []
+        for name, shape in zip(MLP_TENSOR_ORDER, MLP_SHAPES):
+            ws.append(_f32c(state[name + ".weight"], device))
+            bs.append(_f32c(state[name + ".bias"], device))
+            if tuple(ws[-1].shape) != shape:
+                raise ValueError(f"{name}: expected weight {shape}, got {tuple(ws[-1].shape)}")
+        wp = (C.c_void_p * 9)(*[w.data_ptr() for w in ws])
+        bp = (C.c_void_p * 9)(*[b.data_ptr() for b in bs])
+        with torch.cuda.device(device):
+            _lib.check(self.lib.pnr_weights_update(self.handle, C.byref(wp), C.byref(bp),
+                                                   -1 if precision is None else _lib.PRECISION[precision],
+                                                   _stream_ptr(device)), "pnr_weights_update")
+
     def pack(self, state: Dict[str, torch.Tensor], Rw2c: torch.Tensor, device) -> None:
         """state: '<module>.weight' / '<module>.bias' for the nine Linear layers of MLP_TENSOR_ORDER
         (nerfstudio MLP / FieldHead naming, studio_model.py:193-221)."""

@@ -2,11 +2,11 @@
 # Runs ON THE GPU BOX (gpurun -- 'bash tools/collect_profiles.sh [what]'): the bench line, the rocprofv3 kernel trace of
 # the same command, the HBM-traffic PMC passes and the MFMA-busy PMC pass, into gpurun_out/prof_rNN/.
 # tools/summarize_profiles.py then condenses them into profiles/<round>/ (run on the host).
-#   what = all (default) | bench | trace | pmc
+#   what = all (default) | bench | trace | pmc | cfg4 (trace + PMC passes of the K = 12 configuration, fp32)
 set -e -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 WHAT=${1:-all}
-O=gpurun_out/prof_r02
+O=gpurun_out/prof_r03
 mkdir -p $O
 if [ "$WHAT" = all ] || [ "$WHAT" = bench ]; then
   echo "[bench] default flags (fp32 headline, all side legs, CPU baseline)"
@@ -35,5 +35,24 @@ if [ "$WHAT" = all ] || [ "$WHAT" = pmc ]; then
     rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/pmc_mfma_$mode -- python bench.py \
         --steps 3 --warmup 1 --cpu-rays-side 0 --no-other-mode --precision $mode > $O/bench_pmc_mfma_$mode.json 2> $O/pmc_mfma_$mode.err
   done
+fi
+if [ "$WHAT" = all ] || [ "$WHAT" = cfg4 ]; then
+  C="--config cfg4_scannet_20m --cpu-rays-side 0 --no-other-mode --precision fp32"
+  echo "[cfg4] bench line"
+  python bench.py $C --steps 4 --warmup 1 > $O/bench_cfg4.json 2> $O/bench_cfg4.err
+  echo "[cfg4] kernel trace"
+  rm -rf $O/trace_cfg4
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_cfg4 -- python bench.py $C --steps 3 --warmup 1 \
+      > $O/bench_under_rocprof_cfg4.json 2> $O/trace_cfg4.err
+  for counter in FETCH_SIZE WRITE_SIZE; do
+    echo "[cfg4] pmc $counter"
+    rm -rf $O/pmc_${counter}_cfg4
+    rocprofv3 --pmc $counter --output-format csv -d $O/pmc_${counter}_cfg4 -- python bench.py $C --steps 2 --warmup 1 \
+        > $O/bench_pmc_${counter}_cfg4.json 2> $O/pmc_${counter}_cfg4.err
+  done
+  echo "[cfg4] pmc MFMA busy"
+  rm -rf $O/pmc_mfma_cfg4
+  rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/pmc_mfma_cfg4 -- python bench.py $C \
+      --steps 2 --warmup 1 > $O/bench_pmc_mfma_cfg4.json 2> $O/pmc_mfma_cfg4.err
 fi
 echo done; ls $O

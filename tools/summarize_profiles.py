@@ -1,5 +1,5 @@
 """Host side of tools/collect_profiles.sh: condenses gpurun_out/prof_rNN/ into the files kept under profiles/<round>/.
-Usage: python tools/summarize_profiles.py gpurun_out/prof_r02 profiles/r02 [git-sha]"""
+Usage: python tools/summarize_profiles.py gpurun_out/prof_r03 profiles/r03 [git-sha]"""
 import csv
 import glob
 import json
@@ -99,12 +99,67 @@ if keys:
             e["hbm_bytes_per_launch_corrected"] = (2 * f + w) * 1024
     json.dump(out, open(os.path.join(dst, "pmc_hbm_traffic.json"), "w"), indent=1)
 
+# ---- the K = 12 configuration (cfg4_scannet_20m, fp32): bench line, kernel stats, traffic, MFMA busy -------------------
+if os.path.exists(os.path.join(src, "bench_cfg4.json")):
+    shutil.copy(os.path.join(src, "bench_cfg4.json"), os.path.join(dst, "bench_cfg4_n1_fp32.json"))
+stats4 = one("trace_cfg4/**/*kernel_stats.csv")
+if stats4:
+    rows = list(csv.DictReader(open(stats4)))
+    keep = [r for r in rows if "pnr::" in r["Name"]] + [r for r in rows if "pnr::" not in r["Name"]][:4]
+    with open(os.path.join(dst, "kernel_stats_bench_cfg4_fp32.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=rows[0].keys())
+        w.writeheader()
+        w.writerows(keep)
+    trace = list(csv.DictReader(open(one("trace_cfg4/**/*kernel_trace.csv"))))
+    disp = defaultdict(list)
+    for r in trace:
+        n = r["Kernel_Name"]
+        if "k_shade_pairs" in n or "k_point_part" in n or "k_shade_color" in n or "k_pair_weights" in n:
+            disp[n.split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    b = bench_line(os.path.join(src, "bench_under_rocprof_cfg4.json"))
+    json.dump({"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --config cfg4_scannet_20m "
+                          "--steps 3 --warmup 1 --cpu-rays-side 0 --no-other-mode --precision fp32",
+               "collected_at": sha, "workload_key": b["config"]["workload_key"],
+               "hip_event_avg_launch_ms_of_the_same_run": b["roofline"]["avg_launch_ms"],
+               "timed_dispatches": 3, "dispatch_ms": dict(disp)},
+              open(os.path.join(dst, "dispatch_ms_bench_cfg4_fp32.json"), "w"), indent=1)
+p4 = os.path.join(src, "bench_pmc_FETCH_SIZE_cfg4.json")
+if os.path.exists(p4):
+    b = bench_line(p4)
+    out4 = {"command": "rocprofv3 --pmc <COUNTER> --output-format csv -- python bench.py --config cfg4_scannet_20m --steps 2 "
+                       "--warmup 1 --cpu-rays-side 0 --no-other-mode --precision fp32 (one pass per counter)",
+            "collected_at": sha, "workload_key": b["config"]["workload_key"],
+            "units": "FETCH_SIZE / WRITE_SIZE are reported in KiB; bytes = value * 1024",
+            "gfx950_correction": "hbm_read_bytes = 2 * FETCH_SIZE * 1024 (MI355X_MICROARCH.md, HBM section)",
+            "counters_per_launch": b["counters_per_launch"], "kernels": {}}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        f = one(f"pmc_{counter}_cfg4/**/*counter_collection.csv")
+        if not f:
+            continue
+        acc = defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            if r["Counter_Name"] == counter and "pnr::" in name:
+                acc[name].append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            e = out4["kernels"].setdefault(k, {})
+            e[f"{counter}_KiB_timed_launches"] = v[-2:]
+    for k, e in out4["kernels"].items():
+        if "FETCH_SIZE_KiB_timed_launches" in e and "WRITE_SIZE_KiB_timed_launches" in e:
+            f_ = sum(e["FETCH_SIZE_KiB_timed_launches"]) / len(e["FETCH_SIZE_KiB_timed_launches"])
+            w_ = sum(e["WRITE_SIZE_KiB_timed_launches"]) / len(e["WRITE_SIZE_KiB_timed_launches"])
+            e["hbm_bytes_per_launch_corrected"] = (2 * f_ + w_) * 1024
+    c = b["counters_per_launch"]
+    out4["survey_8d_bytes_per_launch"] = {"M_x_164": c["pairs_valid"] * 164,
+                                          "formula": "pairs_valid * 164 B (xyz 12 + emb 128 + color 12 + dir 12)"}
+    json.dump(out4, open(os.path.join(dst, "pmc_hbm_traffic_cfg4.json"), "w"), indent=1)
+
 # MFMA busy / effective clock
 busy = {"command": "rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -- python bench.py --steps 3 "
                    "--warmup 1 --cpu-rays-side 0 --no-other-mode --precision <MODE>", "collected_at": sha,
         "definitions": {"clock_ghz": "GRBM_GUI_ACTIVE / 8 XCDs / dispatch ns",
                         "mfma_busy": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 4 SIMDs * 256 CUs)"}, "kernels": {}}
-for mode in MODES:
+for mode in MODES + ("cfg4",):
     f = one(f"pmc_mfma_{mode}/**/*counter_collection.csv")
     if not f:
         continue
@@ -119,9 +174,9 @@ for mode in MODES:
     for (d, n), v in sorted(rows.items()):
         per[n].append(v)
     for n, vs in per.items():
-        vs = vs[-3:]   # the timed launches
+        vs = vs[-(2 if mode == "cfg4" else 3):]   # the timed launches
         gui = [v.get("GRBM_GUI_ACTIVE", 0) / 8 for v in vs]
-        busy["kernels"][mode + " " + n] = {
+        busy["kernels"][("fp32 cfg4_scannet_20m" if mode == "cfg4" else mode) + " " + n] = {
             "launches": len(vs), "ms": [round(v["ns"] / 1e6, 3) for v in vs],
             "clock_ghz": [round(g / v["ns"], 3) for g, v in zip(gui, vs)],
             "mfma_busy": [round(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (g * 1024 + 1e-9), 3) for g, v in zip(gui, vs)]}
