@@ -513,34 +513,46 @@ def main():
         for n_rays in (4096, 65536):
             pick = torch.randperm(full.shape[0], generator=gen)[:n_rays].to(dev)
             dirs_t = full.index_select(0, pick).contiguous()
-            rnd_t = RendererHIP(scene, wh, SR=SR, K=K, D=400, radius_limit=4 * max(VSIZE[0], VSIZE[1]),
-                                vsize_z=VSIZE[2], precision=args.precision, eval_clamp=False, jitter=0.3, seed=1)
             g_rgb = torch.randn(n_rays, 3, generator=gen).to(dev)
-            fw, bw = [], []
-            for it in range(5):
-                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-                ev[0].record()
-                o = rnd_t.render(dirs_t, cams[0][0], cams[0][1], near, far)
-                ev[1].record()
-                rnd_t.backward(g_rgb, w_dev, cfgd["N"])
-                ev[2].record()
-                torch.cuda.synchronize()
-                if it >= 2:
-                    fw.append(ev[0].elapsed_time(ev[1]))
-                    bw.append(ev[1].elapsed_time(ev[2]))
-            c = o["counters"]
-            bwd_flops = 3 * (c["pairs_valid"] * FLOPS_PER_PAIR + c["samples_valid"] * FLOPS_PER_SAMPLE)
-            f_ms, b_ms = sorted(fw)[1], sorted(bw)[1]
-            train.append({"rays": n_rays, "forward_ms": f_ms, "backward_ms": b_ms,
-                          "rays_per_sec": n_rays / ((f_ms + b_ms) * 1e-3), "pairs_valid": c["pairs_valid"],
+            entry = {"rays": n_rays, "mode": args.precision}
+            # twice: the backward recomputing the MLP chain itself (a render that knows nothing of it), and the render
+            # writing the backward's activation tape as it shades (pnr_render_opts_t.d_tape: what the plugin's training
+            # path does) -- the step is what counts; the backward's FLOPs are 3 x the forward's in the first form
+            # (recompute + data + weight gradients) and 2 x in the second (the recompute moved into the render)
+            for tape in (False, True):
+                rnd_t = RendererHIP(scene, wh, SR=SR, K=K, D=400, radius_limit=4 * max(VSIZE[0], VSIZE[1]),
+                                    vsize_z=VSIZE[2], precision=args.precision, eval_clamp=False, jitter=0.3, seed=1,
+                                    tape=tape)
+                fw, bw = [], []
+                for it in range(5):
+                    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                    ev[0].record()
+                    o = rnd_t.render(dirs_t, cams[0][0], cams[0][1], near, far)
+                    ev[1].record()
+                    rnd_t.backward(g_rgb, w_dev, cfgd["N"])
+                    ev[2].record()
+                    torch.cuda.synchronize()
+                    if it >= 2:
+                        fw.append(ev[0].elapsed_time(ev[1]))
+                        bw.append(ev[1].elapsed_time(ev[2]))
+                c = o["counters"]
+                fwd_flops = c["pairs_valid"] * FLOPS_PER_PAIR + c["samples_valid"] * FLOPS_PER_SAMPLE
+                f_ms, b_ms = sorted(fw)[1], sorted(bw)[1]
+                tag = "_taped" if tape else ""
+                entry.update({"forward_ms" + tag: f_ms, "backward_ms" + tag: b_ms, "step_ms" + tag: f_ms + b_ms,
+                              "backward_tflops" + tag: (2 if tape else 3) * fwd_flops / (b_ms * 1e-3) / 1e12,
+                              "step_tflops" + tag: 3 * fwd_flops / ((f_ms + b_ms) * 1e-3) / 1e12})
+                del rnd_t
+            entry.update({"rays_per_sec": n_rays / (entry["step_ms_taped"] * 1e-3), "pairs_valid": c["pairs_valid"],
                           "samples_valid": c["samples_valid"],
-                          "backward_tflops": bwd_flops / (b_ms * 1e-3) / 1e12,
-                          "mode": args.precision,
-                          "note": "backward = recompute of the MLPs with a row-major tape + data and weight gradients "
-                                  "(3 x the forward FLOPs) as GEMMs: fp32 mode v_mfma_f32_32x32x2_f32 throughout (peak "
-                                  "157.3); bf16x3 mode: all three GEMM shapes on bf16 hi/lo splits; time includes zero-filling the "
-                                  "dense [N,32] gradient"})
-            del rnd_t
+                          "note": "render + pnr_render_backward through the C ABI, dense [N, .] point gradients zero-filled "
+                                  "by the caller each step.  Untagged: the backward recomputes the MLPs into a row-major "
+                                  "tape (its FLOPs: 3 x the forward's, reference arithmetic 542,720 per pair + 137,984 per "
+                                  "sample).  _taped: the render writes the tape (the backward's FLOPs: 2 x).  step_tflops = "
+                                  "3 x the forward's FLOPs (forward + data + weight gradients: what the reference's "
+                                  "autograd step performs; a recompute is this design's own and not counted) / step time; "
+                                  "fp32 peak 157.3"})
+            train.append(entry)
 
     # the PLUGIN surface, for the record beside `value` (which times the C-ABI call): the same workload through
     # PointNerf.get_outputs_for_camera_ray_bundle -- the path `ns-eval` / the trainer's eval images take

@@ -92,6 +92,13 @@ typedef struct {
                               > 0: early ray termination -- samples are shaded front to back in chunks (3, 3, 6, 12,
                               rest of a ray's samples) and a ray whose transmittance has fallen below eps is not
                               shaded further; the skipped samples would change the pixel by less than eps.        */
+    void *d_tape;          /* NULL (default), or the TRAINING workspace (pnr_backward_workspace_bytes(cap_samples, K)
+                              bytes of device memory) of the pnr_render_backward call that will follow this render: the
+                              render then leaves the post-activation outputs of the four per-pair layers there as it
+                              computes them, and the backward -- given the same workspace and the same opts -- does not
+                              recompute them (four row GEMMs: 6 of its 21 ms at 65 536 rays).  fp32, K <= 10 or 16,
+                              early_stop_eps = 0; otherwise ignored (the backward recomputes, as without it).       */
+    size_t tape_bytes;     /* size of d_tape                                                                       */
 } pnr_render_opts_t;
 
 /* MLP arithmetic.  FP32: v_mfma_f32_32x32x2_f32, every product and sum in fp32.  BF16X3: every fp32 product is

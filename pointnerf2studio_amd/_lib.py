@@ -57,7 +57,7 @@ class ViewC(C.Structure):
 class RenderOpts(C.Structure):
     _fields_ = [("SR", C.c_int32), ("K", C.c_int32), ("D", C.c_int32), ("radius_limit", C.c_float),
                 ("vsize_z", C.c_float), ("eval_clamp", C.c_int32), ("bg", C.c_float * 3), ("precision", C.c_int32), ("jitter", C.c_float), ("seed", C.c_uint32),
-                ("early_stop_eps", C.c_float)]
+                ("early_stop_eps", C.c_float), ("d_tape", C.c_void_p), ("tape_bytes", C.c_size_t)]
 
 
 PRECISION = {"fp32": 0, "bf16x3": 1}

@@ -358,6 +358,15 @@ int launch_knn(const GridView &g, int K, float radius_limit, RenderWs &ws, int64
 int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr, const float *d_dirs,
                  const pnr_render_opts_t &opts, int64_t R, RenderWs &ws, int64_t cap, int64_t *d_counters,
                  hipStream_t stream, hipEvent_t ev_points, hipEvent_t ev_between);
+// pnr_train.hip: the four activation tapes (H1, H2, G1, G2) inside a training workspace of `bytes` bytes carved for
+// (cap, K); false if the workspace is too small.  tape_supported: the configurations in which a render given
+// opts.d_tape fills them -- pnr_render* and pnr_render_backward must agree on it.
+bool train_tape_ptrs(void *d_train_workspace, size_t bytes, int64_t cap, int K, float *tape[4], size_t tape_bytes[4]);
+inline bool tape_supported(const pnr_render_opts_t &o)
+{
+    return o.d_tape != nullptr && o.precision == PNR_PRECISION_FP32 && o.early_stop_eps == 0.f &&
+           (o.K <= 10 || o.K == 16);   // the K served by k_shade_pairs<8 / 16> (dense units and K > 16 recompute)
+}
 int launch_refresh_rows(const pnr_scene *scene, const int *pt_list, const int *n_unique, int64_t u_cap,
                         hipStream_t stream);
 int launch_composite(const CamRef &cr, const pnr_render_opts_t &opts, int64_t R, RenderWs &ws, float *d_rgb,

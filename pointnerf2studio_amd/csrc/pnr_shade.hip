@@ -374,6 +374,20 @@ int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr,
     P.pt_list = ws.pt_list;
     P.pt_table = reinterpret_cast<float4 *>(ws.pt_table);
     P.u_cap = (int)ws.u_cap;
+    // a training render (opts.d_tape: the training workspace of the pnr_render_backward that follows) writes the
+    // backward's activation tape as it shades; fp32, K <= 16 on the DPP kernels, no early termination
+    bool taped = false;
+    if (tape_supported(opts) && !early) {
+        float *t4[4];
+        size_t b4[4];
+        if (train_tape_ptrs(opts.d_tape, opts.tape_bytes, cap, K, t4, b4)) {
+            for (int l = 0; l < 4; ++l) {
+                P.tape[l] = t4[l];
+                P.tape_bytes[l] = b4[l];
+            }
+            taped = true;
+        }
+    }
     int dev = 0, cus = 256;
     PNR_HIP_CHECK(hipGetDevice(&dev));
     PNR_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -426,7 +440,8 @@ int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr,
     auto launch_pairs = [&]() {
         if (bf)
             launch_pairs_bf16(seg, dim3(grid), stream, P);
-        else if (su) {
+        else if (taped && !su && launch_pairs_fp32_tape(seg, dim3(grid), stream, P)) {
+        } else if (su) {
             hipLaunchKernelGGL(k_pair_weights, dim3((unsigned)std::min<int64_t>((cap + 255) / 256, 256 * 16)), dim3(256), 0,
                                stream, ws.n_sel, P.i_v0, P.i_v1, P.vs_list, ws.smp_pidx, ws.smp_loc, P.point_rows, K,
                                ws.smp_wgt);

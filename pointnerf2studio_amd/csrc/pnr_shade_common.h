@@ -101,6 +101,10 @@ struct ShadeParams {
     const int *pt_list;     // [U] rows -> point index
     float4 *pt_table;       // [u_cap, 8 row blocks, 2 lane halves, 4] float4
     int u_cap;
+    // training renders (k_shade_pairs<SEG, true>): the backward's activation tapes H1 [rows,256], H2 [rows,264],
+    // G1, G2 [rows,256] and their sizes in bytes
+    float *tape[4];
+    size_t tape_bytes[4];
 };
 
 __device__ __forceinline__ float4 load_w(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff)
@@ -680,6 +684,7 @@ __device__ __forceinline__ void color_head_lds(const float (&b8)[3], const u32x4
 // seg = lanes per sample segment (8, 16, or 0 for exactly K)
 void launch_point_part_fp32(dim3 grid, hipStream_t stream, const ShadeParams &P);
 void launch_pairs_fp32(int seg, dim3 grid, hipStream_t stream, const ShadeParams &P);
+bool launch_pairs_fp32_tape(int seg, dim3 grid, hipStream_t stream, const ShadeParams &P);   // false: no such kernel
 // dense units (any K): su consecutive samples fill tu 32-row tiles of a wave, see k_shade_pairs_dense
 void launch_pairs_fp32_dense(int su, int tu, dim3 grid, hipStream_t stream, const ShadeParams &P);
 void launch_color_fp32(dim3 grid, hipStream_t stream, const ShadeParams &P);

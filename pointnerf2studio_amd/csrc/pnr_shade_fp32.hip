@@ -57,6 +57,7 @@ constexpr int PFS = PNR_PFS;
 #endif
 constexpr int FPM = PNR_FPM;
 static_assert(FPM % 2 == 0 && 16 % FPM == 0, "");
+static_assert(FPM == 16 && PNR_SINK_PER == 16, "the TAPE mode of k_shade_pairs collects an output tile's 16 values in one block");
 constexpr int NG_L1 = 8 * (32 / 4), NG_L2 = 8 * (128 / 4), NG_L3 = 8 * (132 / 4), NG_L4 = 8 * (128 / 4);
 constexpr int NG_TILE = NG_L1 + NG_L2 + NG_L3 + NG_L4;   // 840
 static_assert(NG_TILE % PFS == 0, "the window slot of a group must not depend on the tile");
@@ -144,7 +145,37 @@ __device__ __forceinline__ float to_a(float v)
     return v;
 }
 
-template <int SEG>
+// off: a constant once the caller is unrolled and inlined (an immediate of the instruction)
+__device__ __forceinline__ void lds_add(unsigned addr, float v, int off)
+{
+    asm volatile("ds_add_f32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(off));
+}
+__device__ __forceinline__ void lds_write4(unsigned addr, f32x4 v, int off)
+{
+    asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(off));
+}
+__device__ __forceinline__ f32x4 lds_read4(unsigned addr, int off)
+{
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(off));
+    return v;
+}
+__device__ __forceinline__ void lds_wait()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// TAPE (training renders, ShadeParams.tape_*): the post-activation outputs of the four layers -- H1, H2, G1, G2 of
+// pnr_render_backward's tape, row (valid sample v) * K + slot, row-major -- leave the kernel as it computes them, so
+// that the backward does not recompute the MLP chain with four row GEMMs (6 of its 21 ms at 65 536 rays).  The 16
+// values a lane holds of an output tile are features 32 m + 8 q + 4 h + i of ITS row: written as they are they would be
+// 16-byte pieces 1 KiB apart.  Each output tile therefore passes through a 4.5-KiB wave-private LDS block (32 rows x
+// 32 features, rows 144 B apart: conflict-free), written in the activation gap of the tile and read back transposed in
+// the next gap -- 8 lanes per row, 128 contiguous bytes -- so every store instruction writes whole 128-byte lines of
+// 8 rows.  Two blocks alternate.  The LDS latency of the read-back is exposed once per gap (~2 % of a tile).
+constexpr int TAPE_ROW_B = 144, TAPE_BLK_B = 32 * TAPE_ROW_B, TAPE_WAVE_B = 2 * TAPE_BLK_B;
+
+template <int SEG, bool TAPE = false>
 __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
 {
     const int lane = threadIdx.x & 63;
@@ -164,6 +195,52 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
     const float *w4t = P.wbuf + P.w4acc_off;   // density head in accumulator order: [(tile * 2 + h) * 16 + r]
     const float b4 = P.wbuf[P.b_off[4]];
     const int K = P.K;
+
+    // ---- TAPE: staging blocks, the four tapes, the rows this lane stores ------------------------------------------
+    extern __shared__ float tape_lds[];
+    const unsigned tblk = TAPE ? (unsigned)(uintptr_t)tape_lds + (unsigned)(wave * TAPE_WAVE_B) : 0u;
+    const unsigned t_wr = tblk + (unsigned)((lane & 31) * TAPE_ROW_B + 16 * h);            // + block + 32 q
+    const unsigned t_rd = tblk + (unsigned)((lane >> 3) * TAPE_ROW_B + (lane & 7) * 16);   // + block + 8 i rows
+    __amdgpu_buffer_rsrc_t trsrc[4];
+    if (TAPE) {
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+            trsrc[l] = __builtin_amdgcn_make_buffer_rsrc(P.tape[l], 0, (int)min(P.tape_bytes[l], (size_t)0xFFFFFFF0u),
+                                                         0x00020000);
+    }
+    unsigned tg[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // row offsets (in rows) of rows 8 i + l / 8
+    // block (layer pl, output tile pt), written one gap earlier, goes out: 8 lanes per row, whole 128-byte lines
+    auto tape_flush = [&](int pl, int pt) {
+        const int ld = pl == 1 ? 264 : 256;   // H2 carries the seven extra head inputs behind its 256 columns
+        f32x4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = lds_read4(t_rd, (pt & 1) * TAPE_BLK_B + i * 8 * TAPE_ROW_B);
+        lds_wait();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x4 o;
+            o.x = __float_as_uint(v[i].x);
+            o.y = __float_as_uint(v[i].y);
+            o.z = __float_as_uint(v[i].z);
+            o.w = __float_as_uint(v[i].w);
+            // row tg[i] (0xFFFFFFFF: no such row -> beyond the descriptor's range, dropped), features 32 pt + 4 (l & 7)
+            const unsigned off = tg[i] == 0xFFFFFFFFu ? 0xFFFFFFF0u : tg[i] * (unsigned)(ld * 4) + 16u * (lane & 7);
+            __builtin_amdgcn_raw_buffer_store_b128(o, trsrc[pl], (int)off, 128 * pt, 0);
+        }
+    };
+    // the 16 activations of output tile `tile` of layer `layer` (0..3) into block tile & 1; the block before it in the
+    // sequence (layer 0 tile 0, ..., layer 3 tile 7) goes out first
+    auto tape_tile = [&](int layer, int tile, const float (&t)[16]) {
+        if (tile > 0)
+            tape_flush(layer, tile - 1);
+        else if (layer > 0)
+            tape_flush(layer - 1, 7);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = {t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
+            lds_write4(t_wr, v, (tile & 1) * TAPE_BLK_B + 32 * q);
+        }
+    };
 
     // the weight window of the first tile
     float4 wq[PFS];
@@ -193,6 +270,16 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
             const Camera cam = load_cam_wave(P.cr, cur.cid);   // scalar loads: no wait on the vector-load queue
             pair_inputs<SEG, true, false>(P, cur, cam, lane, xq, ctx);
         }
+        if (TAPE) {
+            // tape rows of the tile rows 8 i + l / 8 this lane stores: (valid sample) * K + slot
+            constexpr int L = SEG ? SEG : 32;
+            const int v_wave0 = V0 + tile * SPT + wave * (SPT / WAVES);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 8 * i + (lane >> 3), sl = r / L, slot = r - sl * L, v = v_wave0 + sl;
+                tg[i] = (slot < K && v < S_valid) ? (unsigned)((v - V0) * K + slot) : 0xFFFFFFFFu;
+            }
+        }
         fetch_a<SEG>(P, walk.at(n + 1), lane, wave, V0, S_valid, nxt);   // a tile past the end loads row 0: harmless
         f32x16 acc[8];
         float X[128], Y[132];
@@ -213,13 +300,17 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
             },
             [&](int m, int i) {
                 if (m > 0 && i < 16 / FPM) {
+                    float t16[16];
 #pragma unroll
                     for (int q = 0; q < FPM; q += 2) {
                         float u, v;
                         leaky2(acc[m - 1][FPM * i + q], acc[m - 1][FPM * i + q + 1], u, v);
                         X[16 * (m - 1) + FPM * i + q] = to_a(u);
                         X[16 * (m - 1) + FPM * i + q + 1] = to_a(v);
+                        t16[(FPM * i + q) & 15] = u;
+                        t16[(FPM * i + q + 1) & 15] = v;
                     }
+                    if (TAPE) tape_tile(0, m - 1, t16);
                 }
             });
         // ---- layer 2 ---------------------------------------------------------------------------------------------
@@ -230,6 +321,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
                 rsrc, voff, goff, wq, X, acc, [&](int m) { return bias_ini(b1, m, h); },
                 [&](int m, int i) {
                     if (i < 16 / FPM) {
+                        float t16[16];
 #pragma unroll
                         for (int q = 0; q < FPM; q += 2) {
                             const int r = FPM * i + q;
@@ -239,9 +331,14 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
                                 X[112 + r] = to_a(u);
                                 X[113 + r] = to_a(v);
                             } else {
-                                leaky2(acc[m - 1][r], acc[m - 1][r + 1], Y[16 * (m - 1) + r], Y[16 * (m - 1) + r + 1]);
+                                leaky2(acc[m - 1][r], acc[m - 1][r + 1], u, v);
+                                Y[16 * (m - 1) + r] = u;
+                                Y[16 * (m - 1) + r + 1] = v;
                             }
+                            t16[r & 15] = u;
+                            t16[(r + 1) & 15] = v;
                         }
+                        if (TAPE) tape_tile(m == 0 ? 0 : 1, m == 0 ? 7 : m - 1, t16);
                     }
                 });
         }
@@ -256,18 +353,24 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
                 rsrc, voff, goff, wq, Y, acc, [&](int m) { return bias_ini(b2, m, h); },
                 [&](int m, int i) {
                     if (i < 16 / FPM) {
+                        float t16[16];
 #pragma unroll
                         for (int q = 0; q < FPM; q += 2) {
                             const int r = FPM * i + q;
                             float u, v;
                             if (m == 0) {
-                                leaky2(last[r], last[r + 1], Y[112 + r], Y[113 + r]);
+                                leaky2(last[r], last[r + 1], u, v);
+                                Y[112 + r] = u;
+                                Y[113 + r] = v;
                             } else {
                                 leaky2(acc[m - 1][r], acc[m - 1][r + 1], u, v);
                                 X[16 * (m - 1) + r] = to_a(u);
                                 X[16 * (m - 1) + r + 1] = to_a(v);
                             }
+                            t16[r & 15] = u;
+                            t16[(r + 1) & 15] = v;
                         }
+                        if (TAPE) tape_tile(m == 0 ? 1 : 2, m == 0 ? 7 : m - 1, t16);
                     }
                 });
         }
@@ -334,8 +437,10 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
             }
         };
         float sv = 0.f;
+        float g2t[16];   // TAPE: the activated values of the output tile being sunk
         auto sink = [&](int t, int r, float a) {
             const float v = leaky(a);
+            if (TAPE) g2t[r] = v;
             const float4 w = hw[r >> 2];
             part += v * ((r & 3) == 0 ? w.x : (r & 3) == 1 ? w.y : (r & 3) == 2 ? w.z : w.w);
             if (SEG != 0) {
@@ -357,13 +462,17 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
                 rsrc, voff, goff, wq, X, acc, [&](int m) { return bias_ini(b3, m, h); },
                 [&](int m, int i) {
                     if (m == 0 && i < 16 / FPM) {
+                        float t16[16];
 #pragma unroll
                         for (int q = 0; q < FPM; q += 2) {
                             float u, v;
                             leaky2(last[FPM * i + q], last[FPM * i + q + 1], u, v);
                             X[112 + FPM * i + q] = to_a(u);
                             X[113 + FPM * i + q] = to_a(v);
+                            t16[(FPM * i + q) & 15] = u;
+                            t16[(FPM * i + q + 1) & 15] = v;
                         }
+                        if (TAPE) tape_tile(2, 7, t16);
                     }
                     if (m > 0 && i == 0) {
                         // the head weights of tile m - 1 become current, those of tile m are fetched
@@ -383,6 +492,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
                             const int r = (i / (8 * PNR_SINK_PER)) * PNR_SINK_PER + e;
                             sink(m - 1, r, acc[m - 1][r]);
                         }
+                        if (TAPE) tape_tile(3, m - 1, g2t);
                     }
 #endif
                 });
@@ -392,6 +502,10 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
         for (int q = 0; q < 4; ++q) hw[q] = hw_nx[q];
 #pragma unroll
         for (int r = 0; r < 16; ++r) sink(7, r, acc[7][r]);
+        if (TAPE) {
+            tape_tile(3, 7, g2t);
+            tape_flush(3, 7);
+        }
         if (SEG != 0) {
 #pragma unroll
             for (int e = 0; e < NS; ++e) {
@@ -439,26 +553,6 @@ constexpr int DENSE_SLOTS_B = DENSE_NS * 1024;
 constexpr int DENSE_SIG_B = 64;                  // density sums of the slots
 constexpr int DENSE_DUMMY_B = 1024 + 64;         // where predicated-off LDS writes go
 constexpr int DENSE_WAVE_B = DENSE_ROWBUF_B + DENSE_SLOTS_B + DENSE_SIG_B + DENSE_DUMMY_B;   // 38 528
-
-// off: a constant once the caller is unrolled and inlined (an immediate of the instruction)
-__device__ __forceinline__ void lds_add(unsigned addr, float v, int off)
-{
-    asm volatile("ds_add_f32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(off));
-}
-__device__ __forceinline__ void lds_write4(unsigned addr, f32x4 v, int off)
-{
-    asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(off));
-}
-__device__ __forceinline__ f32x4 lds_read4(unsigned addr, int off)
-{
-    f32x4 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(off));
-    return v;
-}
-__device__ __forceinline__ void lds_wait()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
 
 __global__ void __launch_bounds__(TPB, 1) k_shade_pairs_dense(ShadeParams P, int SU, int TU)
 {
@@ -1058,6 +1152,19 @@ __global__ void __launch_bounds__(TPB, 1) k_point_part_f32(ShadeParams P)
 void launch_point_part_fp32(dim3 grid, hipStream_t stream, const ShadeParams &P)
 {
     hipLaunchKernelGGL(k_point_part_f32, grid, dim3(TPB), 0, stream, P);
+}
+
+// the training render: the same kernel writing the backward's activation tape (ShadeParams.tape) as it goes
+bool launch_pairs_fp32_tape(int seg, dim3 grid, hipStream_t stream, const ShadeParams &P)
+{
+    const size_t lds = (size_t)WAVES * TAPE_WAVE_B;
+    if (seg == 8)
+        hipLaunchKernelGGL((k_shade_pairs<8, true>), grid, dim3(TPB), lds, stream, P);
+    else if (seg == 16)
+        hipLaunchKernelGGL((k_shade_pairs<16, true>), grid, dim3(TPB), lds, stream, P);
+    else
+        return false;
+    return true;
 }
 
 void launch_pairs_fp32(int seg, dim3 grid, hipStream_t stream, const ShadeParams &P)

@@ -857,6 +857,20 @@ static TrainWs carve_train_ws(void *base, int64_t cap, int K)
     return w;
 }
 
+bool train_tape_ptrs(void *d_train_workspace, size_t bytes, int64_t cap, int K, float *tape[4], size_t tape_bytes[4])
+{
+    if (!d_train_workspace || carve_train_ws(nullptr, cap, K).total > bytes) return false;
+    const TrainWs w = carve_train_ws(d_train_workspace, cap, K);
+    const size_t rows = (size_t)cap * K + TM;
+    tape[0] = w.H1;
+    tape[1] = w.H2;
+    tape[2] = w.G1;
+    tape[3] = w.G2;
+    tape_bytes[0] = tape_bytes[2] = tape_bytes[3] = rows * LD_H * 4;
+    tape_bytes[1] = rows * LD_H2 * 4;
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------
 // small kernels
 // ------------------------------------------------------------------------------------------------
@@ -1745,14 +1759,21 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
     }
 
     // ---- forward with tape -----------------------------------------------------------------------
+    // the render filled H1, H2, G1, G2 itself when it was given this workspace as opts->d_tape (k_shade_pairs<SEG, true>);
+    // the LeakyReLU masks of the data gradients are then read from the taped activations (no sign-bit words)
+    const bool taped = tape_supported(*opts) && opts->d_tape == d_train_workspace && opts->tape_bytes == train_workspace_bytes;
     if (bf)
         hipLaunchKernelGGL(k_train_rows<true>, eg, eb, 0, st, P, tw);
     else
         hipLaunchKernelGGL(k_train_rows<false>, eg, eb, 0, st, P, tw);
-    gemm_forward(st, bf, tw.X0, LD_X0, tw.Wp[0], 288, d_b[0], tw.H1, LD_H, 256, 288, n_rows, rows_max, tw.sgH1);
-    gemm_forward(st, bf, tw.H1, LD_H, tw.Wp[1], 256, d_b[1], tw.H2, LD_H2, 256, 256, n_rows, rows_max, tw.sgH2);
-    gemm_forward(st, bf, tw.H2, LD_H2, tw.Wp[2], 264, d_b[2], tw.G1, LD_H, 256, 264, n_rows, rows_max, tw.sgG1);
-    gemm_forward(st, bf, tw.G1, LD_H, tw.Wp[3], 256, d_b[3], tw.G2, LD_H, 256, 256, n_rows, rows_max);
+    if (!taped) {
+        gemm_forward(st, bf, tw.X0, LD_X0, tw.Wp[0], 288, d_b[0], tw.H1, LD_H, 256, 288, n_rows, rows_max, tw.sgH1);
+        gemm_forward(st, bf, tw.H1, LD_H, tw.Wp[1], 256, d_b[1], tw.H2, LD_H2, 256, 256, n_rows, rows_max, tw.sgH2);
+        gemm_forward(st, bf, tw.H2, LD_H2, tw.Wp[2], 264, d_b[2], tw.G1, LD_H, 256, 264, n_rows, rows_max, tw.sgG1);
+        gemm_forward(st, bf, tw.G1, LD_H, tw.Wp[3], 256, d_b[3], tw.G2, LD_H, 256, 256, n_rows, rows_max);
+    }
+    const unsigned long long *sgH1 = taped ? nullptr : tw.sgH1, *sgH2 = taped ? nullptr : tw.sgH2,
+                             *sgG1 = taped ? nullptr : tw.sgG1;
     hipLaunchKernelGGL(k_train_head_agg, eg, eb, 0, st, P, tw, d_w[4], d_b[4]);
     gemm_forward(st, bf, tw.XC, LD_XC, tw.Wp[5], 288, d_b[5], tw.C1, LD_C, 128, 288, n_smp, smp_max, tw.sgC1);
     gemm_forward(st, bf, tw.C1, LD_C, tw.Wp[6], 128, d_b[6], tw.C2, LD_C, 128, 128, n_smp, smp_max, tw.sgC2);
@@ -1776,12 +1797,12 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
     hipLaunchKernelGGL(k_reduce_rows, dim3((257 + 15) / 16), eb, 0, st, tw.part, 1024, 260, 257, 256, tw.dWp[4], tw.dbp[4]);
     // mlp_head
     gemm_weight(st, bf, tw.G2, LD_H, tw.G1, LD_H, tw.dWp[3], 256, 256, 256, n_rows, rows_max, tw.dbp[3], tw.part);
-    gemm_data(st, bf, tw.G2, LD_H, tw.Wp[3], 256, tw.WT[3], tw.G1, LD_H, 256, 256, 256, n_rows, rows_max, tw.sgG1);   // G1 <- dZ3
+    gemm_data(st, bf, tw.G2, LD_H, tw.Wp[3], 256, tw.WT[3], tw.G1, LD_H, 256, 256, 256, n_rows, rows_max, sgG1);   // G1 <- dZ3
     gemm_weight(st, bf, tw.G1, LD_H, tw.H2, LD_H2, tw.dWp[2], 264, 256, 264, n_rows, rows_max, tw.dbp[2], tw.part);
-    gemm_data(st, bf, tw.G1, LD_H, tw.Wp[2], 264, tw.WT[2], tw.H2, LD_H2, 264, 256, 256, n_rows, rows_max, tw.sgH2);  // H2 <- [dZ2 | d extras]
+    gemm_data(st, bf, tw.G1, LD_H, tw.Wp[2], 264, tw.WT[2], tw.H2, LD_H2, 264, 256, 256, n_rows, rows_max, sgH2);  // H2 <- [dZ2 | d extras]
     // mlp_base
     gemm_weight(st, bf, tw.H2, LD_H2, tw.H1, LD_H, tw.dWp[1], 256, 256, 256, n_rows, rows_max, tw.dbp[1], tw.part);
-    gemm_data(st, bf, tw.H2, LD_H2, tw.Wp[1], 256, tw.WT[1], tw.H1, LD_H, 256, 256, 256, n_rows, rows_max, tw.sgH1);  // H1 <- dZ1
+    gemm_data(st, bf, tw.H2, LD_H2, tw.Wp[1], 256, tw.WT[1], tw.H1, LD_H, 256, 256, 256, n_rows, rows_max, sgH1);  // H1 <- dZ1
     gemm_weight(st, bf, tw.H1, LD_H, tw.X0, LD_X0, tw.dWp[0], 288, 256, 288, n_rows, rows_max, tw.dbp[0], tw.part);
     gemm_data(st, bf, tw.H1, LD_H, tw.Wp[0], 288, tw.WT[0], tw.G2, LD_H, 224, 256, 0, n_rows, rows_max);     // G2 <- dX0[:, :224]
     // point tensors: per-row gradients into H1 (its dZ1 is consumed), rows grouped by point, one ordered sum per point

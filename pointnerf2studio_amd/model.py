@@ -121,6 +121,9 @@ class PointNerfConfig(ModelConfig):
     hip_train_workspace_gb: float = 48.0
     # the reference's op sequence under torch autograd (rocBLAS GEMMs) instead of the fused kernels: only when asked
     hip_allow_torch_fallback: bool = False
+    # renders that a backward follows write the backward's activation tape themselves (pnr_render_opts_t.d_tape): the
+    # backward skips its four recompute GEMMs
+    hip_tape_from_render: bool = True
 
     def __post_init__(self):
         if self.path_point_cloud is not None:
@@ -450,6 +453,7 @@ class PointNerf(Model):
         rnd.opts.jitter = float(self.neural_points.jitter)
         rnd.opts.seed = self._next_seed()
         rnd.opts.early_stop_eps = 0.0 if self.training else float(getattr(self.config, "hip_early_stop_eps", 0.0))
+        rnd.tape = False
         dirs = ray_bundle.directions.to(self._device).reshape(-1, 3)
         # a small bundle (eval batches, chunks) gets a workspace that cannot overflow: no counters to read back; a whole
         # frame keeps the capacity earlier frames needed and checks the overflow counter at the end of the call
@@ -550,6 +554,7 @@ class PointNerf(Model):
         rnd.opts.jitter = float(self.neural_points.jitter)
         rnd.opts.seed = self._next_seed()
         rnd.opts.early_stop_eps = 0.0
+        rnd.tape = bool(getattr(self.config, "hip_tape_from_render", True))
         npts = self.neural_points
         mlp = []
         for name in MLP_TENSOR_ORDER:

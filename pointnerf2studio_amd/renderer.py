@@ -371,7 +371,7 @@ class RendererHIP:
     def __init__(self, scene: SceneHIP, weights: WeightsHIP, SR: int = 80, K: int = 8, D: int = 400,
                  radius_limit: float = 0.016, vsize_z: float = 0.004, eval_clamp: bool = True,
                  bg=(1.0, 1.0, 1.0), precision: str = "fp32", jitter: float = 0.0, seed: int = 0,
-                 early_stop_eps: float = 0.0):
+                 early_stop_eps: float = 0.0, tape: bool = False):
         self.lib = _lib.load()
         self.scene, self.weights = scene, weights
         self.opts = _lib.RenderOpts()
@@ -387,6 +387,11 @@ class RendererHIP:
         self.opts.seed = int(seed) & 0xFFFFFFFF
         # 0: every sample with a neighbour is shaded (the reference's sample set); > 0: early ray termination
         self.opts.early_stop_eps = float(early_stop_eps)
+        # tape: renders leave the activations of the four per-pair layers in the training workspace as they compute them
+        # (pnr_render_opts_t.d_tape) and backward() does not recompute them.  For renders that ARE followed by a backward:
+        # a taped render is a few per cent slower and allocates the training workspace.
+        self.tape = bool(tape)
+        self._tws = None
         self._ws = None
         self._ws_key = None
         self._tmid = {}
@@ -408,7 +413,20 @@ class RendererHIP:
         # (a larger buffer serves a smaller call: the carving depends on (R, cap, K) only)
         self._ws_key = key
         self.cap_samples = cap
+        if self.tape:
+            tws = self._train_workspace(cap, dev)
+            self.opts.d_tape, self.opts.tape_bytes = tws.data_ptr(), tws.numel()
+        else:
+            self.opts.d_tape, self.opts.tape_bytes = None, 0
         return self._ws
+
+    def _train_workspace(self, cap: int, dev) -> torch.Tensor:
+        nbytes = self.lib.pnr_backward_workspace_bytes(cap, self.opts.K)
+        if self._tws is None or self._tws.numel() != nbytes:
+            # (exactly the size of this capacity: the backward recognises the tape a render filled by pointer AND size)
+            self._tws = None
+            self._tws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        return self._tws
 
     def tmid(self, near: float, far: float, dev) -> torch.Tensor:
         key = (self.opts.D, float(near), float(far), str(dev))
@@ -614,10 +632,7 @@ class RendererHIP:
                 off += sizes[i][1]
                 grads.d_w[i] = out[name + ".weight"].data_ptr()
                 grads.d_b[i] = out[name + ".bias"].data_ptr()
-        nbytes = self.lib.pnr_backward_workspace_bytes(cap, self.opts.K)
-        if getattr(self, "_tws", None) is None or self._tws.numel() < nbytes:
-            self._tws = None
-            self._tws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self._train_workspace(cap, dev)
         ws = self._ws
         with torch.cuda.device(dev):
             _lib.check(self.lib.pnr_render_backward(

@@ -14,6 +14,6 @@ for r in csv.DictReader(open(f)):
     if "pnr::" in r["Name"]:
         per_step=float(r["TotalDurationNs"])/11/1e3
         tot+=per_step
-        if per_step>15: print(r["Name"][:90].ljust(90), r["Calls"].rjust(5), "%9.1f us avg %9.1f us per step" % (float(r["AverageNs"])/1e3, per_step))
+        if per_step>8: print(r["Name"][:90].ljust(90), r["Calls"].rjust(5), "%9.1f us avg %9.1f us per step" % (float(r["AverageNs"])/1e3, per_step))
 print("sum of pnr kernels per step (11 steps incl. warm-up): %.1f us" % tot)
 PY
