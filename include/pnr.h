@@ -126,6 +126,10 @@ enum {
 
 const char *pnr_last_error(void);
 int pnr_version(void);
+/* sizeof of the structs that cross this boundary, as the library was compiled: [0] pnr_grid_params_t, [1] pnr_camera_t,
+ * [2] pnr_render_opts_t, [3] pnr_view_t, [4] pnr_grads_t, [5] pnr_probe_t, [6] pnr_render_taps_t, [7] offsetof(
+ * pnr_render_opts_t, d_tape) -- a binding in another language checks its own declarations against these. */
+int pnr_abi_sizes(int64_t out[8]);
 
 /* ---- scene: built once per point-cloud version ------------------------------------------------ */
 int pnr_scene_create(pnr_scene_t **out);

@@ -22,7 +22,7 @@ MAX_CAMS = 16
 
 # every symbol include/pnr.h declares (tests check that the library exports all of them)
 EXPORTED_SYMBOLS = [
-    "pnr_last_error", "pnr_version", "pnr_jitter_uniform",
+    "pnr_last_error", "pnr_version", "pnr_abi_sizes", "pnr_jitter_uniform",
     "pnr_scene_create", "pnr_scene_destroy", "pnr_scene_build", "pnr_scene_info", "pnr_points_pack",
     "pnr_scene_update", "pnr_scene_update_info", "pnr_render_probe", "pnr_points_pack_rows", "pnr_render_touched", "pnr_points_bind", "pnr_point_grads_clear",
     "pnr_weights_create", "pnr_weights_destroy", "pnr_weights_pack", "pnr_weights_update",
@@ -98,6 +98,7 @@ def load() -> C.CDLL:
     lib.pnr_last_error.restype = C.c_char_p
     lib.pnr_last_error.argtypes = []
     lib.pnr_version.restype = C.c_int
+    lib.pnr_abi_sizes.argtypes = [C.POINTER(C.c_int64 * 8)]
     lib.pnr_jitter_uniform.restype = C.c_float
     lib.pnr_jitter_uniform.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
     lib.pnr_scene_create.argtypes = [C.POINTER(vp)]

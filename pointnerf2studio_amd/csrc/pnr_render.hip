@@ -3,6 +3,7 @@
 // fill_invalid with its torch.nonzero sync) by one pass over each ray's compact sample list, and ties
 // the stages together behind pnr_render (NeuralPoints.forward + PointNerf.get_outputs).
 #include <stdarg.h>
+#include <stddef.h>
 
 #include <algorithm>
 #include <atomic>
@@ -262,6 +263,19 @@ using namespace pnr;
 
 extern "C" const char *pnr_last_error(void) { return g_err; }
 extern "C" int pnr_version(void) { return PNR_VERSION; }
+extern "C" int pnr_abi_sizes(int64_t out[8])
+{
+    if (!out) return PNR_ERR_INVALID;
+    out[0] = (int64_t)sizeof(pnr_grid_params_t);
+    out[1] = (int64_t)sizeof(pnr_camera_t);
+    out[2] = (int64_t)sizeof(pnr_render_opts_t);
+    out[3] = (int64_t)sizeof(pnr_view_t);
+    out[4] = (int64_t)sizeof(pnr_grads_t);
+    out[5] = (int64_t)sizeof(pnr_probe_t);
+    out[6] = (int64_t)sizeof(pnr_render_taps_t);
+    out[7] = (int64_t)offsetof(pnr_render_opts_t, d_tape);
+    return PNR_OK;
+}
 extern "C" float pnr_jitter_uniform(uint32_t seed, uint32_t ray, uint32_t sample) { return pnr_uniform(seed, ray, sample); }
 
 extern "C" size_t pnr_render_workspace_bytes(int64_t R, int64_t cap_samples, int32_t K)

@@ -34,8 +34,14 @@ def test_struct_layouts_match_header(lib):
     from pointnerf2studio_amd import _lib
     assert C.sizeof(_lib.GridParams) == 6 * 4 + 3 * 4 + 3 * 4 + 3 * 4 + 3 * 4 + 3 * 4
     assert C.sizeof(_lib.CameraC) == (3 + 9 + 2) * 4
-    assert C.sizeof(_lib.RenderOpts) == 13 * 4
+    assert C.sizeof(_lib.RenderOpts) == 13 * 4 + 4 + 8 + 8        # + pad, d_tape, tape_bytes
     assert C.sizeof(_lib.ViewC) == (3 + 9 + 2 + 4) * 4
+    # ... and against the library itself (sizeof as compiled: pnr_abi_sizes)
+    got = (C.c_int64 * 8)()
+    assert lib.pnr_abi_sizes(C.byref(got)) == 0
+    want = [C.sizeof(_lib.GridParams), C.sizeof(_lib.CameraC), C.sizeof(_lib.RenderOpts), C.sizeof(_lib.ViewC),
+            C.sizeof(_lib.GradsC), C.sizeof(_lib.ProbeC), C.sizeof(_lib.RenderTaps), _lib.RenderOpts.d_tape.offset]
+    assert list(got) == want
 
 
 def test_pinhole_ray_host_statement(lib):
