@@ -367,6 +367,26 @@ int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t *weights, 
                         size_t train_workspace_bytes, const pnr_grads_t *grads, float *d_rgb_recomputed,
                         void *stream);
 
+/* ---- the confidence regulariser of the training loss -------------------------------------------------------
+ * studio_model.py:288-292 gathers conf_coefficient = clamp(points_conf, 1e-4, 1) (straight-through gradient) for every
+ * neighbour slot of the kept rays -- a [1, R'', SR, K] tensor in which unfilled slots read point 0
+ * (studio_utils.py:193-199) -- and studio_model.py:427-429 adds mean(log v + log(1 - v)), v = clamp(., eps, 1 - eps),
+ * times a weight to the loss.  pnr_conf_loss computes that mean over the neighbour lists of the LAST render in the
+ * workspace without materialising the tensor: d_out[0] = the mean (NaN when no ray was kept, as torch.mean of an empty
+ * tensor), d_out[1] = the tensor's element count; sums are taken in a fixed order (repeatable bits).
+ * pnr_conf_loss_backward adds d mean / d points_conf times *d_upstream (a device scalar: d loss / d mean) into
+ * d_grad_conf [N] -- the addends of one point are identical floats, so the result is repeatable as well.  d_conf [N] =
+ * points_conf; d_scratch: pnr_conf_loss_workspace_bytes() bytes, the SAME buffer for both calls.  No host
+ * synchronisation. */
+size_t pnr_conf_loss_workspace_bytes(void);
+int pnr_conf_loss(const pnr_scene_t *scene, const pnr_render_opts_t *opts, int64_t R, void *d_render_workspace,
+                  size_t render_workspace_bytes, int64_t cap_samples, const float *d_conf, float eps, void *d_scratch,
+                  float *d_out, void *stream);
+int pnr_conf_loss_backward(const pnr_scene_t *scene, const pnr_render_opts_t *opts, int64_t R, void *d_render_workspace,
+                           size_t render_workspace_bytes, int64_t cap_samples, const float *d_conf, float eps,
+                           void *d_scratch, const float *d_fwd_out, const float *d_upstream, float *d_grad_conf,
+                           void *stream);
+
 /* ---- probing outputs (point growing) ------------------------------------------------------------------
  * What the reference's legacy model returns with `opt.prob == 1` (models/neural_points_volumetric_model.py:331-352)
  * and run/train_studio.py:335-444 turns into new points: per ray, the shading sample of largest opacity

@@ -31,6 +31,7 @@ EXPORTED_SYMBOLS = [
     "pnr_render_camera", "pnr_render_camera_lists", "pnr_camera_rays", "pnr_pinhole_ray",
     "pnr_render_taps",
     "pnr_backward_workspace_bytes", "pnr_render_backward",
+    "pnr_conf_loss_workspace_bytes", "pnr_conf_loss", "pnr_conf_loss_backward",
     "pnr_profile_enable", "pnr_profile_calls", "pnr_profile_read",
 ]
 NUM_STAGES = 6
@@ -141,6 +142,10 @@ def load() -> C.CDLL:
     lib.pnr_render_backward.argtypes = [vp, vp, C.POINTER(vp * 9), C.POINTER(vp * 9), vp, i64, C.POINTER(CameraC), i32,
                                         vp, i64, C.POINTER(RenderOpts), vp, vp, sz, i64, vp, sz, C.POINTER(GradsC), vp,
                                         vp]
+    lib.pnr_conf_loss_workspace_bytes.restype = sz
+    lib.pnr_conf_loss_workspace_bytes.argtypes = []
+    lib.pnr_conf_loss.argtypes = [vp, C.POINTER(RenderOpts), i64, vp, sz, i64, vp, f32, vp, vp, vp]
+    lib.pnr_conf_loss_backward.argtypes = [vp, C.POINTER(RenderOpts), i64, vp, sz, i64, vp, f32, vp, vp, vp, vp, vp]
     lib.pnr_profile_enable.argtypes = [C.c_int]
     lib.pnr_profile_calls.restype = C.c_int64
     lib.pnr_profile_calls.argtypes = []
@@ -149,7 +154,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         if name not in ("pnr_last_error", "pnr_query_workspace_bytes", "pnr_render_workspace_bytes",
                         "pnr_render_workspace_bytes_for", "pnr_profile_calls", "pnr_jitter_uniform",
-                        "pnr_backward_workspace_bytes", "pnr_pinhole_ray"):
+                        "pnr_backward_workspace_bytes", "pnr_pinhole_ray", "pnr_conf_loss_workspace_bytes"):
             fn.restype = C.c_int
     _lib = lib
     return lib

@@ -1654,6 +1654,181 @@ extern "C" int pnr_point_grads_clear(float *d_embedding, float *d_color, float *
     return PNR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The confidence regulariser (studio_model.py:288-292,427-429) over the neighbour slots of a render.
+// term(c) = log v + log(1 - v), v = clamp(clamp(c, 1e-4, 1), eps, 1 - eps); d term / d c = 1 / v - 1 / (1 - v) where
+// neither clamp of v is active (the inner clamp passes its gradient straight through).
+// ------------------------------------------------------------------------------------------------
+namespace pnr {
+__device__ __forceinline__ float conf_term(float c, float eps, float &dterm)
+{
+    const float cc = fminf(fmaxf(c, 0.0001f), 1.0f);
+    const float v = fminf(fmaxf(cc, eps), 1.0f - eps);
+    dterm = (cc > eps && cc < 1.0f - eps) ? (1.0f / v - 1.0f / (1.0f - v)) : 0.f;
+    return logf(v) + logf(1.0f - v);
+}
+
+constexpr int CONF_BLOCKS = 512;   // partial sums (double) + filled-slot counts, one per block
+
+// one thread per (selected sample, slot): partial sums per block in a FIXED tree, so that the total is repeatable
+__global__ void __launch_bounds__(256) k_conf_partial(const int *__restrict__ n_sel, int K, const int *__restrict__ smp_pidx,
+                                                      const float *__restrict__ conf, float eps,
+                                                      double *__restrict__ part, long long *__restrict__ filled)
+{
+    __shared__ double sh[256];
+    __shared__ int shn[256];
+    const long long n = (long long)n_sel[0] * K;
+    double acc = 0.0;
+    int cnt = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int p = smp_pidx[i];
+        if (p >= 0) {
+            float d;
+            acc += (double)conf_term(conf[p], eps, d);
+            ++cnt;
+        }
+    }
+    sh[threadIdx.x] = acc;
+    shn[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            sh[threadIdx.x] += sh[threadIdx.x + o];
+            shn[threadIdx.x] += shn[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = sh[0];
+        filled[blockIdx.x] = shn[0];
+    }
+}
+
+// out[0] = mean over the reference's [1, R'', SR, K] tensor (unfilled slots read point 0), out[1] = its element count
+__global__ void k_conf_final(const double *__restrict__ part, const long long *__restrict__ filled, int nblocks,
+                             const unsigned long long *__restrict__ shards, int SR, int K,
+                             const float *__restrict__ conf, float eps, float *__restrict__ out,
+                             long long *__restrict__ slots_out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0.0;
+    long long nf = 0;
+    for (int i = 0; i < nblocks; ++i) {
+        s += part[i];
+        nf += filled[i];
+    }
+    const long long slots = (long long)shard_sum(shards, SH_KEPT) * SR * K;
+    float d;
+    s += (double)(slots - nf) * (double)conf_term(conf[0], eps, d);
+    out[0] = (float)(s / (double)slots);     // (no kept ray: 0 / 0 = NaN, as torch.mean of an empty tensor)
+    out[1] = (float)slots;
+    *slots_out = slots;                      // exact, for the backward
+}
+
+// d_conf[p] += upstream / slots * dterm(conf[p]) per filled slot.  The addends of one point are IDENTICAL floats, so the
+// order in which the atomics land does not matter: repeatable bits.  Point 0 also stands for every unfilled slot: its
+// slots are only counted here and added once, by k_conf_bwd_zero.
+__global__ void __launch_bounds__(256) k_conf_bwd(const int *__restrict__ n_sel, int K, const int *__restrict__ smp_pidx,
+                                                  const float *__restrict__ conf, float eps,
+                                                  const float *__restrict__ upstream, const long long *__restrict__ slots,
+                                                  float *__restrict__ d_conf, unsigned long long *__restrict__ zero_cnt)
+{
+    const long long n = (long long)n_sel[0] * K;
+    const float g = (float)((double)upstream[0] / (double)*slots);
+    unsigned long long mine = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int p = smp_pidx[i];
+        if (p > 0) {
+            float d;
+            conf_term(conf[p], eps, d);
+            if (d != 0.f) unsafeAtomicAdd(&d_conf[p], g * d);
+        } else if (p == 0) {
+            ++mine;
+        }
+    }
+    if (mine) atomicAdd(zero_cnt, mine);
+}
+__global__ void k_conf_bwd_zero(const double *__restrict__ part, const long long *__restrict__ filled, int nblocks,
+                                const float *__restrict__ conf, float eps, const float *__restrict__ upstream,
+                                const long long *__restrict__ slots_in, float *__restrict__ d_conf,
+                                unsigned long long *__restrict__ zero_cnt)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    long long nf = 0;
+    for (int i = 0; i < nblocks; ++i) nf += filled[i];
+    const long long slots = *slots_in;
+    float d;
+    conf_term(conf[0], eps, d);
+    const float g = (float)((double)upstream[0] / (double)slots);
+    d_conf[0] += (float)((double)((slots - nf) + (long long)*zero_cnt) * (double)g * (double)d);
+    *zero_cnt = 0;
+}
+}  // namespace pnr
+
+extern "C" size_t pnr_conf_loss_workspace_bytes(void) { return (size_t)pnr::CONF_BLOCKS * 16 + 64; }   // + zero count, slots
+
+static int conf_common(const char *who, const pnr_scene_t *scene, const pnr_render_opts_t *opts, int64_t R,
+                       void *d_render_workspace, size_t render_workspace_bytes, int64_t cap_samples, const float *d_conf,
+                       void *d_scratch, RenderWs &ws)
+{
+    PNR_REQUIRE(scene && opts && d_render_workspace && d_conf && d_scratch, "%s: null argument", who);
+    if (!scene->built) {
+        set_error("%s: scene not built", who);
+        return PNR_ERR_STATE;
+    }
+    const size_t need = pnr_render_workspace_bytes_for(scene, opts, R, cap_samples);
+    if (render_workspace_bytes < need) {
+        set_error("%s: workspace of %zu bytes < %zu of the render it follows", who, render_workspace_bytes, need);
+        return PNR_ERR_WORKSPACE;
+    }
+    ws = carve_render_ws(d_render_workspace, R, cap_samples, opts->K, scene->N, scene->info[2]);
+    return PNR_OK;
+}
+
+extern "C" int pnr_conf_loss(const pnr_scene_t *scene, const pnr_render_opts_t *opts, int64_t R, void *d_render_workspace,
+                             size_t render_workspace_bytes, int64_t cap_samples, const float *d_conf, float eps,
+                             void *d_scratch, float *d_out, void *stream_)
+{
+    hipStream_t st = (hipStream_t)stream_;
+    RenderWs ws{};
+    const int rc = conf_common("pnr_conf_loss", scene, opts, R, d_render_workspace, render_workspace_bytes, cap_samples,
+                               d_conf, d_scratch, ws);
+    if (rc != PNR_OK) return rc;
+    PNR_REQUIRE(d_out != nullptr && eps >= 0.f && eps < 0.5f, "pnr_conf_loss: d_out null or eps=%g", eps);
+    double *part = (double *)d_scratch;
+    long long *filled = (long long *)(part + CONF_BLOCKS);
+    hipLaunchKernelGGL(k_conf_partial, dim3(CONF_BLOCKS), dim3(256), 0, st, ws.n_sel, opts->K, ws.smp_pidx, d_conf, eps, part,
+                       filled);
+    hipLaunchKernelGGL(k_conf_final, dim3(1), dim3(64), 0, st, part, filled, CONF_BLOCKS, ws.shards, opts->SR, opts->K,
+                       d_conf, eps, d_out, filled + CONF_BLOCKS + 1);
+    PNR_HIP_CHECK(hipGetLastError());
+    return PNR_OK;
+}
+
+extern "C" int pnr_conf_loss_backward(const pnr_scene_t *scene, const pnr_render_opts_t *opts, int64_t R,
+                                      void *d_render_workspace, size_t render_workspace_bytes, int64_t cap_samples,
+                                      const float *d_conf, float eps, void *d_scratch, const float *d_fwd_out,
+                                      const float *d_upstream, float *d_grad_conf, void *stream_)
+{
+    hipStream_t st = (hipStream_t)stream_;
+    RenderWs ws{};
+    const int rc = conf_common("pnr_conf_loss_backward", scene, opts, R, d_render_workspace, render_workspace_bytes,
+                               cap_samples, d_conf, d_scratch, ws);
+    if (rc != PNR_OK) return rc;
+    PNR_REQUIRE(d_fwd_out && d_upstream && d_grad_conf, "pnr_conf_loss_backward: null argument");
+    double *part = (double *)d_scratch;
+    long long *filled = (long long *)(part + CONF_BLOCKS);
+    unsigned long long *zero_cnt = (unsigned long long *)(filled + CONF_BLOCKS);
+    PNR_HIP_CHECK(hipMemsetAsync(zero_cnt, 0, 8, st));
+    const long long *slots = filled + CONF_BLOCKS + 1;
+    hipLaunchKernelGGL(k_conf_bwd, dim3(CONF_BLOCKS), dim3(256), 0, st, ws.n_sel, opts->K, ws.smp_pidx, d_conf, eps, d_upstream,
+                       slots, d_grad_conf, zero_cnt);
+    hipLaunchKernelGGL(k_conf_bwd_zero, dim3(1), dim3(64), 0, st, part, filled, CONF_BLOCKS, d_conf, eps, d_upstream, slots,
+                       d_grad_conf, zero_cnt);
+    PNR_HIP_CHECK(hipGetLastError());
+    return PNR_OK;
+}
+
 extern "C" size_t pnr_backward_workspace_bytes(int64_t cap_samples, int32_t K)
 {
     if (cap_samples < 1) cap_samples = 1;

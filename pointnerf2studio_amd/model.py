@@ -124,6 +124,10 @@ class PointNerfConfig(ModelConfig):
     # renders that a backward follows write the backward's activation tape themselves (pnr_render_opts_t.d_tape): the
     # backward skips its four recompute GEMMs
     hip_tape_from_render: bool = True
+    # training: the confidence regulariser (studio_model.py:288-292,427-429) as a kernel pair over the render's neighbour
+    # lists; the outputs then carry `conf_coefficient_loss_term` (the mean get_loss_dict weights) instead of the
+    # `conf_coefficient` tensor.  False: `conf_coefficient` values + `conf_coefficient_weights` multiplicities (torch ops)
+    hip_conf_loss_kernel: bool = True
 
     def __post_init__(self):
         if self.path_point_cloud is not None:
@@ -169,6 +173,29 @@ class _FusedRenderFn(torch.autograd.Function):
         for name in MLP_TENSOR_ORDER:
             grads += [g[name + ".weight"], g[name + ".bias"]]
         return (None, None, None, None, None, None, *grads)
+
+
+class _ConfLossFn(torch.autograd.Function):
+    """mean(log v + log(1 - v)) over the reference's conf_coefficient tensor of the last render (pnr_conf_loss) and its
+    gradient w.r.t. points_conf (pnr_conf_loss_backward): studio_model.py:288-292,427-429 without the [1,R'',SR,K] gather."""
+
+    @staticmethod
+    def forward(ctx, rnd, eps, conf):
+        out = rnd.conf_loss(conf.detach(), eps)
+        ctx.rnd, ctx.eps, ctx.call = rnd, eps, rnd.calls
+        ctx.save_for_backward(conf, out)
+        ctx.mark_non_differentiable(out)
+        return out[0], out
+
+    @staticmethod
+    def backward(ctx, g, _g_out):
+        conf, out = ctx.saved_tensors
+        if ctx.rnd.calls != ctx.call:
+            raise RuntimeError("fused training: the renderer ran another render before backward(); its workspace no longer "
+                               "holds this step's neighbour lists")
+        grad = torch.zeros_like(conf, memory_format=torch.contiguous_format)
+        ctx.rnd.conf_loss_backward(conf.detach(), ctx.eps, out, g, grad)
+        return None, None, grad
 
 
 class PointNerf(Model):
@@ -568,7 +595,11 @@ class PointNerf(Model):
         rgb, ray_mask = _FusedRenderFn.apply(self, rnd, dirs, cams, ray_cam, cap, npts.points_embeding,
                                              npts.points_color, npts.points_dir, *mlp)
         out = {"coarse_raycolor": rgb, "ray_mask": ray_mask}
-        if self.training:
+        if self.training and getattr(self.config, "hip_conf_loss_kernel", True):
+            term, both = _ConfLossFn.apply(rnd, float(self.config.zero_epsilon), npts.points_conf)
+            out["conf_coefficient_loss_term"] = term
+            out["conf_coefficient_slots"] = both[1]      # elements of the reference's [1,R'',SR,K] tensor
+        elif self.training:
             cnt = rnd._counters_dev                                    # int64 [PNR_NUM_COUNTERS] on the device
             pidx = rnd.taps(R)["smp_pidx"]                             # [cap, K] view of the render workspace
             rows = torch.arange(pidx.shape[0], device=pidx.device)[:, None] < cnt[2]       # selected samples
@@ -737,7 +768,10 @@ class PointNerf(Model):
         keep = (outputs["ray_mask"] > 0)[..., None].to(outputs["coarse_raycolor"].dtype)
         diff = (image - outputs["coarse_raycolor"]) * keep
         loss_dict = {"ray_masked_coarse_raycolor_loss": torch.sum(diff * diff) / (3.0 * torch.sum(keep)) + 1e-6}
-        if self.training:
+        if self.training and "conf_coefficient_loss_term" in outputs:
+            # (the fused path computed the mean itself: _ConfLossFn)
+            loss_dict["conf_coefficient_loss"] = outputs["conf_coefficient_loss_term"] * self.config.zero_one_loss_weights
+        elif self.training:
             val = torch.clamp(outputs["conf_coefficient"], self.config.zero_epsilon, 1 - self.config.zero_epsilon)
             term = torch.log(val) + torch.log(1 - val)
             w = outputs.get("conf_coefficient_weights")

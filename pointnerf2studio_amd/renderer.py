@@ -645,6 +645,37 @@ class RendererHIP:
             out["point_index"] = sp_index[:U].to(torch.long)
         return out
 
+    def conf_loss(self, conf: torch.Tensor, eps: float) -> torch.Tensor:
+        """pnr_conf_loss on the LAST render: [mean(log v + log(1 - v)), element count] of the reference's conf_coefficient
+        tensor (studio_model.py:288-292,427-429) as a float32 [2] device tensor; no host read."""
+        if self._last is None:
+            raise RuntimeError("RendererHIP.conf_loss: no render call yet")
+        R, cap = self._last[1], self._last[6]
+        dev = self.scene.device
+        c = _f32c(conf.reshape(-1), dev)
+        if getattr(self, "_conf_scratch", None) is None:
+            self._conf_scratch = torch.empty(self.lib.pnr_conf_loss_workspace_bytes(), dtype=torch.uint8, device=dev)
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        ws = self._ws
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.pnr_conf_loss(self.scene.handle, C.byref(self.opts), R, _ptr(ws), ws.numel(), cap, _ptr(c),
+                                              float(eps), _ptr(self._conf_scratch), _ptr(out), _stream_ptr(dev)),
+                       "pnr_conf_loss")
+        return out
+
+    def conf_loss_backward(self, conf: torch.Tensor, eps: float, fwd: torch.Tensor, upstream: torch.Tensor,
+                           grad_conf: torch.Tensor) -> None:
+        """pnr_conf_loss_backward: grad_conf [N] (float32, contiguous) += d mean / d conf * upstream (device scalar)."""
+        R, cap = self._last[1], self._last[6]
+        dev = self.scene.device
+        c = _f32c(conf.reshape(-1), dev)
+        up = _f32c(upstream.reshape(1), dev)
+        ws = self._ws
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.pnr_conf_loss_backward(self.scene.handle, C.byref(self.opts), R, _ptr(ws), ws.numel(), cap,
+                                                       _ptr(c), float(eps), _ptr(self._conf_scratch), _ptr(fwd), _ptr(up),
+                                                       _ptr(grad_conf), _stream_ptr(dev)), "pnr_conf_loss_backward")
+
     def touched(self, index: Optional[torch.Tensor] = None, count: Optional[torch.Tensor] = None):
         """pnr_render_touched: the distinct neighbour points of the LAST render (ascending), without a host read:
         (index int32 [cap] -- entries beyond the count repeat the first one --, count int64 [1] on the device).  cap =

@@ -130,9 +130,9 @@ def _plugin_model(device):
 
 def _plugin_loss(model_or_ddp, model, bundle, G, sel):
     out = model_or_ddp(bundle(sel))
-    # a sum over rays (per-rank losses add up to the whole batch's) + the conf regulariser's own term
-    val = torch.clamp(out["conf_coefficient"], 1e-3, 1 - 1e-3)
-    conf = torch.sum((torch.log(val) + torch.log(1 - val)) * out["conf_coefficient_weights"]) * 1e-6
+    # a sum over rays (per-rank losses add up to the whole batch's) + the conf regulariser's own term, also as a sum
+    # (the mean over the rank's slots times their number)
+    conf = out["conf_coefficient_loss_term"] * out["conf_coefficient_slots"] * 1e-6
     return (out["coarse_raycolor"] * G[sel]).sum() + conf
 
 

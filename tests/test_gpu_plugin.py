@@ -60,7 +60,7 @@ def test_training_get_outputs_matches_oracle_and_backpropagates(oracle, gpu_devi
     model.train()
     model.neural_points.jitter = 0.0              # the oracle is evaluated at jitter 0
     out = model(bundle)
-    assert "conf_coefficient" in out
+    assert "conf_coefficient_loss_term" in out
     assert torch.equal(out["ray_mask"].cpu(), ref["ray_mask"])
     # training mode does not clamp (nerfstudio RGBRenderer); compare where the oracle's eval clamp is inactive
     rgb, rrgb = out["coarse_raycolor"].detach().cpu(), ref["coarse_raycolor"]
@@ -150,6 +150,48 @@ def test_consecutive_fused_training_steps_reuse_scene_and_workspace(oracle, gpu_
     model.train()
     tr = model(bundle)["coarse_raycolor"].detach()
     assert (ev["coarse_raycolor"] - tr)[inside].abs().max().item() <= 1e-5
+
+
+def test_conf_regulariser_kernel_equals_the_torch_statement(oracle, gpu_device):
+    """pnr_conf_loss / pnr_conf_loss_backward (hip_conf_loss_kernel, default) against the torch-op form of the same term
+    (values + multiplicities, itself equal to the reference's mean by test_weighted_conf_loss_equals_the_references_mean)
+    and against the reference's literal tensor built from the neighbour lists: value, gradient w.r.t. points_conf, and
+    the gradient's bits twice."""
+    model, bundle, _ = _model_and_bundle(oracle, gpu_device, N=40000, H=24, W=24)
+    model.train()
+    model.neural_points.jitter = 0.0
+    with torch.no_grad():   # confidences on both sides of both clamps
+        c = model.neural_points.points_conf
+        c.copy_(torch.rand(c.shape, generator=torch.Generator().manual_seed(2)).to(gpu_device) * 1.3 - 0.15)
+    image = torch.rand(bundle.directions.shape[0], 3, device=gpu_device)
+    res = {}
+    for kernel in (True, False, True):
+        model.config.hip_conf_loss_kernel = kernel
+        model.zero_grad(set_to_none=True)
+        out = model(bundle)
+        loss = model.get_loss_dict(out, {"image": image})["conf_coefficient_loss"]
+        loss.backward()
+        res.setdefault(kernel, []).append((loss.item(), model.neural_points.points_conf.grad.clone(), out))
+    (lk, gk, out_k), (lt, gt, _) = res[True][0], res[False][0]
+    assert abs(lk - lt) <= 1e-6 * abs(lt) and abs(lt) > 1e-6
+    assert (gk - gt).abs().max().item() <= 1e-5 * gt.abs().max().item() and gt.abs().max().item() > 0
+    assert torch.equal(res[True][1][1], gk), "the kernel's gradient must be bitwise repeatable"
+    # the reference's literal tensor: [R'', SR, K] gather with clamp(pidx, 0) (studio_utils.py:193-199)
+    rnd = model._renderer_train
+    R = bundle.directions.shape[0]
+    taps = rnd.taps(R)
+    cnt, off = taps["ray_cnt"], taps["ray_off"]
+    kept = torch.nonzero(out_k["ray_mask"] > 0).reshape(-1)
+    SR, K = model.config.SR, model.config.K
+    pidx = torch.zeros((kept.numel(), SR, K), dtype=torch.long, device=gpu_device)
+    for i, r in enumerate(kept.tolist()):
+        n = int(cnt[r])
+        pidx[i, :n] = taps["smp_pidx"][int(off[r]):int(off[r]) + n].long().clamp(min=0)
+    conf = model.neural_points.points_conf.detach()[0, :, 0][pidx]
+    cc = torch.clamp(torch.clamp(conf, 0.0001, 1), model.config.zero_epsilon, 1 - model.config.zero_epsilon)
+    want = torch.mean(torch.log(cc) + torch.log(1 - cc)).item() * model.config.zero_one_loss_weights
+    assert abs(lk - want) <= 2e-6 * abs(want)
+    assert float(out_k["conf_coefficient_slots"]) == kept.numel() * SR * K
 
 
 def _bundle(device, H, W, az, el=30.0):
