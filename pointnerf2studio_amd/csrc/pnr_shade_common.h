@@ -62,12 +62,29 @@ __device__ __forceinline__ float leaky(float x)
     return r;
 }
 
+// Packed fp32 forms in the fp32 MLP kernels (default on; -DPNR_NO_PK_LEAKY builds the scalar forms for A/B runs): the
+// LeakyReLU multiply of two values as ONE v_pk_mul_f32 (forced through inline asm: left alone hipcc turns the vector
+// multiply back into two v_mul_f32 -- 20 v_pk_mul_f32 against 864 v_mul_f32 in the pair kernel's ISA) and, in the pair
+// kernel's layer-4 sink, the density product as v_pk_fma_f32 and the neighbour weight as v_pk_mul_f32 on pairs of
+// values: 487 fewer VALU instructions per 32-pair tile (2 270 -> 1 780), 33.10 -> 33.00 ms on cfg 1 (A/B on one device,
+// three rounds; the kernel is NOT limited by its VALU count -- see DESIGN.md section 4.1).
+#ifndef PNR_NO_PK_LEAKY
+#define PNR_PK_LEAKY 1
+#endif
 // two LeakyReLUs with one packed multiply (v_pk_mul_f32: the same IEEE product as two v_mul_f32)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void leaky2(float a, float b, float &ra, float &rb)
 {
     const f32x2 x = {a, b};
+#ifdef PNR_PK_LEAKY
+    // forced: hipcc turns the vector multiply below back into two v_mul_f32 (20 v_pk_mul_f32 against 864 v_mul_f32 in the
+    // fp32 pair kernel's ISA)
+    f32x2 y;
+    const f32x2 k = {0.1f, 0.1f};
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(y) : "v"(x), "v"(k));
+#else
     const f32x2 y = x * 0.1f;
+#endif
     asm("v_max_f32 %0, %1, %2" : "=v"(ra) : "v"(a), "v"(y.x));
     asm("v_max_f32 %0, %1, %2" : "=v"(rb) : "v"(b), "v"(y.y));
 }
