@@ -153,18 +153,22 @@ def plugin_legs(args, cfgd, points, weights, cams, dev, near, far):
     sd = {"neural_points.xyz": points["xyz"], "neural_points.points_embeding": points["embedding"],
           "neural_points.points_conf": points["conf"], "neural_points.points_dir": points["dir"],
           "neural_points.points_color": points["color"], "neural_points.Rw2c": points["Rw2c"]}
+    # as `ns-train pointnerf-original` configures it: nerfstudio's collider writes the planes (its near plane kept in eval
+    # too, so that the frames are the ones `value` renders), bundles are one camera each (studio_datamanager.py:62-110)
     cfg = PointNerfConfig(ranges=list(cfgd["ranges"]), max_o=cfgd["max_o"], SR=cfgd["SR"], K=cfgd["K"], P=cfgd["P"],
-                          vsize=[cfgd["vsize"]] * 3, hip_mlp_mode=args.precision, enable_collider=False,
-                          eval_num_rays_per_chunk=REF_CHUNK)
+                          vsize=[cfgd["vsize"]] * 3, hip_mlp_mode=args.precision, enable_collider=True,
+                          collider_params={"near_plane": float(near), "far_plane": float(far)},
+                          eval_num_rays_per_chunk=REF_CHUNK, hip_single_camera_bundles=True)
     model = PointNerf(cfg, point_state_dict=sd).to(dev)
     model.load_state_dict(weights, strict=False)
     model.neural_points.jitter = float(args.jitter)
+    if hasattr(model.collider, "reset_near_plane"):
+        model.collider.reset_near_plane = False
     bundles = []
     for campos, camrot in cams:
         d = synthetic.make_rays(H, W, campos, camrot, cfgd["angle_x"]).to(dev).reshape(H, W, 3)
         bundles.append(RayBundle(
             origins=campos.to(dev)[None, None].expand(H, W, 3).contiguous(), directions=d,
-            nears=torch.full((H, W, 1), float(near), device=dev), fars=torch.full((H, W, 1), float(far), device=dev),
             metadata={"camrotc2w": camrot.to(dev)[None, None].expand(H, W, -1, -1).reshape(H, W, -1)}))
     model.eval()
     for s in range(max(args.warmup, 1) + len(bundles)):      # warm-up: every view once (capacity, camera memo)
@@ -196,7 +200,7 @@ def plugin_legs(args, cfgd, points, weights, cams, dev, near, far):
     model.train()
     torch.manual_seed(12)
     full = bundles[0].directions.reshape(-1, 3)
-    campos0, camrot0 = cams[0]
+    campos0_dev, camrot0_dev = cams[0][0].to(dev), cams[0][1].to(dev)
     opt = torch.optim.Adam([{"params": g, "lr": lr} for g, lr in
                             ((model.get_param_groups()["fields"], 5e-4), (model.get_param_groups()["neural_points"], 2e-3))])
     callbacks = model.get_training_callbacks(None)
@@ -204,9 +208,8 @@ def plugin_legs(args, cfgd, points, weights, cams, dev, near, far):
 
     def one_step(with_adam):
         pick = torch.randint(0, full.shape[0], (n_rays,), device=dev)      # (drawn on the device: no host work)
-        b = RayBundle(origins=campos0.to(dev)[None].expand(n_rays, 3), directions=full.index_select(0, pick),
-                      nears=torch.full((n_rays, 1), float(near), device=dev),
-                      fars=torch.full((n_rays, 1), float(far), device=dev), metadata={"camrotc2w": camrot0.to(dev)})
+        b = RayBundle(origins=campos0_dev[None].expand(n_rays, 3), directions=full.index_select(0, pick),
+                      metadata={"camrotc2w": camrot0_dev})
         batch = {"image": torch.rand((n_rays, 3), device=dev)}
         opt.zero_grad(set_to_none=True)
         out = model(b)

@@ -228,6 +228,18 @@ int pnr_render(const pnr_scene_t *scene, const pnr_weights_t *weights, const flo
                float *d_rgb, float *d_depth, float *d_acc, int8_t *d_ray_mask, int64_t *d_counters,
                void *d_workspace, size_t workspace_bytes, int64_t cap_samples, void *stream);
 
+/* pnr_render for a bundle whose camera POSE lives on the device: d_campos [3] and d_camrotc2w [9] -- ray_bundle.origins[0]
+ * and metadata["camrotc2w"] where the datamanager left them (studio_datamanager.py:79) -- are read by the kernels; the
+ * planes stay host values (they come from a collider's attributes or the datamanager's config, not from the device).
+ * The reference reads four scalars / vectors back per call (studio_utils.py:148-155); with this entry a bundle is
+ * rendered without any device-to-host read.  pnr_render_backward after it: pass cams = NULL (the camera the render left
+ * in its workspace is used). */
+int pnr_render_pose(const pnr_scene_t *scene, const pnr_weights_t *weights, const float *d_dirs, int64_t R,
+                    const float *d_campos, const float *d_camrotc2w, float near_plane, float far_plane,
+                    const float *d_tmid, const pnr_render_opts_t *opts, float *d_rgb, float *d_depth, float *d_acc,
+                    int8_t *d_ray_mask, int64_t *d_counters, void *d_workspace, size_t workspace_bytes,
+                    int64_t cap_samples, void *stream);
+
 /* The counter-based uniform in [0,1) (24 random bits) the kernels draw for coarse sample `sample` of ray `ray` when
  * jitter > 0; host-callable so a caller can reproduce a frame.  `ray` is the index of the ray inside the call for
  * pnr_render / pnr_render_views / pnr_query_raypos, and view * H * W + pixel id for pnr_render_camera(_lists): a frame
@@ -359,6 +371,7 @@ size_t pnr_backward_workspace_bytes(int64_t cap_samples, int32_t K);
  * raw weights (as given to pnr_weights_pack; `weights` only supplies Rw2c), d_grad_rgb [R,3] is d loss / d rgb.
  * opts->early_stop_eps must be 0.  d_rgb_recomputed (may be null) receives the fp32 rgb [R,3] of the recomputed
  * forward.  No host synchronisation; everything is queued on `stream`. */
+/* (cams may be NULL after pnr_render_pose: the camera that render left in the workspace is used; n_cams = 1 then) */
 int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t *weights, const float *const d_w[9],
                         const float *const d_b[9], const float *d_dirs, int64_t R, const pnr_camera_t *cams,
                         int32_t n_cams, const int32_t *d_ray_cam, int64_t rays_per_cam,

@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "pnr_scene_update", "pnr_scene_update_info", "pnr_render_probe", "pnr_points_pack_rows", "pnr_render_touched", "pnr_points_bind", "pnr_point_grads_clear",
     "pnr_weights_create", "pnr_weights_destroy", "pnr_weights_pack", "pnr_weights_update",
     "pnr_query_workspace_bytes", "pnr_query_raypos",
-    "pnr_render_workspace_bytes", "pnr_render_workspace_bytes_for", "pnr_render", "pnr_render_views",
+    "pnr_render_workspace_bytes", "pnr_render_workspace_bytes_for", "pnr_render", "pnr_render_views", "pnr_render_pose",
     "pnr_render_camera", "pnr_render_camera_lists", "pnr_camera_rays", "pnr_pinhole_ray",
     "pnr_render_taps",
     "pnr_backward_workspace_bytes", "pnr_render_backward",
@@ -128,6 +128,8 @@ def load() -> C.CDLL:
     lib.pnr_render_workspace_bytes_for.argtypes = [vp, C.POINTER(RenderOpts), i64, i64]
     lib.pnr_render.argtypes = [vp, vp, vp, i64, C.POINTER(CameraC), vp, C.POINTER(RenderOpts), vp, vp, vp, vp, vp,
                                vp, sz, i64, vp]
+    lib.pnr_render_pose.argtypes = [vp, vp, vp, i64, vp, vp, f32, f32, vp, C.POINTER(RenderOpts), vp, vp, vp, vp, vp, vp, sz,
+                                    i64, vp]
     lib.pnr_render_views.argtypes = [vp, vp, vp, i64, C.POINTER(CameraC), i32, vp, i64, vp, C.POINTER(RenderOpts), vp, vp,
                                      vp, vp, vp, vp, sz, i64, vp]
     lib.pnr_render_camera.argtypes = [vp, vp, C.POINTER(ViewC), i32, i32, i32, vp, i64, vp, C.POINTER(RenderOpts), vp, vp, vp,

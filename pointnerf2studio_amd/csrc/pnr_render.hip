@@ -40,6 +40,16 @@ __global__ void k_set_cams(CamSet set, int n, Camera *__restrict__ dst)
     if (i < n) dst[i] = set.c[i];
 }
 
+// one camera whose pose lives on the device (pnr_render_pose): position [3], rotation [9] row-major
+__global__ void k_set_cam_dev(const float *__restrict__ pos, const float *__restrict__ rot, Camera *__restrict__ dst)
+{
+    const int i = threadIdx.x;
+    float *d = reinterpret_cast<float *>(dst);
+    if (i < 3) d[i] = pos[i];
+    else if (i < 12) d[i] = rot[i - 3];
+    else if (i < 16) d[i] = 0.f;
+}
+
 __global__ void __launch_bounds__(TPB) k_composite(CamRef cr, pnr_render_opts_t opts, int64_t R,
                                                     const int *__restrict__ ray_cnt, const int *__restrict__ ray_off,
                                                     const int *__restrict__ ray_flag,
@@ -311,7 +321,7 @@ static int render_views(const pnr_scene_t *scene, const pnr_weights_t *weights, 
                         int64_t rays_per_cam, const RayGen *gen, const float *d_tmid, const pnr_render_opts_t *opts,
                         float *d_rgb, float *d_depth, float *d_acc, int8_t *d_ray_mask, int64_t *d_counters,
                         void *d_workspace, size_t workspace_bytes, int64_t cap_samples, hipStream_t stream,
-                        const char *who)
+                        const char *who, const float *d_pose_pos = nullptr, const float *d_pose_rot = nullptr)
 {
     PNR_REQUIRE(scene && weights && (d_dirs || gen) && d_tmid && opts && d_rgb && d_ray_mask && d_counters &&
                     d_workspace,
@@ -347,7 +357,10 @@ static int render_views(const pnr_scene_t *scene, const pnr_weights_t *weights, 
     }
     const bool factored = true;  // both arithmetic modes start mlp_base layer 0 from the per-point table
     RenderWs ws = carve_render_ws(d_workspace, R, cap_samples, opts->K, scene->N, scene->info[2]);
-    hipLaunchKernelGGL(k_set_cams, dim3(1), dim3(64), 0, stream, set, n_cams, ws.cams);
+    if (d_pose_pos)
+        hipLaunchKernelGGL(k_set_cam_dev, dim3(1), dim3(64), 0, stream, d_pose_pos, d_pose_rot, ws.cams);
+    else
+        hipLaunchKernelGGL(k_set_cams, dim3(1), dim3(64), 0, stream, set, n_cams, ws.cams);
     CamRef cr{};
     cr.cams = ws.cams;
     cr.ray_cam = d_ray_cam;
@@ -444,6 +457,22 @@ extern "C" int pnr_render_views(const pnr_scene_t *scene, const pnr_weights_t *w
     return render_views(scene, weights, d_dirs, R, set, nears, n_cams, d_ray_cam, rays_per_cam, nullptr, d_tmid, opts,
                         d_rgb, d_depth, d_acc, d_ray_mask, d_counters, d_workspace, workspace_bytes, cap_samples,
                         (hipStream_t)stream, "pnr_render_views");
+}
+
+extern "C" int pnr_render_pose(const pnr_scene_t *scene, const pnr_weights_t *weights, const float *d_dirs, int64_t R,
+                               const float *d_campos, const float *d_camrotc2w, float near_plane, float far_plane,
+                               const float *d_tmid, const pnr_render_opts_t *opts, float *d_rgb, float *d_depth,
+                               float *d_acc, int8_t *d_ray_mask, int64_t *d_counters, void *d_workspace,
+                               size_t workspace_bytes, int64_t cap_samples, void *stream)
+{
+    PNR_REQUIRE(d_dirs && d_campos && d_camrotc2w, "pnr_render_pose: null argument");
+    (void)far_plane;   // (the far plane is in d_tmid, as for pnr_render)
+    CamSet set{};
+    float nears[PNR_MAX_CAMS] = {0};
+    nears[0] = near_plane;
+    return render_views(scene, weights, d_dirs, R, set, nears, 1, nullptr, R, nullptr, d_tmid, opts, d_rgb, d_depth, d_acc,
+                        d_ray_mask, d_counters, d_workspace, workspace_bytes, cap_samples, (hipStream_t)stream,
+                        "pnr_render_pose", d_campos, d_camrotc2w);
 }
 
 static int check_views(const pnr_view_t *views, int32_t n_views, int32_t H, int32_t W, const int32_t *d_pixels,

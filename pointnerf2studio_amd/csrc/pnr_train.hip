@@ -1846,7 +1846,7 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
 {
     const char *who = "pnr_render_backward";
     hipStream_t st = (hipStream_t)stream_;
-    PNR_REQUIRE(scene && weights && d_w && d_b && d_dirs && cams && opts && d_grad_rgb && d_render_workspace &&
+    PNR_REQUIRE(scene && weights && d_w && d_b && d_dirs && opts && d_grad_rgb && d_render_workspace &&
                     d_train_workspace && grads,
                 "%s: null argument", who);
     for (int i = 0; i < 9; ++i) PNR_REQUIRE(d_w[i] && d_b[i], "%s: null weight pointer %d", who, i);
@@ -1890,7 +1890,7 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
     cr.n_cams = n_cams;
     cr.jitter = opts->jitter;
     cr.seed = opts->seed;
-    {
+    if (cams) {   // (cams == NULL: the cameras the render left in its workspace -- after pnr_render_pose)
         CamSet set{};
         for (int c = 0; c < n_cams; ++c) {
             for (int i = 0; i < 3; ++i) set.c[c].o[i] = cams[c].campos[i];

@@ -128,6 +128,11 @@ class PointNerfConfig(ModelConfig):
     # lists; the outputs then carry `conf_coefficient_loss_term` (the mean get_loss_dict weights) instead of the
     # `conf_coefficient` tensor.  False: `conf_coefficient` values + `conf_coefficient_weights` multiplicities (torch ops)
     hip_conf_loss_kernel: bool = True
+    # every bundle handed to the model comes from ONE camera (the reference's datamanager picks one image per batch,
+    # studio_datamanager.py:62-81, and the reference itself reads origins[0] / camrotc2w[0] only, studio_utils.py:148-152):
+    # the pose is then read by the kernels from the bundle's device tensors (pnr_render_pose) and, with a collider that
+    # states its planes, a call issues no device-to-host read at all.  False: bundles may mix cameras (one read to know)
+    hip_single_camera_bundles: bool = False
 
     def __post_init__(self):
         if self.path_point_cloud is not None:
@@ -144,7 +149,10 @@ class _FusedRenderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, rnd, dirs, cams, ray_cam, cap, emb, color, pdir, *mlp):
         R = dirs.shape[0]
-        out = rnd.render_views(dirs, cams, R, ray_cam=ray_cam, cap_samples=cap, sync_counters=cap is None)
+        if isinstance(cams, tuple):     # (campos, camrotc2w on the device, near, far): _device_pose
+            out = rnd.render_pose(dirs, cams[0], cams[1], cams[2], cams[3], cap_samples=cap, sync_counters=cap is None)
+        else:
+            out = rnd.render_views(dirs, cams, R, ray_cam=ray_cam, cap_samples=cap, sync_counters=cap is None)
         ctx.model, ctx.rnd = model, rnd
         ctx.shapes = (emb.shape, color.shape, pdir.shape)
         ctx.state = {name + suf: mlp[2 * i + j] for i, name in enumerate(MLP_TENSOR_ORDER)
@@ -465,6 +473,21 @@ class PointNerf(Model):
             self._cam_memo = None
         return result
 
+    def _device_pose(self, ray_bundle):
+        """(campos [3], camrotc2w [9] on the device, near, far) when the bundle can be rendered without a host read:
+        hip_single_camera_bundles vouches for one camera and the planes are known from the collider's memo; else None
+        (the caller takes _bundle_cameras, whose read also fills that memo)."""
+        if not getattr(self.config, "hip_single_camera_bundles", False):
+            return None
+        plane_key, planes = self._collider_planes(ray_bundle)
+        if planes is None:
+            return None
+        meta = ray_bundle.metadata["camrotc2w"]
+        rot = meta.reshape(9) if tuple(meta.shape) == (3, 3) else meta.reshape(-1, 9)[0]
+        pos = ray_bundle.origins.reshape(-1, 3)[0]
+        dev = self._device
+        return (pos.to(dev, torch.float32).contiguous(), rot.to(dev, torch.float32).contiguous(), planes[0], planes[1])
+
     def _next_seed(self) -> int:
         seed = self._render_calls & 0xFFFFFFFF
         self._render_calls += 1
@@ -475,7 +498,9 @@ class PointNerf(Model):
         (studio_utils.py:166, hard-coded 0.3); the fused path uses the same fraction (`neural_points.jitter`) with the
         library's counter-based uniforms and a fresh seed per call.  Set `neural_points.jitter = 0` for deterministic
         mid-point renders.  The clamp follows the module's mode as nerfstudio's RGBRenderer does."""
-        cams, ray_cam = self._bundle_cameras(ray_bundle, one_camera, owner)
+        pose = self._device_pose(ray_bundle)
+        if pose is None:
+            cams, ray_cam = self._bundle_cameras(ray_bundle, one_camera, owner)
         rnd = self._fused_renderer(clamp=not self.training)
         rnd.opts.jitter = float(self.neural_points.jitter)
         rnd.opts.seed = self._next_seed()
@@ -485,7 +510,10 @@ class PointNerf(Model):
         # a small bundle (eval batches, chunks) gets a workspace that cannot overflow: no counters to read back; a whole
         # frame keeps the capacity earlier frames needed and checks the overflow counter at the end of the call
         cap = self._worst_case_cap(rnd, dirs.shape[0], backward=False)
-        out = rnd.render_views(dirs, cams, dirs.shape[0], ray_cam=ray_cam, cap_samples=cap, sync_counters=cap is None)
+        if pose is not None:
+            out = rnd.render_pose(dirs, pose[0], pose[1], pose[2], pose[3], cap_samples=cap, sync_counters=cap is None)
+        else:
+            out = rnd.render_views(dirs, cams, dirs.shape[0], ray_cam=ray_cam, cap_samples=cap, sync_counters=cap is None)
         if cap is None:
             self.host_reads += 1
         return {"coarse_raycolor": out["rgb"], "ray_mask": out["ray_mask"], "depth": out["depth"],
@@ -576,7 +604,8 @@ class PointNerf(Model):
         the workspace that holds nothing, and the number of unfilled slots of kept rays for the single entry of point
         0) -- so that no count has to reach the host; get_loss_dict takes the weighted mean, which is all the loss (a
         mean) looks at."""
-        cams, ray_cam = self._bundle_cameras(ray_bundle)
+        pose = self._device_pose(ray_bundle)
+        cams, ray_cam = (None, None) if pose is not None else self._bundle_cameras(ray_bundle)
         rnd = self._fused_renderer(clamp=not self.training, live=True)
         rnd.opts.jitter = float(self.neural_points.jitter)
         rnd.opts.seed = self._next_seed()
@@ -592,8 +621,8 @@ class PointNerf(Model):
         cap = self._worst_case_cap(rnd, R, backward=True)
         if cap is None:
             self.host_reads += 1
-        rgb, ray_mask = _FusedRenderFn.apply(self, rnd, dirs, cams, ray_cam, cap, npts.points_embeding,
-                                             npts.points_color, npts.points_dir, *mlp)
+        rgb, ray_mask = _FusedRenderFn.apply(self, rnd, dirs, cams if pose is None else pose, ray_cam, cap,
+                                             npts.points_embeding, npts.points_color, npts.points_dir, *mlp)
         out = {"coarse_raycolor": rgb, "ray_mask": ray_mask}
         if self.training and getattr(self.config, "hip_conf_loss_kernel", True):
             term, both = _ConfLossFn.apply(rnd, float(self.config.zero_epsilon), npts.points_conf)
@@ -629,11 +658,14 @@ class PointNerf(Model):
         if not self._fusable():
             raise RuntimeError("get_probe_outputs needs the fused HIP path (default network shape)")
         was_training = self.training
+        single = getattr(self.config, "hip_single_camera_bundles", False)
         self.eval()
         try:
+            self.config.hip_single_camera_bundles = False     # (the probe takes the cameras from the host)
             out = self._get_outputs_fused(ray_bundle)
             out.update(self._renderer.probe())
         finally:
+            self.config.hip_single_camera_bundles = single
             self.train(was_training)
         return out
 

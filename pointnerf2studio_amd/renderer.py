@@ -500,6 +500,50 @@ class RendererHIP:
             # overflow: grow to what the frame actually needs (+12 %) and render again
             cap = int(cnt[2] * 1.125) + 1024
 
+    def render_pose(self, directions: torch.Tensor, campos_dev: torch.Tensor, camrot_dev: torch.Tensor, near: float,
+                    far: float, cap_samples: Optional[int] = None, sync_counters: bool = True,
+                    out: Optional[dict] = None):
+        """pnr_render_pose: one camera whose pose lives on the DEVICE (campos_dev [3], camrot_dev [9], float32 contiguous
+        GPU tensors -- a bundle's origins[0] and camrotc2w): nothing is read back to launch the render.  backward() works
+        after it (the camera stays in the workspace); probe() does not."""
+        dev = directions.device
+        if not directions.is_cuda:
+            raise RuntimeError("RendererHIP.render_pose: directions must be a GPU tensor (no CPU fallback)")
+        d = _f32c(directions.reshape(-1, 3), dev)
+        pos, rot = _f32c(campos_dev.reshape(3), dev), _f32c(camrot_dev.reshape(9), dev)
+        R = d.shape[0]
+        tm = self.tmid(near, far, dev).reshape(1, 2, -1).contiguous()
+        cap = int(cap_samples or self.cap_samples or max(4096, min(R * self.opts.SR, R * 16)))
+        if out is None:
+            out = {
+                "rgb": torch.empty((R, 3), dtype=torch.float32, device=dev),
+                "depth": torch.empty((R,), dtype=torch.float32, device=dev),
+                "acc": torch.empty((R,), dtype=torch.float32, device=dev),
+                "ray_mask": torch.empty((R,), dtype=torch.int8, device=dev),
+                "counters_dev": torch.zeros(_lib.NUM_COUNTERS, dtype=torch.int64, device=dev),
+            }
+        while True:
+            ws = self._workspace(R, cap, dev)
+            self._last = (d, R, None, 1, None, R, cap)      # (no host camera: the backward reads the workspace's)
+            self._pose_keep = (pos, rot)
+            self.calls += 1
+            with torch.cuda.device(dev):
+                _lib.check(self.lib.pnr_render_pose(
+                    self.scene.handle, self.weights.handle, _ptr(d), R, _ptr(pos), _ptr(rot), float(near), float(far),
+                    _ptr(tm), C.byref(self.opts), _ptr(out["rgb"]), _ptr(out["depth"]), _ptr(out["acc"]),
+                    _ptr(out["ray_mask"]), _ptr(out["counters_dev"]), _ptr(ws), ws.numel(), cap, _stream_ptr(dev)),
+                    "pnr_render_pose")
+            self._counters_dev = out["counters_dev"]
+            if not sync_counters:
+                self.last_counters = None
+                return out
+            cnt = out["counters_dev"].cpu().tolist()
+            out["counters"] = dict(zip(_lib.COUNTER_NAMES, cnt))
+            self.last_counters = out["counters"]
+            if cnt[6] == 0:
+                return out
+            cap = int(cnt[2] * 1.125) + 1024
+
     def render_camera(self, views: Sequence[View], H: int, W: int, pixels: Optional[torch.Tensor] = None,
                       cap_samples: Optional[int] = None, sync_counters: bool = True, out: Optional[dict] = None):
         """pnr_render_camera: the views' rays are generated inside the kernels from pose + intrinsics; no direction
@@ -717,6 +761,8 @@ class RendererHIP:
         if getattr(self, "_last", None) is None:
             raise RuntimeError("RendererHIP.probe: no render call to probe")
         d, R, arr, n, rc, rays_per_cam, cap = self._last
+        if arr is None:
+            raise RuntimeError("RendererHIP.probe: not after render_pose (render with host cameras to probe)")
         dev = self.scene.device
         out, pc = {}, _lib.ProbeC()
         for key, (field, tail) in self.PROBE_KEYS.items():

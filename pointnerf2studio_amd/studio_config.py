@@ -147,7 +147,9 @@ if HAVE_NERFSTUDIO:  # pragma: no cover - nerfstudio is not installable in the b
             _target=PointNerfPipeline,
             datamanager=PointNerfDataManagerConfig(_target=PointNerfDataManager, eval_num_rays_per_batch=4096,
                                                    train_num_rays_per_batch=4096),
-            model=PointNerfConfig(_target=PointNerf, eval_num_rays_per_chunk=EVAL_NUM_RAYS_PER_CHUNK),
+            # (PointNerfDataManager hands over one image per batch: every bundle is one camera)
+            model=PointNerfConfig(_target=PointNerf, eval_num_rays_per_chunk=EVAL_NUM_RAYS_PER_CHUNK,
+                                  hip_single_camera_bundles=True),
         ),
         max_num_iterations=200000,
         steps_per_save=25000,

@@ -308,6 +308,63 @@ def test_training_steps_issue_one_host_read_and_no_full_repack(oracle, gpu_devic
     assert int(inside.sum()) > 100 and (ev - fresh)[inside].abs().max().item() <= 1e-6
 
 
+def test_single_camera_bundles_need_no_host_read(oracle, gpu_device):
+    """hip_single_camera_bundles (what the registered method config sets: the datamanager hands over one image per batch)
+    + a collider that states its planes: the kernels read the pose from the bundle's device tensors (pnr_render_pose) and a
+    training step -- a NEW bundle object every time, as under nerfstudio -- issues no device-to-host read at all.  Same
+    image, same gradients as the path that reads the camera back."""
+    pts = small_scene(40000)
+    sd = {"neural_points.xyz": pts["xyz"], "neural_points.points_embeding": pts["embedding"],
+          "neural_points.points_conf": pts["conf"], "neural_points.points_dir": pts["dir"],
+          "neural_points.points_color": pts["color"], "neural_points.Rw2c": pts["Rw2c"]}
+    cfg = PointNerfConfig(ranges=list(synthetic.CHAIR_RANGES), max_o=410000, enable_collider=True,
+                          collider_params={"near_plane": 2.0, "far_plane": 6.0}, hip_single_camera_bundles=True)
+    model = PointNerf(cfg, point_state_dict=sd).to(gpu_device)
+    model.load_state_dict(synthetic.make_weights(0, sigma_scale=300.0, bias_scale=0.1), strict=False)
+    model.train()
+    model.neural_points.jitter = 0.0
+    image = torch.rand(24 * 24, 3, device=gpu_device)
+
+    def step(az):
+        campos, camrot, dirs = camera_rays(24, 24, az=az)
+        R = dirs.shape[0]
+        # as the datamanager builds it: no nears / fars (the collider writes them), the rotation as a [3,3] tensor
+        b = RayBundle(origins=campos[None].expand(R, 3).to(gpu_device), directions=dirs.to(gpu_device),
+                      metadata={"camrotc2w": camrot.to(gpu_device)})
+        model.zero_grad(set_to_none=True)
+        out = model(b)
+        sum(model.get_loss_dict(out, {"image": image}).values()).backward()
+        return out["coarse_raycolor"].detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters()
+                                                         if p.grad is not None}
+
+    step(35.0)                                  # the first bundle: the collider's planes are read once
+    reads = model.host_reads
+    rgb_a, g_a = step(150.0)
+    rgb_b, g_b = step(35.0)
+    assert model.host_reads == reads, "a single-camera step with known planes must not read anything back"
+    model.config.hip_single_camera_bundles = False
+    rgb_c, g_c = step(35.0)
+    assert model.host_reads == reads + 1
+    assert torch.equal(rgb_b, rgb_c) and not torch.equal(rgb_a, rgb_b)
+    assert set(g_b) == set(g_c)
+    for n in g_b:
+        assert torch.equal(g_b[n], g_c[n]), n
+    # eval: the shim's collider resets the near plane to 0 outside training -- another collider state, read once as well
+    model.config.hip_single_camera_bundles = True
+    model.eval()
+    with torch.no_grad():
+        campos, camrot, dirs = camera_rays(24, 24, az=35.0)
+        mk = lambda: RayBundle(origins=campos[None].expand(576, 3).to(gpu_device), directions=dirs.to(gpu_device),
+                               metadata={"camrotc2w": camrot.to(gpu_device)})
+        model(mk())
+        reads = model.host_reads
+        e1 = model(mk())["coarse_raycolor"]
+        assert model.host_reads == reads
+    ref = oracle.render(pts, synthetic.make_weights(0, sigma_scale=300.0, bias_scale=0.1), oracle_cfg(oracle),
+                        campos[None].expand(576, 3), dirs, 0.0, 6.0, camrot)
+    assert (e1.cpu() - ref["coarse_raycolor"]).abs().max().item() <= 1e-4
+
+
 def test_dropin_query_op_signature(oracle, gpu_device):
     """The 17-argument call of studio_utils.py:172-188, verbatim."""
     from pointnerf2studio_amd.neural_points import QueryWorldcoordsHIP
