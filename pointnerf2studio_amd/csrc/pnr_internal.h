@@ -147,10 +147,10 @@ struct CamSet {
 __device__ __forceinline__ unsigned jitter_key(const CamRef &cr, long long r)
 {
     if (!cr.gen_rays) return (unsigned)r;
-    const unsigned long long v = (unsigned long long)r / (unsigned long long)cr.n_pixels;
-    const unsigned long long i = (unsigned long long)r - v * (unsigned long long)cr.n_pixels;
-    const unsigned p = cr.pixels ? (unsigned)cr.pixels[cr.pix_per_view ? (unsigned long long)r : i] : (unsigned)i;
-    return (unsigned)(v * (unsigned long long)cr.frame_pixels + p);
+    const unsigned v = (unsigned)r / (unsigned)cr.n_pixels;       // (a call renders fewer than 2^31 rays)
+    const unsigned i = (unsigned)r - v * (unsigned)cr.n_pixels;
+    const unsigned p = cr.pixels ? (unsigned)cr.pixels[cr.pix_per_view ? (unsigned)r : i] : i;
+    return v * (unsigned)cr.frame_pixels + p;
 }
 __device__ __forceinline__ int cam_id(const CamRef &cr, long long r)
 {

@@ -76,14 +76,15 @@ RenderWs carve_render_ws(void *base, int64_t R, int64_t cap, int K, int64_t N, i
 // arithmetic per ray (diff_ray_marching.py:312-323): seg_j * (1 + jitter * (u_j - 0.5)); running sum (torch's CPU
 // cumsum accumulates float32 in double and rounds every prefix); + near; mid-points of consecutive end points.
 // `carry` (running double sum) and `e_prev` (end point of sample 64w - 1) flow from word to word.
+// jkey: jitter_key(cr, ray), computed ONCE per ray by the caller (it holds a division)
 __device__ __forceinline__ float sample_t(const CamRef &cr, const float *__restrict__ tab, float near_plane,
-                                          int64_t r, int D, int w, int lane, double &carry, float &e_prev)
+                                          unsigned jkey, int D, int w, int lane, double &carry, float &e_prev)
 {
     const int j = w * 64 + lane;
     if (cr.jitter == 0.0f) return j < D ? tab[j] : 0.f;
     float seg = 0.f;
     if (j < D) {
-        const float u = pnr_uniform(cr.seed, jitter_key(cr, r), (unsigned)j);
+        const float u = pnr_uniform(cr.seed, jkey, (unsigned)j);
         seg = tab[D + j] * (1.0f + cr.jitter * (u - 0.5f));
     }
     double s = (double)seg;
@@ -238,6 +239,7 @@ __global__ void __launch_bounds__(TPB) k_select(GridView g, CamRef cr, const flo
         // jittered parameters are a running sum from sample 0: the scan runs over every word up to wh, the probes
         // over [wl, wh] only
         const int w_first = jittered ? 0 : wl;
+        const unsigned jkey = jittered ? jitter_key(cr, r) : 0u;
 #pragma unroll
         for (int k = 0; k < MAXW; ++k) {
             occ[k] = 0ull;
@@ -245,7 +247,7 @@ __global__ void __launch_bounds__(TPB) k_select(GridView g, CamRef cr, const flo
             const int w = w_first + k;
             if (w > wh) continue;  // wave-uniform
             const int j = w * 64 + lane;
-            const float t = raypos ? 0.f : sample_t(cr, tmid, near_plane, r, D, w, lane, carry, e_prev);
+            const float t = raypos ? 0.f : sample_t(cr, tmid, near_plane, jkey, D, w, lane, carry, e_prev);
             if (j < D && w >= wl) {
                 float px, py, pz;
                 sample_pos(raypos, rd, cam, r, D, j, t, px, py, pz);
@@ -342,9 +344,10 @@ __global__ void __launch_bounds__(TPB) k_expand(CamRef cr, const float *__restri
         float e_prev = near_plane;
         // the ray's eight occupancy words: one 64-byte load, word w broadcast from lane w
         const unsigned long long mine = lane < 8 ? ray_bits[r * 8 + lane] : 0ull;
+        const unsigned jkey = cr.jitter != 0.0f ? jitter_key(cr, r) : 0u;
         for (int w = 0; w < nwords && base < SR; ++w) {
             const unsigned long long m = __shfl(mine, w, 64);
-            const float t = raypos ? 0.f : sample_t(cr, tmid, near_plane, r, D, w, lane, carry, e_prev);
+            const float t = raypos ? 0.f : sample_t(cr, tmid, near_plane, jkey, D, w, lane, carry, e_prev);
             if ((m >> lane) & 1ull) {
                 const int rank = base + __popcll(m & ((1ull << lane) - 1ull));
                 const int64_t s = (int64_t)off + rank;
