@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
 OBJ_DIR = os.path.join(PKG_DIR, "csrc", "_obj")
 
 SOURCES = ["pnr_scan.hip", "pnr_scene.hip", "pnr_query.hip", "pnr_shade.hip", "pnr_shade_fp32.hip", "pnr_shade_bf16.hip",
-           "pnr_render.hip", "pnr_train.hip"]
+           "pnr_render.hip", "pnr_train.hip", "pnr_train_chain.hip"]
 
 # -ffp-contract=off: the voxel coordinate, the sample position (o + d*t) and the neighbour distance
 # must be evaluated exactly as the reference / oracle do (no FMA contraction); the MLP runs on fp32
@@ -36,7 +36,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # per-file additions.  pnr_shade_fp32.hip: MFMA results in VGPRs rather than AGPRs -- every output value of the MLP is
 # read by vector-ALU code (LeakyReLU) right away, and one wave per SIMD does not overlap its own VALU and MFMA work
 # (tools/ub_mfma_dep.hip): the 512 v_accvgpr_read per tile that the AGPR form needs cost their full issue time.
-FILE_FLAGS = {"pnr_shade_fp32.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+FILE_FLAGS = {"pnr_shade_fp32.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+              "pnr_train_chain.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def hipcc() -> str:
@@ -56,6 +57,7 @@ def _stale(target: str, deps) -> bool:
 def build_library(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     headers = [os.path.join(CSRC, "pnr_internal.h"), os.path.join(CSRC, "pnr_shade_common.h"),
+               os.path.join(CSRC, "pnr_train_chain.h"),
                os.path.join(INCLUDE, "pnr.h"), os.path.abspath(__file__)]
     cc = hipcc()
     jobs = []

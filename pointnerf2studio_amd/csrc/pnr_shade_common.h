@@ -122,6 +122,11 @@ struct ShadeParams {
     // G1, G2 [rows,256] and their sizes in bytes
     float *tape[4];
     size_t tape_bytes[4];
+    // ... and the LeakyReLU masks of the same four layers as BITS, [layer][row][lane half][4 words]: word w of a row's
+    // half holds [activation > 0] of the features of output tiles 2 w, 2 w + 1 in accumulator order, the first at bit 31
+    // (what k_train_pairs_bwd shifts out as it walks the layers backwards); tape_bits_rows = rows per layer
+    unsigned *tape_bits;
+    size_t tape_bits_rows;
 };
 
 __device__ __forceinline__ float4 load_w(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff)

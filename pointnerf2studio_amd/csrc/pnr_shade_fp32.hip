@@ -201,14 +201,12 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
     const unsigned tblk = TAPE ? (unsigned)(uintptr_t)tape_lds + (unsigned)(wave * TAPE_WAVE_B) : 0u;
     const unsigned t_wr = tblk + (unsigned)((lane & 31) * TAPE_ROW_B + 16 * h);            // + block + 32 q
     const unsigned t_rd = tblk + (unsigned)((lane >> 3) * TAPE_ROW_B + (lane & 7) * 16);   // + block + 8 i rows
-    __amdgpu_buffer_rsrc_t trsrc[4];
-    if (TAPE) {
-#pragma unroll
-        for (int l = 0; l < 4; ++l)
-            trsrc[l] = __builtin_amdgcn_make_buffer_rsrc(P.tape[l], 0, (int)min(P.tape_bytes[l], (size_t)0xFFFFFFF0u),
-                                                         0x00020000);
-    }
-    unsigned tg[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // row offsets (in rows) of rows 8 i + l / 8
+    // descriptors of the tile's 32 tape rows (set per tile: offsets inside them stay small whatever the tape's size)
+    __amdgpu_buffer_rsrc_t trsrc[4], brsrc[4];
+    unsigned tg[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // rows 8 i + l / 8 of the tile: tape row - the tile's first
+    // the mask bits of the lane's own row (ShadeParams.tape_bits): one running word, four finished words per layer
+    unsigned sbw = 0u, sbq[4] = {0u, 0u, 0u, 0u};
+    unsigned brow = 0xFFFFFFFFu;   // the lane's tape row - the tile's first, 0xFFFFFFFF = none
     // block (layer pl, output tile pt), written one gap earlier, goes out: 8 lanes per row, whole 128-byte lines
     auto tape_flush = [&](int pl, int pt) {
         const int ld = pl == 1 ? 264 : 256;   // H2 carries the seven extra head inputs behind its 256 columns
@@ -224,8 +222,9 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
             o.z = __float_as_uint(v[i].z);
             o.w = __float_as_uint(v[i].w);
             // row tg[i] (0xFFFFFFFF: no such row -> beyond the descriptor's range, dropped), features 32 pt + 4 (l & 7)
-            const unsigned off = tg[i] == 0xFFFFFFFFu ? 0xFFFFFFF0u : tg[i] * (unsigned)(ld * 4) + 16u * (lane & 7);
-            __builtin_amdgcn_raw_buffer_store_b128(o, trsrc[pl], (int)off, 128 * pt, 0);
+            const unsigned off =
+                tg[i] == 0xFFFFFFFFu ? 0xFFFFFFF0u : tg[i] * (unsigned)(ld * 4) + 16u * (lane & 7) + 128u * (unsigned)pt;
+            __builtin_amdgcn_raw_buffer_store_b128(o, trsrc[pl], (int)off, 0, 0);
         }
     };
     // the 16 activations of output tile `tile` of layer `layer` (0..3) into block tile & 1; the block before it in the
@@ -239,6 +238,20 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
         for (int q = 0; q < 4; ++q) {
             const f32x4 v = {t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
             lds_write4(t_wr, v, (tile & 1) * TAPE_BLK_B + 32 * q);
+        }
+        // [value > 0] shifted into the running word (compare into vcc, add-with-carry: word = 2 word + bit)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(sbw) : "v"(t[r]) : "vcc");
+        if (tile & 1) sbq[tile >> 1] = sbw;
+        if (tile == 7) {
+            u32x4 o;
+            o.x = sbq[0];
+            o.y = sbq[1];
+            o.z = sbq[2];
+            o.w = sbq[3];
+            const unsigned off = brow == 0xFFFFFFFFu ? 0xFFFFFFF0u : brow * 32u + 16u * (unsigned)h;
+            __builtin_amdgcn_raw_buffer_store_b128(o, brsrc[layer], (int)off, 0, 0);
         }
     };
 
@@ -273,12 +286,21 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
         if (TAPE) {
             // tape rows of the tile rows 8 i + l / 8 this lane stores: (valid sample) * K + slot
             constexpr int L = SEG ? SEG : 32;
-            const int v_wave0 = V0 + tile * SPT + wave * (SPT / WAVES);
+            const int v_wave0 = __builtin_amdgcn_readfirstlane(V0 + tile * SPT + wave * (SPT / WAVES));
+            const int64_t row_base = (int64_t)(v_wave0 - V0) * K;   // uniform: the tile's first tape row
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                const int ld = l == 1 ? 264 : 256;
+                trsrc[l] = __builtin_amdgcn_make_buffer_rsrc(P.tape[l] + row_base * ld, 0, 32 * ld * 4, 0x00020000);
+                brsrc[l] = __builtin_amdgcn_make_buffer_rsrc(
+                    P.tape_bits + ((int64_t)l * (int64_t)P.tape_bits_rows + row_base) * 8, 0, 32 * 32, 0x00020000);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 8 * i + (lane >> 3), sl = r / L, slot = r - sl * L, v = v_wave0 + sl;
-                tg[i] = (slot < K && v < S_valid) ? (unsigned)((v - V0) * K + slot) : 0xFFFFFFFFu;
+                tg[i] = (slot < K && v < S_valid) ? (unsigned)(sl * K + slot) : 0xFFFFFFFFu;
             }
+            brow = ctx.row_ok ? (unsigned)((ctx.v_idx - v_wave0) * K + ctx.slot) : 0xFFFFFFFFu;
         }
         fetch_a<SEG>(P, walk.at(n + 1), lane, wave, V0, S_valid, nxt);   // a tile past the end loads row 0: harmless
         f32x16 acc[8];

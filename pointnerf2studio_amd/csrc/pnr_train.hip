@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "pnr_shade_common.h"
+#include "pnr_train_chain.h"
 
 namespace pnr {
 
@@ -770,7 +771,10 @@ static const int W_OUT[9] = {256, 256, 256, 256, 1, 128, 128, 128, 3};
 static const int W_IN[9] = {284, 256, 263, 256, 256, 280, 128, 128, 128};
 static const int W_LD[9] = {288, 256, 264, 256, 256, 288, 128, 128, 128};
 
-constexpr int MAX_SPLIT_WGS = 768;                                  // workgroups of one weight-gradient GEMM
+#ifndef PNR_SPLIT_WGS
+#define PNR_SPLIT_WGS 768
+#endif
+constexpr int MAX_SPLIT_WGS = PNR_SPLIT_WGS;                        // workgroups of one weight-gradient GEMM
 constexpr size_t PART_FLOATS = (size_t)MAX_SPLIT_WGS * TM * TN;     // their partial tiles
 constexpr size_t CSUM_FLOATS = (size_t)MAX_SPLIT_WGS * 256;         // + one partial bias-gradient row per split
 
@@ -799,6 +803,13 @@ struct TrainWs {
     int *pt_cursor;   // [rows]
     int *pt_rows;     // [rows] row ids grouped by point
     void *pt_scan;    // scan scratch
+    // exact mode (k_train_pairs_bwd, pnr_train_chain.hip): the gradients at the four pre-activations of the pair MLPs
+    // [rows, 256] each, the per-row point gradients [rows, 40] and the chain's packed W^T stream
+    float *D3, *D2, *D1, *D0;
+    float *rowgrad;
+    float *chainW;
+    unsigned *tape_bits;   // [4 layers: H1, H2, G1, G2][rows][2 lane halves][4]: LeakyReLU masks as bits (ShadeParams.tape_bits)
+    size_t bits_rows;      // rows per layer
     size_t total;
 };
 
@@ -853,15 +864,26 @@ static TrainWs carve_train_ws(void *base, int64_t cap, int K)
     w.pt_cursor = (int *)take(rows * 4);
     w.pt_rows = (int *)take(rows * 4);
     w.pt_scan = take(scan_temp_bytes((int64_t)rows + 1));
+    w.D3 = (float *)take(rows * LD_H * 4);
+    w.D2 = (float *)take(rows * LD_H * 4);
+    w.D1 = (float *)take(rows * LD_H * 4);
+    w.D0 = (float *)take(rows * LD_H * 4);
+    w.rowgrad = (float *)take(rows * 40 * 4);
+    w.chainW = (float *)take((CHAIN_W_FLOATS + 256) * 4);
+    w.tape_bits = (unsigned *)take(rows * 128);
+    w.bits_rows = rows;
     w.total = off;
     return w;
 }
 
-bool train_tape_ptrs(void *d_train_workspace, size_t bytes, int64_t cap, int K, float *tape[4], size_t tape_bytes[4])
+bool train_tape_ptrs(void *d_train_workspace, size_t bytes, int64_t cap, int K, float *tape[4], size_t tape_bytes[4],
+                     unsigned **tape_bits, size_t *tape_bits_rows)
 {
     if (!d_train_workspace || carve_train_ws(nullptr, cap, K).total > bytes) return false;
     const TrainWs w = carve_train_ws(d_train_workspace, cap, K);
     const size_t rows = (size_t)cap * K + TM;
+    *tape_bits = w.tape_bits;
+    *tape_bits_rows = w.bits_rows;
     tape[0] = w.H1;
     tape[1] = w.H2;
     tape[2] = w.G1;
@@ -1333,6 +1355,7 @@ __global__ void __launch_bounds__(256) k_reduce_rows(const float *__restrict__ p
 
 // density head + K-aggregation backwards (dAGG arrives in XC[:, 0:256], d sigma in d_out.x):
 //   dG2 = w (dAGG + d sigma * [z > 0] * w4);  G2 <- dG2 * LeakyReLU'(G2) (in place);  dw4, db4 accumulated
+template <bool WRITE>
 __global__ void __launch_bounds__(256) k_train_head_agg_bwd(TrainWs w, int K, const float *__restrict__ w4)
 {
     const int lane = threadIdx.x & 63;
@@ -1355,12 +1378,14 @@ __global__ void __launch_bounds__(256) k_train_head_agg_bwd(TrainWs w, int K, co
             dw.z += coef * gq.z;
             dw.w += coef * gq.w;
             db += coef;
-            float4 o;
-            o.x = (wk * da.x + coef * wq.x) * (gq.x > 0.f ? 1.0f : 0.1f);
-            o.y = (wk * da.y + coef * wq.y) * (gq.y > 0.f ? 1.0f : 0.1f);
-            o.z = (wk * da.z + coef * wq.z) * (gq.z > 0.f ? 1.0f : 0.1f);
-            o.w = (wk * da.w + coef * wq.w) * (gq.w > 0.f ? 1.0f : 0.1f);
-            *gp = o;
+            if (WRITE) {   // (exact mode: k_train_pairs_bwd forms dZ4 in registers, G2 stays the tape)
+                float4 o;
+                o.x = (wk * da.x + coef * wq.x) * (gq.x > 0.f ? 1.0f : 0.1f);
+                o.y = (wk * da.y + coef * wq.y) * (gq.y > 0.f ? 1.0f : 0.1f);
+                o.z = (wk * da.z + coef * wq.z) * (gq.z > 0.f ? 1.0f : 0.1f);
+                o.w = (wk * da.w + coef * wq.w) * (gq.w > 0.f ? 1.0f : 0.1f);
+                *gp = o;
+            }
         }
     }
     // per-workgroup partial rows, summed by k_reduce_head (8192 waves x 257 atomics on 257 addresses took 0.8 ms whatever
@@ -1968,26 +1993,74 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
     gemm_weight(st, bf, tw.C1, LD_C, tw.XC, LD_XC, tw.dWp[5], 288, 128, 288, n_smp, smp_max, tw.dbp[5], tw.part);
     gemm_data(st, bf, tw.C1, LD_C, tw.Wp[5], 288, tw.WT[5], tw.XC, LD_XC, 256, 128, 0, n_smp, smp_max);   // XC[:, :256] <- dAGG
     // density head + aggregation
-    hipLaunchKernelGGL(k_train_head_agg_bwd, dim3(1024), eb, 0, st, tw, K, d_w[4]);          // G2 <- dZ4
-    hipLaunchKernelGGL(k_reduce_rows, dim3((257 + 15) / 16), eb, 0, st, tw.part, 1024, 260, 257, 256, tw.dWp[4], tw.dbp[4]);
-    // mlp_head
-    gemm_weight(st, bf, tw.G2, LD_H, tw.G1, LD_H, tw.dWp[3], 256, 256, 256, n_rows, rows_max, tw.dbp[3], tw.part);
-    gemm_data(st, bf, tw.G2, LD_H, tw.Wp[3], 256, tw.WT[3], tw.G1, LD_H, 256, 256, 256, n_rows, rows_max, sgG1);   // G1 <- dZ3
-    gemm_weight(st, bf, tw.G1, LD_H, tw.H2, LD_H2, tw.dWp[2], 264, 256, 264, n_rows, rows_max, tw.dbp[2], tw.part);
-    gemm_data(st, bf, tw.G1, LD_H, tw.Wp[2], 264, tw.WT[2], tw.H2, LD_H2, 264, 256, 256, n_rows, rows_max, sgH2);  // H2 <- [dZ2 | d extras]
-    // mlp_base
-    gemm_weight(st, bf, tw.H2, LD_H2, tw.H1, LD_H, tw.dWp[1], 256, 256, 256, n_rows, rows_max, tw.dbp[1], tw.part);
-    gemm_data(st, bf, tw.H2, LD_H2, tw.Wp[1], 256, tw.WT[1], tw.H1, LD_H, 256, 256, 256, n_rows, rows_max, sgH1);  // H1 <- dZ1
-    gemm_weight(st, bf, tw.H1, LD_H, tw.X0, LD_X0, tw.dWp[0], 288, 256, 288, n_rows, rows_max, tw.dbp[0], tw.part);
-    gemm_data(st, bf, tw.H1, LD_H, tw.Wp[0], 288, tw.WT[0], tw.G2, LD_H, 224, 256, 0, n_rows, rows_max);     // G2 <- dX0[:, :224]
-    // point tensors: per-row gradients into H1 (its dZ1 is consumed), rows grouped by point, one ordered sum per point
-    if (grads->d_embedding || grads->d_color || grads->d_dir || grads->d_point_grads) {
-        PNR_REQUIRE(!grads->d_point_grads || (grads->d_point_index && grads->point_cap >= 1),
-                    "%s: sparse point gradients need d_point_index and point_cap", who);
-        float *rowgrad = tw.H1;
+    const bool want_points = grads->d_embedding || grads->d_color || grads->d_dir || grads->d_point_grads;
+    PNR_REQUIRE(!grads->d_point_grads || (grads->d_point_index && grads->point_cap >= 1),
+                "%s: sparse point gradients need d_point_index and point_cap", who);
+    float *rowgrad = nullptr;
+    if (!bf && K == 8) {
+        // exact mode, K = 8 (32-row tiles hold whole samples: the geometry of k_shade_pairs<8>, whose tape writer leaves
+        // the mask bits): the whole data-gradient chain of the pair MLPs in one kernel (pnr_train_chain.hip).  dw4 / db4
+        // first (the tape G2 is read, nothing is written over it), then the chain: D3..D0 = the gradients at the four
+        // pre-activations, rowgrad = the rows' point gradients, pt_cnt = rows per touched point
+        if (!taped) launch_tape_bits(tw.cnt, tw.H1, tw.H2, tw.G1, tw.G2, tw.bits_rows, tw.tape_bits, st);
+        hipLaunchKernelGGL(k_train_head_agg_bwd<false>, dim3(1024), eb, 0, st, tw, K, d_w[4]);
+        hipLaunchKernelGGL(k_reduce_rows, dim3((257 + 15) / 16), eb, 0, st, tw.part, 1024, 260, 257, 256, tw.dWp[4], tw.dbp[4]);
+        launch_pack_chain(d_w[0], d_w[1], d_w[2], d_w[3], d_w[4], tw.chainW, st);
         PNR_HIP_CHECK(hipMemsetAsync(tw.pt_cnt, 0, (size_t)(rows_max + 1) * 4, st));
         PNR_HIP_CHECK(hipMemsetAsync(tw.pt_cursor, 0, (size_t)rows_max * 4, st));
-        hipLaunchKernelGGL(k_train_rowgrad, eg, eb, 0, st, P, tw, ws.pt_rank, rowgrad);
+        ChainParams C{};
+        C.wchain = tw.chainW;
+        C.w4acc = tw.chainW + CHAIN_W_FLOATS;
+        C.cnt = tw.cnt;
+        C.row_pidx = tw.row_pidx;
+        C.row_w = tw.row_w;
+        C.row_z = tw.row_z;
+        C.d_out = tw.d_out;
+        C.XC = tw.XC;
+        C.tape_bits = tw.tape_bits;
+        C.bits_rows = tw.bits_rows;
+        C.X0 = tw.X0;
+        C.D3 = tw.D3;
+        C.D2 = tw.D2;
+        C.D1 = tw.D1;
+        C.D0 = tw.D0;
+        C.rowgrad = tw.rowgrad;
+        C.pt_rank = ws.pt_rank;
+        C.pt_cnt = tw.pt_cnt;
+        C.vs_list = ws.vs_list;
+        C.smp_ray = ws.smp_ray;
+        C.dirs = d_dirs;
+        for (int i = 0; i < 9; ++i) C.Rw2c[i] = weights->Rw2c[i];
+        C.K = K;
+        launch_pairs_bwd(C, rows_max, st);
+        gemm_weight(st, bf, tw.D3, LD_H, tw.G1, LD_H, tw.dWp[3], 256, 256, 256, n_rows, rows_max, tw.dbp[3], tw.part);
+        gemm_weight(st, bf, tw.D2, LD_H, tw.H2, LD_H2, tw.dWp[2], 264, 256, 264, n_rows, rows_max, tw.dbp[2], tw.part);
+        gemm_weight(st, bf, tw.D1, LD_H, tw.H1, LD_H, tw.dWp[1], 256, 256, 256, n_rows, rows_max, tw.dbp[1], tw.part);
+        gemm_weight(st, bf, tw.D0, LD_H, tw.X0, LD_X0, tw.dWp[0], 288, 256, 288, n_rows, rows_max, tw.dbp[0], tw.part);
+        rowgrad = tw.rowgrad;
+    } else {
+        hipLaunchKernelGGL(k_train_head_agg_bwd<true>, dim3(1024), eb, 0, st, tw, K, d_w[4]);          // G2 <- dZ4
+        hipLaunchKernelGGL(k_reduce_rows, dim3((257 + 15) / 16), eb, 0, st, tw.part, 1024, 260, 257, 256, tw.dWp[4], tw.dbp[4]);
+        // mlp_head
+        gemm_weight(st, bf, tw.G2, LD_H, tw.G1, LD_H, tw.dWp[3], 256, 256, 256, n_rows, rows_max, tw.dbp[3], tw.part);
+        gemm_data(st, bf, tw.G2, LD_H, tw.Wp[3], 256, tw.WT[3], tw.G1, LD_H, 256, 256, 256, n_rows, rows_max, sgG1);   // G1 <- dZ3
+        gemm_weight(st, bf, tw.G1, LD_H, tw.H2, LD_H2, tw.dWp[2], 264, 256, 264, n_rows, rows_max, tw.dbp[2], tw.part);
+        gemm_data(st, bf, tw.G1, LD_H, tw.Wp[2], 264, tw.WT[2], tw.H2, LD_H2, 264, 256, 256, n_rows, rows_max, sgH2);  // H2 <- [dZ2 | d extras]
+        // mlp_base
+        gemm_weight(st, bf, tw.H2, LD_H2, tw.H1, LD_H, tw.dWp[1], 256, 256, 256, n_rows, rows_max, tw.dbp[1], tw.part);
+        gemm_data(st, bf, tw.H2, LD_H2, tw.Wp[1], 256, tw.WT[1], tw.H1, LD_H, 256, 256, 256, n_rows, rows_max, sgH1);  // H1 <- dZ1
+        gemm_weight(st, bf, tw.H1, LD_H, tw.X0, LD_X0, tw.dWp[0], 288, 256, 288, n_rows, rows_max, tw.dbp[0], tw.part);
+        gemm_data(st, bf, tw.H1, LD_H, tw.Wp[0], 288, tw.WT[0], tw.G2, LD_H, 224, 256, 0, n_rows, rows_max);     // G2 <- dX0[:, :224]
+        // per-row point gradients into H1 (its dZ1 is consumed)
+        if (want_points) {
+            rowgrad = tw.H1;
+            PNR_HIP_CHECK(hipMemsetAsync(tw.pt_cnt, 0, (size_t)(rows_max + 1) * 4, st));
+            PNR_HIP_CHECK(hipMemsetAsync(tw.pt_cursor, 0, (size_t)rows_max * 4, st));
+            hipLaunchKernelGGL(k_train_rowgrad, eg, eb, 0, st, P, tw, ws.pt_rank, rowgrad);
+        }
+    }
+    // point tensors: rows grouped by point, one ordered sum per point
+    if (want_points) {
         int rcs = scan_exclusive_i32(tw.pt_cnt, tw.pt_start, rows_max, ws.n_sel + 3, nullptr, tw.pt_scan, st);
         if (rcs != PNR_OK) return rcs;
         hipLaunchKernelGGL(k_train_fill, dim3(1024), eb, 0, st, tw, ws.pt_rank);
