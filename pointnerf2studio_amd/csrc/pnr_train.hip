@@ -330,6 +330,141 @@ __global__ void __launch_bounds__(256, PNR_GEMM_WGS) k_gemm(GemmArgs g)
     }
 }
 
+// Weight gradients of the 256-wide layers (the four pair-level Linears): C[256, N] (partial of split z) = sum over the
+// split's rows k of dZ[k][m] X[k][n].  k_gemm<true> tiles N in 128 columns: N = 264 and 288 (mlp_head.0 with its seven
+// extra inputs, mlp_base.0 with the 60 encoded distances) then pay a third column tile for 8 / 32 columns -- 1.8 ms
+// against 1.2 for N = 256 at 65 536 rays.  Here a workgroup owns all 256 rows of dW and NB x 32 columns (3 x 32 = 96:
+// 288 = 3 x 96 exactly, 264 in three tiles with 9 % padding instead of 45 %; 4 x 32 for N = 256), a wave 64 rows:
+// 2 x NB accumulators, 2 + NB LDS reads per 2 NB MFMAs.  Same pipeline as k_gemm: two register stages, two LDS
+// buffers, branch-free loads, barriers that wait for LDS only; partial tiles in k_reduce_parts' layout, stored straight
+// from the accumulators (a row of 32 columns is one 128-byte segment; once per ~350 chunks).
+template <int NB>
+__global__ void __launch_bounds__(256, 2) k_wgrad256(GemmArgs g)
+{
+    constexpr int WN = 32 * NB, LDA = 256 + 4, LDB = WN + 4;
+    constexpr int NLB = (TK * WN / 4 + 255) / 256;   // float4 loads per thread for the B tile (the last one partial)
+    __shared__ float As[2][TK][LDA];
+    __shared__ float Bs[2][TK][LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int rows = *g.dev_rows, N = g.N;
+    const int n0 = blockIdx.y * WN;
+    const int nz = active_splits(rows, gridDim.z);
+    if ((int)blockIdx.z >= nz) return;
+    const int chunk = ((rows + nz - 1) / nz + TK - 1) / TK * TK;
+    const int k_begin = min(rows, (int)blockIdx.z * chunk), k_end = min(rows, k_begin + chunk);
+    if (k_begin >= k_end) return;
+    float4 ra[2][TK / 4], rb[2][NLB];
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool want_csum = g.colsum && blockIdx.y == 0;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int ar = tid >> 6, ac = (tid & 63) * 4;                    // A: rows ar + 4 i, columns ac .. ac + 3
+    auto load_tiles = [&](int k0, auto par) {
+        constexpr int P = decltype(par)::value;
+#pragma unroll
+        for (int i = 0; i < TK / 4; ++i) {
+            const int k = min(k0 + ar + 4 * i, k_end - 1);
+            ra[P][i] = *reinterpret_cast<const float4 *>(g.A + (int64_t)k * g.lda + ac);
+        }
+#pragma unroll
+        for (int i = 0; i < NLB; ++i) {
+            const int idx = min(tid + 256 * i, TK * WN / 4 - 1);
+            const int br = idx / (WN / 4), bc = (idx - br * (WN / 4)) * 4;
+            const int k = min(k0 + br, k_end - 1), n = min(n0 + bc, N - 4);
+            rb[P][i] = *reinterpret_cast<const float4 *>(g.B + (int64_t)k * g.ldb + n);
+        }
+    };
+    auto store_tiles = [&](int buf, int k0, auto par) {
+        constexpr int P = decltype(par)::value;
+#pragma unroll
+        for (int i = 0; i < TK / 4; ++i) {
+            const float4 v = (k0 + ar + 4 * i < k_end) ? ra[P][i] : z4;
+            *reinterpret_cast<float4 *>(&As[buf][ar + 4 * i][ac]) = v;
+            if (want_csum) {
+                csum.x += v.x;
+                csum.y += v.y;
+                csum.z += v.z;
+                csum.w += v.w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NLB; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < TK * WN / 4) {
+                const int br = idx / (WN / 4), bc = (idx - br * (WN / 4)) * 4;
+                const float4 v = (k0 + br < k_end && n0 + bc < N) ? rb[P][i] : z4;
+                *reinterpret_cast<float4 *>(&Bs[buf][br][bc]) = v;
+            }
+        }
+    };
+    auto lds_barrier = [] {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    auto mfma_chunk = [&](int buf) {
+#pragma unroll
+        for (int kk = 0; kk < TK; kk += 2) {
+            const float a0 = As[buf][kk + h][wave * 64 + j], a1 = As[buf][kk + h][wave * 64 + 32 + j];
+            float bv[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) bv[b] = Bs[buf][kk + h][32 * b + j];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[b], acc[0][b], 0, 0, 0);
+                acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[b], acc[1][b], 0, 0, 0);
+            }
+        }
+    };
+    typedef std::integral_constant<int, 0> P0;
+    typedef std::integral_constant<int, 1> P1;
+    const int nchunks = (k_end - k_begin + TK - 1) / TK;
+    load_tiles(k_begin, P0());
+    load_tiles(k_begin + TK, P1());
+    store_tiles(0, k_begin, P0());
+    lds_barrier();
+    for (int c = 0; c < nchunks; c += 2) {
+        const int k0 = k_begin + c * TK;
+        load_tiles(k0 + 2 * TK, P0());
+        mfma_chunk(0);
+        store_tiles(1, k0 + TK, P1());
+        lds_barrier();
+        load_tiles(k0 + 3 * TK, P1());
+        mfma_chunk(1);
+        store_tiles(0, k0 + 2 * TK, P0());
+        lds_barrier();
+    }
+    if (want_csum) {
+        // bias gradient: the four row groups' partial rows through LDS, added in a fixed order (bitwise repeatable)
+        float *cs = &As[0][0][0];
+        __syncthreads();
+        *reinterpret_cast<float4 *>(&cs[ar * 256 + ac]) = csum;
+        __syncthreads();
+        g.colsum[(int64_t)blockIdx.z * 256 + tid] = ((cs[tid] + cs[256 + tid]) + cs[512 + tid]) + cs[768 + tid];
+    }
+    // partial tile of split z: [256, ldc] block, columns n0 .. n0 + WN
+    float *cp = g.C + (int64_t)blockIdx.z * 256 * g.ldc;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int col = n0 + 32 * b + j;
+            if (col < N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wave * 64 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    cp[(int64_t)row * g.ldc + col] = acc[a][b][r];
+                }
+            }
+        }
+}
+
 // dst[m][n] += sum over the active splits of part[z][m][n]  (part: [nz, M, ld], dst: [M, ld]);
 // db[m] += sum over the active splits of csum[z][m]
 __global__ void __launch_bounds__(256) k_reduce_parts(const float *__restrict__ part, const float *__restrict__ csum,
@@ -1074,8 +1209,11 @@ __global__ void __launch_bounds__(256) k_train_rows(TrainParams P, TrainWs w)
                         dv = d == 5 ? dd[5] : dv;
                         arg = dv * (float)(1 << f);
                     }
+                    // the exact mode's render encodes with the branch-free Cody-Waite sincos, every octave from its own
+                    // argument (point_inputs / pair_inputs<.., true, false>): the same function here, so the taped inputs
+                    // are the ones the render multiplied (libm's sincosf: ~150 instructions a call, half this kernel)
                     float sn, cs;
-                    sincosf(arg, &sn, &cs);
+                    fast_sincos_nb(arg, sn, cs);
                     *reinterpret_cast<float2 *>(x0 + 32 + 2 * u) = valid ? make_float2(sn, cs) : make_float2(0.f, 0.f);
                 }
             }
@@ -1629,6 +1767,14 @@ static void gemm_weight(hipStream_t st, bool bf, const float *dZ, int lda, const
     if (bf) {
         const dim3 grid((unsigned)((M + TM - 1) / TM), (unsigned)((N + TN - 1) / TN), (unsigned)nsplit);
         hipLaunchKernelGGL(k_gemm_tn_bf16x3, grid, dim3(256), 0, st, g);
+    } else if (M == 256 && N % 128 != 0) {
+        // mlp_head.0 (N = 264) and mlp_base.0 (N = 288): whole-M tiles of 96 columns (k_wgrad256<3>: 1.34 ms against the
+        // 1.8 of three 128-column tiles at 65 536 rays; at N = 256 the 128 x 128 tiles of k_gemm are the faster ones, 1.22
+        // against 1.50 for k_wgrad256<4>), about one round of 512 workgroups
+        const int nt = (N + 95) / 96;
+        nsplit = (int)std::min<int64_t>(std::max<int64_t>(1, 512 / nt), (rows_max + 4 * TK - 1) / (4 * TK));
+        while ((size_t)nsplit * M * ldw > PART_FLOATS && nsplit > 1) --nsplit;
+        hipLaunchKernelGGL(k_wgrad256<3>, dim3(1u, (unsigned)nt, (unsigned)nsplit), dim3(256), 0, st, g);
     } else {
         gemm<true, false, EPI_PARTIAL>(st, g, M, nsplit);
     }

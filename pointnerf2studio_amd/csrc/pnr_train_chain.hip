@@ -28,6 +28,11 @@ namespace pnr {
 #ifndef PNR_CPFS
 #define PNR_CPFS 6
 #endif
+#ifdef PNR_CHAIN_EXP_NO_X0   // (timing experiments: results are wrong)
+#define PNR_CHAIN_X0_FIRST 32
+#else
+#define PNR_CHAIN_X0_FIRST 0
+#endif
 constexpr int CPFS = PNR_CPFS;
 static_assert(CNG_TILE % CPFS == 0, "the window slot of a group must not depend on the tile");
 constexpr int CT_ROW_B = 144, CT_BLK_B = 32 * CT_ROW_B, CT_WAVE_B = 2 * CT_BLK_B;   // as the render's tape writer
@@ -93,6 +98,7 @@ __device__ __forceinline__ void chain_layer(__amdgpu_buffer_rsrc_t rsrc, int vof
 constexpr int CX_ROW_B = 784, CX_BLK_B = 32 * CX_ROW_B;
 constexpr int CG_ROW_B = 176, CG_BLK_B = 32 * CG_ROW_B;
 constexpr int CHAIN_WAVE_B = CT_WAVE_B + CX_BLK_B + CG_BLK_B;   // 39 936
+constexpr int CHAIN_LDS_B = WAVES * CHAIN_WAVE_B + 1024;        // + the density head in accumulator order, shared
 
 __global__ void __launch_bounds__(TPB, 1) k_train_pairs_bwd(ChainParams P)
 {
@@ -108,6 +114,7 @@ __global__ void __launch_bounds__(TPB, 1) k_train_pairs_bwd(ChainParams P)
     const unsigned t_wr = tblk + (unsigned)(j * CT_ROW_B + 16 * h);                      // + block + 32 q
     const unsigned t_rd = tblk + (unsigned)((lane >> 3) * CT_ROW_B + (lane & 7) * 16);   // + block + 8 i rows
     const unsigned xblk = tblk + CT_WAVE_B, gblk = xblk + CX_BLK_B;
+    const unsigned w4lds = (unsigned)(uintptr_t)chain_lds + (unsigned)(WAVES * CHAIN_WAVE_B) + 64u * (unsigned)h;   // + 128 m + 16 q
     const unsigned x_rd = xblk + (unsigned)(j * CX_ROW_B + 48 * h);                      // + 96 m: 48 bytes of the lane
     const unsigned g_wr = gblk + (unsigned)(j * CG_ROW_B);
 
@@ -121,6 +128,15 @@ __global__ void __launch_bounds__(TPB, 1) k_train_pairs_bwd(ChainParams P)
         for (int p = 0; p < CPFS; ++p) wq[p] = load_w(rsrc, voff, goff(p));
     }
     const f32x2 k01 = {0.1f, 0.1f};
+    // the density head (1 KiB, [(tile * 2 + h) * 16 + r]) into LDS once: read per output tile of the prologue as LDS
+    // reads, which do not queue behind the prologue's memory loads
+    if (threadIdx.x < 64) {
+        const float4 w = *reinterpret_cast<const float4 *>(P.w4acc + 4 * lane);
+        const f32x4 wv = {w.x, w.y, w.z, w.w};
+        asm volatile("ds_write_b128 %0, %1" ::"v"((unsigned)(uintptr_t)chain_lds + (unsigned)(WAVES * CHAIN_WAVE_B) + 16u * (unsigned)lane),
+                     "v"(wv));
+    }
+    __syncthreads();
 
     for (int tile = (int)blockIdx.x; tile < ntiles; tile += (int)gridDim.x) {
         // ---- the wave's 32 rows: rows beyond the call's last one read the last row and store nothing ------------------
@@ -148,7 +164,7 @@ __global__ void __launch_bounds__(TPB, 1) k_train_pairs_bwd(ChainParams P)
             const float *x0l = P.X0 + (int64_t)row0c * 288 + 32 + 4 * l48;
             const unsigned xw = xblk + 16u * (unsigned)l48;
 #pragma unroll
-            for (int rr = 0; rr < 32; ++rr) {
+            for (int rr = PNR_CHAIN_X0_FIRST; rr < 32; ++rr) {
                 const int rrc = min(row0 + rr, n_rows - 1) - row0c;   // uniform
                 const float4 x = *reinterpret_cast<const float4 *>(x0l + rrc * 288);
                 const f32x4 xv = {x.x, x.y, x.z, x.w};
@@ -177,7 +193,6 @@ __global__ void __launch_bounds__(TPB, 1) k_train_pairs_bwd(ChainParams P)
         const __amdgpu_buffer_rsrc_t rG =
             __builtin_amdgcn_make_buffer_rsrc(P.rowgrad + (int64_t)row0c * 40, 0, nv * 160, 0x00020000);
         const float *xc = P.XC + (int64_t)v * 288 + 4 * h;
-        const float *w4h = P.w4acc + 16 * h;
 
         // block (layer pl, output tile pt), written one gap earlier, goes out: 8 lanes per row, whole 128-byte lines
         auto tape_flush = [&](int pl, int pt) {
@@ -193,7 +208,11 @@ __global__ void __launch_bounds__(TPB, 1) k_train_pairs_bwd(ChainParams P)
                 o.z = __float_as_uint(t[i].z);
                 o.w = __float_as_uint(t[i].w);
                 const int off = (8 * i + (lane >> 3)) * 1024 + 16 * (lane & 7) + 128 * pt;
+#ifndef PNR_CHAIN_EXP_NO_ST
                 __builtin_amdgcn_raw_buffer_store_b128(o, rD[pl], off, 0, 0);
+#else
+                if (n_rows < 0) __builtin_amdgcn_raw_buffer_store_b128(o, rD[pl], off, 0, 0);
+#endif
             }
         };
         auto tape_tile = [&](int layer, int tt, const float (&t)[16]) {
@@ -233,13 +252,28 @@ __global__ void __launch_bounds__(TPB, 1) k_train_pairs_bwd(ChainParams P)
         float X[128], Y[128];
         f32x16 acc[9];
         // ---- dZ3 = w (dAGG + d sigma [z > 0] w4) * L'(G2): the lane's 128 features of its row --------------------------
+        // the row's 128 values of dAGG in ONE burst of loads (the staging asm of the loop below is a compiler barrier for
+        // memory operations: loads left inside it were issued and waited for one at a time, ~16 us per tile)
+        float4 dagg[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+#ifndef PNR_CHAIN_EXP_NO_XC
+            dagg[i] = *reinterpret_cast<const float4 *>(xc + 32 * (i >> 2) + 8 * (i & 3));
+#else
+            dagg[i] = make_float4(dsig, wk, coef, vx);   // (timing experiment)
+#endif
+        }
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
+            f32x4 w4v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w4v[q] = c_lds_read4(w4lds + 128u * (unsigned)m, 16 * q);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w4v[0]), "+v"(w4v[1]), "+v"(w4v[2]), "+v"(w4v[3])::"memory");
             f32x16 pre;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 da = *reinterpret_cast<const float4 *>(xc + 32 * m + 8 * q);
-                const float4 wv = *reinterpret_cast<const float4 *>(w4h + 32 * m + 4 * q);
+                const float4 da = dagg[4 * m + q];
+                const f32x4 wv = w4v[q];
                 pre[4 * q + 0] = wk * da.x + coef * wv.x;
                 pre[4 * q + 1] = wk * da.y + coef * wv.y;
                 pre[4 * q + 2] = wk * da.z + coef * wv.z;
@@ -477,9 +511,9 @@ void launch_pairs_bwd(const ChainParams &P, int64_t rows_max, hipStream_t st)
     const int64_t tiles = (rows_max + 127) / 128;
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cus, tiles));
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(k_train_pairs_bwd),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, WAVES * CHAIN_WAVE_B);
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_B);
     (void)attr;
-    hipLaunchKernelGGL(k_train_pairs_bwd, dim3(grid), dim3(TPB), (size_t)WAVES * CHAIN_WAVE_B, st, P);
+    hipLaunchKernelGGL(k_train_pairs_bwd, dim3(grid), dim3(TPB), (size_t)CHAIN_LDS_B, st, P);
 }
 
 void launch_tape_bits(const int *cnt, const float *H1, const float *H2, const float *G1, const float *G2, size_t bits_rows,
