@@ -153,12 +153,11 @@ __device__ __forceinline__ int active_splits(int rows, int nz_grid)
     return min(nz_grid, max(1, (rows + MIN_ROWS_PER_SPLIT - 1) / MIN_ROWS_PER_SPLIT));
 }
 
+// the body of k_gemm for workgroup (bx, by, bz) of a (gx, ., gz) grid: also run by the batched weight-gradient launch
 template <bool TA, bool TB, int EPI>
-__global__ void __launch_bounds__(256, PNR_GEMM_WGS) k_gemm(GemmArgs g)
+__device__ __forceinline__ void gemm_body(const GemmArgs &g, int bx, int by, int bz, int gx, int gz,
+                                          float (&As)[2][TK][LDT], float (&Bs)[2][TK][LDT])
 {
-    __shared__ float As[2][TK][LDT];
-    static_assert(2 * TK * LDT >= 4096, "two 8-KiB epilogue regions per operand buffer");
-    __shared__ float Bs[2][TK][LDT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int rows = *g.dev_rows;
@@ -172,16 +171,16 @@ __global__ void __launch_bounds__(256, PNR_GEMM_WGS) k_gemm(GemmArgs g)
     // (an empty workgroup still costs ~2 us of a CU slot: 0.4 ms per GEMM at 114 k of them).
     const int n_nt = (N + TN - 1) / TN;
     const int total = TA ? 1 : n_nt * ((M + TM - 1) / TM);
-    for (int it = TA ? 0 : (int)blockIdx.x; it < total; it += TA ? 1 : (int)gridDim.x) {
-    const int m0 = (TA ? (int)blockIdx.x : it / n_nt) * TM, n0 = (TA ? (int)blockIdx.y : it % n_nt) * TN;
+    for (int it = TA ? 0 : bx; it < total; it += TA ? 1 : gx) {
+    const int m0 = (TA ? bx : it / n_nt) * TM, n0 = (TA ? by : it % n_nt) * TN;
     if (m0 >= M || n0 >= N) return;
     int k_begin = 0, k_end = TA ? rows : g.K;
     if (TA) {
-        // split of the reduction over gridDim.z, in multiples of TK
-        const int nz = active_splits(rows, gridDim.z);
-        if ((int)blockIdx.z >= nz) return;
+        // split of the reduction over gz, in multiples of TK
+        const int nz = active_splits(rows, gz);
+        if (bz >= nz) return;
         const int chunk = ((rows + nz - 1) / nz + TK - 1) / TK * TK;
-        k_begin = min(rows, (int)blockIdx.z * chunk);
+        k_begin = min(rows, bz * chunk);
         k_end = min(rows, k_begin + chunk);
         if (k_begin >= k_end) return;
     }
@@ -193,7 +192,7 @@ __global__ void __launch_bounds__(256, PNR_GEMM_WGS) k_gemm(GemmArgs g)
     // merges), barriers that wait for LDS only.  Two chunks per loop iteration; chunks beyond k_end are all-zero.
     float4 ra[2][NLD], rb[2][NLD];
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool want_csum = TA && g.colsum && blockIdx.y == 0;
+    const bool want_csum = TA && g.colsum && by == 0;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     auto load_tiles = [&](int k0, auto par) {
         constexpr int P = decltype(par)::value;
@@ -311,7 +310,7 @@ __global__ void __launch_bounds__(256, PNR_GEMM_WGS) k_gemm(GemmArgs g)
             float t = cs[tid];
 #pragma unroll
             for (int q = 1; q < 8; ++q) t += cs[q * TM + tid];
-            g.colsum[(int64_t)blockIdx.z * g.M + m0 + tid] = t;
+            g.colsum[(int64_t)bz * g.M + m0 + tid] = t;
         }
         __syncthreads();   // cs lies in the epilogue region of wave 0
     }
@@ -321,13 +320,23 @@ __global__ void __launch_bounds__(256, PNR_GEMM_WGS) k_gemm(GemmArgs g)
         // weight gradients: split z writes its partial [M, ldc] block; k_reduce_parts sums the blocks (12.6 M float
         // atomics per GEMM -- 768 workgroups x 16 K -- cost more than the GEMM itself at training-batch sizes)
         GemmArgs gp = g;
-        gp.C = g.C + (int64_t)blockIdx.z * g.M * g.ldc;
+        gp.C = g.C + (int64_t)bz * g.M * g.ldc;
         gemm_epilogue<EPI>(gp, acc, M, N, m0, n0, wm, wn, lane, lds_wave);
     } else {
         gemm_epilogue<EPI>(g, acc, M, N, m0, n0, wm, wn, lane, lds_wave);
     }
     __syncthreads();   // before the next tile's operands overwrite the epilogue regions
     }
+}
+
+
+template <bool TA, bool TB, int EPI>
+__global__ void __launch_bounds__(256, PNR_GEMM_WGS) k_gemm(GemmArgs g)
+{
+    __shared__ float As[2][TK][LDT];
+    static_assert(2 * TK * LDT >= 4096, "two 8-KiB epilogue regions per operand buffer");
+    __shared__ float Bs[2][TK][LDT];
+    gemm_body<TA, TB, EPI>(g, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.z, As, Bs);
 }
 
 // Weight gradients of the 256-wide layers (the four pair-level Linears): C[256, N] (partial of split z) = sum over the
@@ -339,24 +348,23 @@ __global__ void __launch_bounds__(256, PNR_GEMM_WGS) k_gemm(GemmArgs g)
 // buffers, branch-free loads, barriers that wait for LDS only; partial tiles in k_reduce_parts' layout, stored straight
 // from the accumulators (a row of 32 columns is one 128-byte segment; once per ~350 chunks).
 template <int NB>
-__global__ void __launch_bounds__(256, 2) k_wgrad256(GemmArgs g)
+__device__ __forceinline__ void wgrad256_body(const GemmArgs &g, int by, int bz, int gz, float (&As)[2][TK][256 + 4],
+                                              float (&Bs)[2][TK][32 * NB + 4])
 {
-    constexpr int WN = 32 * NB, LDA = 256 + 4, LDB = WN + 4;
+    constexpr int WN = 32 * NB;
     constexpr int NLB = (TK * WN / 4 + 255) / 256;   // float4 loads per thread for the B tile (the last one partial)
-    __shared__ float As[2][TK][LDA];
-    __shared__ float Bs[2][TK][LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int rows = *g.dev_rows, N = g.N;
-    const int n0 = blockIdx.y * WN;
-    const int nz = active_splits(rows, gridDim.z);
-    if ((int)blockIdx.z >= nz) return;
+    const int n0 = by * WN;
+    const int nz = active_splits(rows, gz);
+    if (bz >= nz) return;
     const int chunk = ((rows + nz - 1) / nz + TK - 1) / TK * TK;
-    const int k_begin = min(rows, (int)blockIdx.z * chunk), k_end = min(rows, k_begin + chunk);
+    const int k_begin = min(rows, bz * chunk), k_end = min(rows, k_begin + chunk);
     if (k_begin >= k_end) return;
     float4 ra[2][TK / 4], rb[2][NLB];
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool want_csum = g.colsum && blockIdx.y == 0;
+    const bool want_csum = g.colsum && by == 0;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int ar = tid >> 6, ac = (tid & 63) * 4;                    // A: rows ar + 4 i, columns ac .. ac + 3
     auto load_tiles = [&](int k0, auto par) {
@@ -446,10 +454,10 @@ __global__ void __launch_bounds__(256, 2) k_wgrad256(GemmArgs g)
         __syncthreads();
         *reinterpret_cast<float4 *>(&cs[ar * 256 + ac]) = csum;
         __syncthreads();
-        g.colsum[(int64_t)blockIdx.z * 256 + tid] = ((cs[tid] + cs[256 + tid]) + cs[512 + tid]) + cs[768 + tid];
+        g.colsum[(int64_t)bz * 256 + tid] = ((cs[tid] + cs[256 + tid]) + cs[512 + tid]) + cs[768 + tid];
     }
     // partial tile of split z: [256, ldc] block, columns n0 .. n0 + WN
-    float *cp = g.C + (int64_t)blockIdx.z * 256 * g.ldc;
+    float *cp = g.C + (int64_t)bz * 256 * g.ldc;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -463,6 +471,50 @@ __global__ void __launch_bounds__(256, 2) k_wgrad256(GemmArgs g)
                 }
             }
         }
+}
+
+
+template <int NB>
+__global__ void __launch_bounds__(256, 2) k_wgrad256(GemmArgs g)
+{
+    __shared__ float As[2][TK][256 + 4];
+    __shared__ float Bs[2][TK][32 * NB + 4];
+    wgrad256_body<NB>(g, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.z, As, Bs);
+}
+
+// Every weight gradient of a training step in TWO launches (and one reducer launch): at the batch ns-train draws (4096
+// rays, ~68 k rows) a weight-gradient GEMM is 8.9 GFLOP -- 57 us of the matrix pipes -- and seven of them one after the
+// other, each followed by its reducer, cost 0.6 ms of launches, half-empty rounds and tails.  The jobs of a batch are
+// independent (exact mode: the data-gradient chain leaves every dZ in its own buffer); a workgroup finds its job from
+// the prefix of workgroup counts.
+constexpr int MAX_WGRAD_JOBS = 8;
+struct WgradBatch {
+    GemmArgs g[MAX_WGRAD_JOBS];
+    int wg0[MAX_WGRAD_JOBS + 1];   // first workgroup of job j; [n] = all
+    int tx[MAX_WGRAD_JOBS], ty[MAX_WGRAD_JOBS], nz[MAX_WGRAD_JOBS];
+    int n;
+};
+__device__ __forceinline__ int wgrad_job(const WgradBatch &b, int wg)
+{
+    int j = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_WGRAD_JOBS; ++i) j += (i < b.n && wg >= b.wg0[i]) ? 1 : 0;
+    return j;
+}
+__global__ void __launch_bounds__(256, PNR_GEMM_WGS) k_wgrad_batch128(WgradBatch b)
+{
+    __shared__ float As[2][TK][LDT];
+    __shared__ float Bs[2][TK][LDT];
+    const int j = wgrad_job(b, (int)blockIdx.x), l = (int)blockIdx.x - b.wg0[j];
+    const int bx = l % b.tx[j], by = (l / b.tx[j]) % b.ty[j], bz = l / (b.tx[j] * b.ty[j]);
+    gemm_body<true, false, EPI_PARTIAL>(b.g[j], bx, by, bz, b.tx[j], b.nz[j], As, Bs);
+}
+__global__ void __launch_bounds__(256, 2) k_wgrad_batch96(WgradBatch b)
+{
+    __shared__ float As[2][TK][256 + 4];
+    __shared__ float Bs[2][TK][96 + 4];
+    const int j = wgrad_job(b, (int)blockIdx.x), l = (int)blockIdx.x - b.wg0[j];
+    wgrad256_body<3>(b.g[j], l % b.ty[j], l / b.ty[j], b.nz[j], As, Bs);
 }
 
 // dst[m][n] += sum over the active splits of part[z][m][n]  (part: [nz, M, ld], dst: [M, ld]);
@@ -485,6 +537,48 @@ __global__ void __launch_bounds__(256) k_reduce_parts(const float *__restrict__ 
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         int z = 0;
         for (; z + 4 <= used; z += 4) {   // four independent loads in flight
+            a0 += src[(int64_t)(z + 0) * stride];
+            a1 += src[(int64_t)(z + 1) * stride];
+            a2 += src[(int64_t)(z + 2) * stride];
+            a3 += src[(int64_t)(z + 3) * stride];
+        }
+        for (; z < used; ++z) a0 += src[(int64_t)z * stride];
+        const float t = (a0 + a1) + (a2 + a3);
+        if (is_b)
+            db[i - n] += t;
+        else
+            dst[i] += t;
+    }
+}
+
+// k_reduce_parts for every job of a batched weight-gradient launch: blockIdx.y = job
+struct ReduceBatch {
+    const float *part[MAX_WGRAD_JOBS], *csum[MAX_WGRAD_JOBS];
+    const int *rows[MAX_WGRAD_JOBS];
+    float *dst[MAX_WGRAD_JOBS], *db[MAX_WGRAD_JOBS];
+    int nz[MAX_WGRAD_JOBS], M[MAX_WGRAD_JOBS], N[MAX_WGRAD_JOBS], ld[MAX_WGRAD_JOBS];
+};
+__global__ void __launch_bounds__(256) k_reduce_parts_batch(ReduceBatch b)
+{
+    const int j = blockIdx.y;
+    const float *__restrict__ part = b.part[j];
+    const float *__restrict__ csum = b.csum[j];
+    float *__restrict__ dst = b.dst[j];
+    float *__restrict__ db = b.db[j];
+    const int M = b.M[j], N = b.N[j], ld = b.ld[j];
+    const int rows = *b.rows[j];
+    const int nz = active_splits(rows, b.nz[j]);
+    const int chunk = ((rows + nz - 1) / nz + TK - 1) / TK * TK;
+    const int used = chunk > 0 ? min(nz, (rows + chunk - 1) / chunk) : 0;
+    const int n = M * ld;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n + M; i += gridDim.x * blockDim.x) {
+        const bool is_b = i >= n;
+        if (!is_b && i % ld >= N) continue;
+        const float *src = is_b ? csum + (i - n) : part + i;
+        const int stride = is_b ? M : n;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int z = 0;
+        for (; z + 4 <= used; z += 4) {   // the same expression as k_reduce_parts
             a0 += src[(int64_t)(z + 0) * stride];
             a1 += src[(int64_t)(z + 1) * stride];
             a2 += src[(int64_t)(z + 2) * stride];
@@ -912,6 +1006,9 @@ static const int W_LD[9] = {288, 256, 264, 256, 256, 288, 128, 128, 128};
 constexpr int MAX_SPLIT_WGS = PNR_SPLIT_WGS;                        // workgroups of one weight-gradient GEMM
 constexpr size_t PART_FLOATS = (size_t)MAX_SPLIT_WGS * TM * TN;     // their partial tiles
 constexpr size_t CSUM_FLOATS = (size_t)MAX_SPLIT_WGS * 256;         // + one partial bias-gradient row per split
+// the batched launch keeps the partial tiles of all seven GEMMs at once: 2 x 192 x 256 x 256 + 170 x 256 x (264 + 288) +
+// 2 x 256 x 128 x 128 + 85 x 128 x 288 floats at the split counts of a large workspace, + the bias rows
+constexpr size_t POOL_FLOATS = (size_t)62 << 20;
 
 struct TrainWs {
     int *cnt;        // [0] rows = S * K, [1] S valid samples
@@ -943,6 +1040,8 @@ struct TrainWs {
     float *D3, *D2, *D1, *D0;
     float *rowgrad;
     float *chainW;
+    float *D6, *D5;        // [cap, 128] gradients at the colour MLP's pre-activations 6 and 5 (C3 holds the 7th)
+    float *DAGG;           // [cap, 256] gradient of the aggregated features
     unsigned *tape_bits;   // [4 layers: H1, H2, G1, G2][rows][2 lane halves][4]: LeakyReLU masks as bits (ShadeParams.tape_bits)
     size_t bits_rows;      // rows per layer
     size_t total;
@@ -988,7 +1087,7 @@ static TrainWs carve_train_ws(void *base, int64_t cap, int K)
     }
     for (int i = 0; i < 9; ++i) w.Wp[i] = (float *)take((size_t)W_OUT[i] * W_LD[i] * 4);
     for (int i = 0; i < 9; ++i) w.WT[i] = (float *)take((size_t)W_OUT[i] * W_LD[i] * 4);
-    w.part = (float *)take((size_t)(PART_FLOATS + CSUM_FLOATS) * 4);
+    w.part = (float *)take(std::max((size_t)(PART_FLOATS + CSUM_FLOATS), POOL_FLOATS) * 4);
     const size_t dw0 = off;
     for (int i = 0; i < 9; ++i) w.dWp[i] = (float *)take((size_t)W_OUT[i] * W_LD[i] * 4);
     for (int i = 0; i < 9; ++i) w.dbp[i] = (float *)take((size_t)W_OUT[i] * 4);
@@ -1005,6 +1104,9 @@ static TrainWs carve_train_ws(void *base, int64_t cap, int K)
     w.D0 = (float *)take(rows * LD_H * 4);
     w.rowgrad = (float *)take(rows * 40 * 4);
     w.chainW = (float *)take((CHAIN_W_FLOATS + 256) * 4);
+    w.D6 = (float *)take(smp * LD_C * 4);
+    w.D5 = (float *)take(smp * LD_C * 4);
+    w.DAGG = (float *)take(smp * 256 * 4);
     w.tape_bits = (unsigned *)take(rows * 128);
     w.bits_rows = rows;
     w.total = off;
@@ -1782,6 +1884,50 @@ static void gemm_weight(hipStream_t st, bool bf, const float *dZ, int lda, const
                        ldw, dev_rows, dW, db);
 }
 
+// the weight-gradient GEMMs of a step, collected and launched together (k_wgrad_batch128 / k_wgrad_batch96 +
+// k_reduce_parts_batch); exact mode only
+struct WgradQueue {
+    WgradBatch a{}, b{};
+    ReduceBatch r{};
+    int nr = 0;
+    float *pool;
+    size_t pool_floats, used = 0;
+    WgradQueue(float *p, size_t n) : pool(p), pool_floats(n) {}
+    // dW[M, N] += dZ[rows, M]^T . X[rows, N];  db[M] += column sums of dZ
+    void add(const float *dZ, int lda, const float *X, int ldx, float *dW, int ldw, int M, int N, const int *dev_rows,
+             int64_t rows_max, float *db)
+    {
+        const bool narrow = M == 256 && N % 128 != 0;
+        WgradBatch &q = narrow ? b : a;
+        const int tx = narrow ? 1 : (M + TM - 1) / TM, ty = narrow ? (N + 95) / 96 : (N + TN - 1) / TN;
+        const int budget = narrow ? 512 : (M == 256 ? MAX_SPLIT_WGS : 256);
+        int nsplit = (int)std::min<int64_t>(std::max<int64_t>(1, budget / (tx * ty)), (rows_max + 4 * TK - 1) / (4 * TK));
+        const size_t per = (size_t)M * ldw + M;   // a split's partial tile and bias row
+        const size_t left = pool_floats - used;
+        nsplit = (int)std::max<size_t>(1, std::min<size_t>((size_t)nsplit, left / per));
+        float *part = pool + used, *csum = part + (size_t)nsplit * M * ldw;
+        used += (size_t)nsplit * per;
+        const int j = q.n++;
+        GemmArgs &g = q.g[j];
+        g = GemmArgs{};
+        g.A = dZ; g.B = X; g.C = part; g.lda = lda; g.ldb = ldx; g.ldc = ldw; g.M = M; g.N = N; g.K = 0;
+        g.dev_rows = dev_rows; g.colsum = csum;
+        q.tx[j] = tx;
+        q.ty[j] = ty;
+        q.nz[j] = nsplit;
+        q.wg0[j + 1] = q.wg0[j] + tx * ty * nsplit;
+        r.part[nr] = part; r.csum[nr] = csum; r.rows[nr] = dev_rows; r.dst[nr] = dW; r.db[nr] = db;
+        r.nz[nr] = nsplit; r.M[nr] = M; r.N[nr] = N; r.ld[nr] = ldw;
+        ++nr;
+    }
+    void launch(hipStream_t st)
+    {
+        if (a.n) hipLaunchKernelGGL(k_wgrad_batch128, dim3((unsigned)a.wg0[a.n]), dim3(256), 0, st, a);
+        if (b.n) hipLaunchKernelGGL(k_wgrad_batch96, dim3((unsigned)b.wg0[b.n]), dim3(256), 0, st, b);
+        if (nr) hipLaunchKernelGGL(k_reduce_parts_batch, dim3(288, (unsigned)nr), dim3(256), 0, st, r);
+    }
+};
+
 }  // namespace pnr
 
 using namespace pnr;
@@ -2132,18 +2278,31 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
     // colour MLP
     hipLaunchKernelGGL(k_train_color_head_bwd, dim3(256), eb, 0, st, tw, d_w[8]);  // C3 <- dZ7
     hipLaunchKernelGGL(k_reduce_rows, dim3((387 + 15) / 16), eb, 0, st, tw.part, 1024, 388, 387, 384, tw.dWp[8], tw.dbp[8]);
-    gemm_weight(st, bf, tw.C3, LD_C, tw.C2, LD_C, tw.dWp[7], 128, 128, 128, n_smp, smp_max, tw.dbp[7], tw.part);
-    gemm_data(st, bf, tw.C3, LD_C, tw.Wp[7], 128, tw.WT[7], tw.C2, LD_C, 128, 128, 128, n_smp, smp_max, tw.sgC2);  // C2 <- dZ6
-    gemm_weight(st, bf, tw.C2, LD_C, tw.C1, LD_C, tw.dWp[6], 128, 128, 128, n_smp, smp_max, tw.dbp[6], tw.part);
-    gemm_data(st, bf, tw.C2, LD_C, tw.Wp[6], 128, tw.WT[6], tw.C1, LD_C, 128, 128, 128, n_smp, smp_max, tw.sgC1);  // C1 <- dZ5
-    gemm_weight(st, bf, tw.C1, LD_C, tw.XC, LD_XC, tw.dWp[5], 288, 128, 288, n_smp, smp_max, tw.dbp[5], tw.part);
-    gemm_data(st, bf, tw.C1, LD_C, tw.Wp[5], 288, tw.WT[5], tw.XC, LD_XC, 256, 128, 0, n_smp, smp_max);   // XC[:, :256] <- dAGG
+    // exact mode, K = 8: every data gradient goes to its own buffer (nothing is written over an activation a weight
+    // gradient still reads), the seven weight-gradient GEMMs are queued and leave together at the end
+    const bool batched = !bf && K == 8;
+    WgradQueue wq(tw.part, POOL_FLOATS);
+    if (batched) {
+        gemm_data(st, bf, tw.C3, LD_C, tw.Wp[7], 128, tw.WT[7], tw.D6, LD_C, 128, 128, 128, n_smp, smp_max, tw.sgC2);   // dZ6
+        gemm_data(st, bf, tw.D6, LD_C, tw.Wp[6], 128, tw.WT[6], tw.D5, LD_C, 128, 128, 128, n_smp, smp_max, tw.sgC1);   // dZ5
+        gemm_data(st, bf, tw.D5, LD_C, tw.Wp[5], 288, tw.WT[5], tw.DAGG, 256, 256, 128, 0, n_smp, smp_max);            // dAGG
+        wq.add(tw.C3, LD_C, tw.C2, LD_C, tw.dWp[7], 128, 128, 128, n_smp, smp_max, tw.dbp[7]);
+        wq.add(tw.D6, LD_C, tw.C1, LD_C, tw.dWp[6], 128, 128, 128, n_smp, smp_max, tw.dbp[6]);
+        wq.add(tw.D5, LD_C, tw.XC, LD_XC, tw.dWp[5], 288, 128, 288, n_smp, smp_max, tw.dbp[5]);
+    } else {
+        gemm_weight(st, bf, tw.C3, LD_C, tw.C2, LD_C, tw.dWp[7], 128, 128, 128, n_smp, smp_max, tw.dbp[7], tw.part);
+        gemm_data(st, bf, tw.C3, LD_C, tw.Wp[7], 128, tw.WT[7], tw.C2, LD_C, 128, 128, 128, n_smp, smp_max, tw.sgC2);  // C2 <- dZ6
+        gemm_weight(st, bf, tw.C2, LD_C, tw.C1, LD_C, tw.dWp[6], 128, 128, 128, n_smp, smp_max, tw.dbp[6], tw.part);
+        gemm_data(st, bf, tw.C2, LD_C, tw.Wp[6], 128, tw.WT[6], tw.C1, LD_C, 128, 128, 128, n_smp, smp_max, tw.sgC1);  // C1 <- dZ5
+        gemm_weight(st, bf, tw.C1, LD_C, tw.XC, LD_XC, tw.dWp[5], 288, 128, 288, n_smp, smp_max, tw.dbp[5], tw.part);
+        gemm_data(st, bf, tw.C1, LD_C, tw.Wp[5], 288, tw.WT[5], tw.XC, LD_XC, 256, 128, 0, n_smp, smp_max);   // XC[:, :256] <- dAGG
+    }
     // density head + aggregation
     const bool want_points = grads->d_embedding || grads->d_color || grads->d_dir || grads->d_point_grads;
     PNR_REQUIRE(!grads->d_point_grads || (grads->d_point_index && grads->point_cap >= 1),
                 "%s: sparse point gradients need d_point_index and point_cap", who);
     float *rowgrad = nullptr;
-    if (!bf && K == 8) {
+    if (batched) {
         // exact mode, K = 8 (32-row tiles hold whole samples: the geometry of k_shade_pairs<8>, whose tape writer leaves
         // the mask bits): the whole data-gradient chain of the pair MLPs in one kernel (pnr_train_chain.hip).  dw4 / db4
         // first (the tape G2 is read, nothing is written over it), then the chain: D3..D0 = the gradients at the four
@@ -2162,7 +2321,7 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
         C.row_w = tw.row_w;
         C.row_z = tw.row_z;
         C.d_out = tw.d_out;
-        C.XC = tw.XC;
+        C.XC = tw.DAGG;
         C.tape_bits = tw.tape_bits;
         C.bits_rows = tw.bits_rows;
         C.X0 = tw.X0;
@@ -2179,10 +2338,11 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
         for (int i = 0; i < 9; ++i) C.Rw2c[i] = weights->Rw2c[i];
         C.K = K;
         launch_pairs_bwd(C, rows_max, st);
-        gemm_weight(st, bf, tw.D3, LD_H, tw.G1, LD_H, tw.dWp[3], 256, 256, 256, n_rows, rows_max, tw.dbp[3], tw.part);
-        gemm_weight(st, bf, tw.D2, LD_H, tw.H2, LD_H2, tw.dWp[2], 264, 256, 264, n_rows, rows_max, tw.dbp[2], tw.part);
-        gemm_weight(st, bf, tw.D1, LD_H, tw.H1, LD_H, tw.dWp[1], 256, 256, 256, n_rows, rows_max, tw.dbp[1], tw.part);
-        gemm_weight(st, bf, tw.D0, LD_H, tw.X0, LD_X0, tw.dWp[0], 288, 256, 288, n_rows, rows_max, tw.dbp[0], tw.part);
+        wq.add(tw.D3, LD_H, tw.G1, LD_H, tw.dWp[3], 256, 256, 256, n_rows, rows_max, tw.dbp[3]);
+        wq.add(tw.D2, LD_H, tw.H2, LD_H2, tw.dWp[2], 264, 256, 264, n_rows, rows_max, tw.dbp[2]);
+        wq.add(tw.D1, LD_H, tw.H1, LD_H, tw.dWp[1], 256, 256, 256, n_rows, rows_max, tw.dbp[1]);
+        wq.add(tw.D0, LD_H, tw.X0, LD_X0, tw.dWp[0], 288, 256, 288, n_rows, rows_max, tw.dbp[0]);
+        wq.launch(st);
         rowgrad = tw.rowgrad;
     } else {
         hipLaunchKernelGGL(k_train_head_agg_bwd<true>, dim3(1024), eb, 0, st, tw, K, d_w[4]);          // G2 <- dZ4

@@ -25,7 +25,7 @@ struct ChainParams {
     const float *row_w;      // [rows] normalised inverse-distance weight
     const float *row_z;      // [rows] density head before the ReLU
     const float4 *d_out;     // [S] .x = d sigma
-    const float *XC;         // [S, 288]: d AGG in columns 0..255
+    const float *XC;         // [S, 256]: d AGG
     const unsigned *tape_bits;        // LeakyReLU masks of H1, H2, G1, G2 as bits (ShadeParams.tape_bits / k_tape_bits)
     size_t bits_rows;
     const float *X0;         // [rows, 288] taped layer-0 inputs (the (sin, cos) pairs of the embedding channels)

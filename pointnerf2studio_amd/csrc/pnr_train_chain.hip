@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(TPB, 1) k_train_pairs_bwd(ChainParams P)
         rD[3] = __builtin_amdgcn_make_buffer_rsrc(P.D0 + (int64_t)row0c * 256, 0, nv * 1024, 0x00020000);
         const __amdgpu_buffer_rsrc_t rG =
             __builtin_amdgcn_make_buffer_rsrc(P.rowgrad + (int64_t)row0c * 40, 0, nv * 160, 0x00020000);
-        const float *xc = P.XC + (int64_t)v * 288 + 4 * h;
+        const float *xc = P.XC + (int64_t)v * 256 + 4 * h;
 
         // block (layer pl, output tile pt), written one gap earlier, goes out: 8 lanes per row, whole 128-byte lines
         auto tape_flush = [&](int pl, int pt) {
