@@ -127,6 +127,7 @@ struct ShadeParams {
     // (what k_train_pairs_bwd shifts out as it walks the layers backwards); tape_bits_rows = rows per layer
     unsigned *tape_bits;
     size_t tape_bits_rows;
+    float *tape_rowz;   // [rows] the density head's pre-activation of every row (the backward's [z > 0])
 };
 
 __device__ __forceinline__ float4 load_w(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff)

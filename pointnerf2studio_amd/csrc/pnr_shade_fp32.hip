@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
     const unsigned t_wr = tblk + (unsigned)((lane & 31) * TAPE_ROW_B + 16 * h);            // + block + 32 q
     const unsigned t_rd = tblk + (unsigned)((lane >> 3) * TAPE_ROW_B + (lane & 7) * 16);   // + block + 8 i rows
     // descriptors of the tile's 32 tape rows (set per tile: offsets inside them stay small whatever the tape's size)
-    __amdgpu_buffer_rsrc_t trsrc[4], brsrc[4];
+    __amdgpu_buffer_rsrc_t trsrc[4], brsrc[4], zrsrc;
     unsigned tg[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // rows 8 i + l / 8 of the tile: tape row - the tile's first
     // the mask bits of the lane's own row (ShadeParams.tape_bits): one running word, four finished words per layer
     unsigned sbw = 0u, sbq[4] = {0u, 0u, 0u, 0u};
@@ -295,6 +295,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
                 brsrc[l] = __builtin_amdgcn_make_buffer_rsrc(
                     P.tape_bits + ((int64_t)l * (int64_t)P.tape_bits_rows + row_base) * 8, 0, 32 * 32, 0x00020000);
             }
+            zrsrc = __builtin_amdgcn_make_buffer_rsrc(P.tape_rowz + row_base, 0, 32 * 4, 0x00020000);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 8 * i + (lane >> 3), sl = r / L, slot = r - sl * L, v = v_wave0 + sl;
@@ -577,6 +578,9 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_pairs(ShadeParams P)
             }
         }
         part += __shfl_xor(part, 32, 64);
+        if (TAPE)   // the row's density pre-activation (lane half 0 of an existing row; the others out of range)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(part + b4), zrsrc,
+                                                  (brow == 0xFFFFFFFFu || h) ? 0x7FFFFFF0 : (int)(brow * 4u), 0, 0);
         const float alpha = fmaxf(part + b4, 0.f);
         const float sigma = seg_sum<SEG>(alpha * ctx.wgt, K, lane);
         if (writer && h == 0) {

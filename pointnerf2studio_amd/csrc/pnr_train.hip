@@ -1114,13 +1114,14 @@ static TrainWs carve_train_ws(void *base, int64_t cap, int K)
 }
 
 bool train_tape_ptrs(void *d_train_workspace, size_t bytes, int64_t cap, int K, float *tape[4], size_t tape_bytes[4],
-                     unsigned **tape_bits, size_t *tape_bits_rows)
+                     unsigned **tape_bits, size_t *tape_bits_rows, float **tape_rowz)
 {
     if (!d_train_workspace || carve_train_ws(nullptr, cap, K).total > bytes) return false;
     const TrainWs w = carve_train_ws(d_train_workspace, cap, K);
     const size_t rows = (size_t)cap * K + TM;
     *tape_bits = w.tape_bits;
     *tape_bits_rows = w.bits_rows;
+    *tape_rowz = w.row_z;
     tape[0] = w.H1;
     tape[1] = w.H2;
     tape[2] = w.G1;
@@ -1390,6 +1391,41 @@ __global__ void __launch_bounds__(256) k_train_head_agg(TrainParams P, TrainWs w
             xc[256 + lane] = val;
         }
         if (lane == 0) w.sig[v] = sigma;
+    }
+}
+
+// The same products after a render that wrote the tape: the render already holds them -- the aggregated features (its
+// colour kernel's blocked layout, agg_idx4), the densities, and (written with the tape) every row's density
+// pre-activation.  One wavefront per valid sample copies its 256 aggregated features into the colour MLP's input row and
+// encodes the view direction; the 1-KiB-per-row read of G2 that k_train_head_agg needs is gone.
+__global__ void __launch_bounds__(256) k_train_head_taped(TrainParams P, TrainWs w, const float4 *__restrict__ agg,
+                                                          const float *__restrict__ smp_sigma)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwv = (gridDim.x * blockDim.x) >> 6;
+    const int S = w.cnt[1];
+    // float4 `lane` of a row = features 4 lane .. 4 lane + 3 = accumulator tile t, quarter q, lane half h
+    const int t = lane >> 3, q = (lane & 7) >> 1, h = lane & 1;
+    const int in_block = (2 * t + (q >> 1)) * 128 + h * 64 + (q & 1) * 32;
+    for (int v = wv; v < S; v += nwv) {
+        float *xc = w.XC + (int64_t)v * LD_XC;
+        *reinterpret_cast<float4 *>(xc + 4 * lane) = agg[(int64_t)(v >> 5) * 2048 + in_block + (v & 31)];
+        if (lane < 32) {
+            const int ray = P.smp_ray[P.vs_list[v]];
+            float vv[3];
+            rot_rows(P.Rw2c, P.dirs[3 * (int64_t)ray], P.dirs[3 * (int64_t)ray + 1], P.dirs[3 * (int64_t)ray + 2], vv[0],
+                     vv[1], vv[2]);
+            float val = 0.f;
+            if (lane < 24) {
+                const int qq = lane % 12, d = qq >> 2, f = qq & 3;
+                const float dv = d == 0 ? vv[0] : (d == 1 ? vv[1] : vv[2]);
+                float sn, cs;
+                sincosf(dv * (float)(1 << f), &sn, &cs);
+                val = lane < 12 ? sn : cs;
+            }
+            xc[256 + lane] = val;
+        }
+        if (lane == 0) w.sig[v] = smp_sigma[v];
     }
 }
 
@@ -2266,7 +2302,10 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
     }
     const unsigned long long *sgH1 = taped ? nullptr : tw.sgH1, *sgH2 = taped ? nullptr : tw.sgH2,
                              *sgG1 = taped ? nullptr : tw.sgG1;
-    hipLaunchKernelGGL(k_train_head_agg, eg, eb, 0, st, P, tw, d_w[4], d_b[4]);
+    if (taped)
+        hipLaunchKernelGGL(k_train_head_taped, eg, eb, 0, st, P, tw, reinterpret_cast<const float4 *>(ws.agg), ws.smp_sigma);
+    else
+        hipLaunchKernelGGL(k_train_head_agg, eg, eb, 0, st, P, tw, d_w[4], d_b[4]);
     gemm_forward(st, bf, tw.XC, LD_XC, tw.Wp[5], 288, d_b[5], tw.C1, LD_C, 128, 288, n_smp, smp_max, tw.sgC1);
     gemm_forward(st, bf, tw.C1, LD_C, tw.Wp[6], 128, d_b[6], tw.C2, LD_C, 128, 128, n_smp, smp_max, tw.sgC2);
     gemm_forward(st, bf, tw.C2, LD_C, tw.Wp[7], 128, d_b[7], tw.C3, LD_C, 128, 128, n_smp, smp_max);
