@@ -1869,35 +1869,7 @@ __global__ void __launch_bounds__(256) k_train_point_sum(TrainWs w, const int *_
     const int lane = threadIdx.x & 63;
     const int wv = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwv = (gridDim.x * blockDim.x) >> 6;
     const int U = n_sel[3];
-    for (int u = wv; u < U; u += nwv) {
-        const int b = w.pt_start[u], c = w.pt_start[u + 1] - b;
-        float acc = 0.f;
-        if (c <= 64) {
-            // rank sort inside the wavefront (row ids are distinct), then the rows in ascending order
-            const int mine = lane < c ? w.pt_rows[b + lane] : 0x7FFFFFFF;
-            int rank = 0;
-            for (int j = 0; j < c; ++j) rank += __shfl(mine, j, 64) < mine ? 1 : 0;
-            // lane `rank` must end up holding `mine`: a gather by inverse permutation through ds_bpermute's twin
-            const int sorted = __builtin_amdgcn_ds_permute(rank << 2, mine);
-            for (int j = 0; j < c; ++j) {
-                const int row = __shfl(sorted, j, 64);
-                if (lane < 38) acc += rowgrad[(int64_t)row * LD_RG + lane];
-            }
-        } else {
-            // a point shared by more than 64 rows (rare): repeated selection of the next larger row id
-            int prev = -1;
-            for (int j = 0; j < c; ++j) {
-                int best = 0x7FFFFFFF;
-                for (int i = lane; i < c; i += 64) {
-                    const int r = w.pt_rows[b + i];
-                    if (r > prev && r < best) best = r;
-                }
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) best = min(best, __shfl_xor(best, d, 64));
-                prev = best;
-                if (lane < 38) acc += rowgrad[(int64_t)best * LD_RG + lane];
-            }
-        }
+    auto emit = [&](int u, float acc) {
         const int pidx = pt_list[u];
         if (sp_rows) {
             if (u < sp_cap) {
@@ -1910,6 +1882,61 @@ __global__ void __launch_bounds__(256) k_train_point_sum(TrainWs w, const int *_
             if (d_color) d_color[(int64_t)pidx * 3 + (lane - 32)] += acc;
         } else if (lane < 38) {
             if (d_dir) d_dir[(int64_t)pidx * 3 + (lane - 35)] += acc;
+        }
+    };
+    // a point shared by more than 64 rows (rare): repeated selection of the next larger row id
+    auto crowded = [&](int b, int c) {
+        float acc = 0.f;
+        int prev = -1;
+        for (int j = 0; j < c; ++j) {
+            int best = 0x7FFFFFFF;
+            for (int i = lane; i < c; i += 64) {
+                const int r = w.pt_rows[b + i];
+                if (r > prev && r < best) best = r;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) best = min(best, __shfl_xor(best, d, 64));
+            prev = best;
+            if (lane < 38) acc += rowgrad[(int64_t)best * LD_RG + lane];
+        }
+        return acc;
+    };
+    // Two points per iteration: a point's work is a chain of four dependent memory latencies (group bounds -> row ids ->
+    // gradient rows -> the accumulated tensor) and a handful of rows, so a wavefront that walks its points one by one
+    // mostly waits (0.39 ms at 65 536 rays with every wave slot of the device taken).  The two chains are independent;
+    // each point's rows are still added in ascending row order (the same expression, bitwise repeatable).
+    for (int u0 = wv; u0 < U; u0 += 2 * nwv) {
+        const int u1 = u0 + nwv;
+        const bool ok1 = u1 < U;
+        const int b0 = w.pt_start[u0], c0 = w.pt_start[u0 + 1] - b0;
+        const int b1 = ok1 ? w.pt_start[u1] : 0, c1 = ok1 ? w.pt_start[u1 + 1] - b1 : 0;
+        if (c0 <= 64 && c1 <= 64) {
+            // rank sort inside the wavefront (row ids are distinct), then the rows in ascending order
+            const int m0 = lane < c0 ? w.pt_rows[b0 + lane] : 0x7FFFFFFF;
+            const int m1 = lane < c1 ? w.pt_rows[b1 + lane] : 0x7FFFFFFF;
+            int r0 = 0, r1 = 0;
+            for (int j = 0; j < c0; ++j) r0 += __shfl(m0, j, 64) < m0 ? 1 : 0;
+            for (int j = 0; j < c1; ++j) r1 += __shfl(m1, j, 64) < m1 ? 1 : 0;
+            // lane `rank` must end up holding `mine`: a gather by inverse permutation through ds_bpermute's twin
+            const int s0 = __builtin_amdgcn_ds_permute(r0 << 2, m0);
+            const int s1 = __builtin_amdgcn_ds_permute(r1 << 2, m1);
+            float a0 = 0.f, a1 = 0.f;
+            const int cm = max(c0, c1);
+            for (int j = 0; j < cm; ++j) {
+                const int row0 = __shfl(s0, j, 64), row1 = __shfl(s1, j, 64);
+                float g0 = 0.f, g1 = 0.f;
+                if (lane < 38) {
+                    if (j < c0) g0 = rowgrad[(int64_t)row0 * LD_RG + lane];
+                    if (j < c1) g1 = rowgrad[(int64_t)row1 * LD_RG + lane];
+                }
+                if (j < c0) a0 += g0;
+                if (j < c1) a1 += g1;
+            }
+            emit(u0, a0);
+            if (ok1) emit(u1, a1);
+        } else {
+            emit(u0, crowded(b0, c0));
+            if (ok1) emit(u1, crowded(b1, c1));
         }
     }
 }
