@@ -3,6 +3,7 @@
 # the same command, the HBM-traffic PMC passes and the MFMA-busy PMC pass, into gpurun_out/prof_rNN/.
 # tools/summarize_profiles.py then condenses them into profiles/<round>/ (run on the host).
 #   what = all (default) | bench | trace | pmc | cfg4 (trace + PMC passes of the K = 12 configuration, fp32)
+#          | train (per-kernel times and a PMC pass of the training step, tools/train_step_bench.py, 4096 and 65 536 rays)
 set -e -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 WHAT=${1:-all}
@@ -54,5 +55,15 @@ if [ "$WHAT" = all ] || [ "$WHAT" = cfg4 ]; then
   rm -rf $O/pmc_mfma_cfg4
   rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/pmc_mfma_cfg4 -- python bench.py $C \
       --steps 2 --warmup 1 > $O/bench_pmc_mfma_cfg4.json 2> $O/pmc_mfma_cfg4.err
+fi
+if [ "$WHAT" = all ] || [ "$WHAT" = train ]; then
+  for rays in 4096 65536; do
+    echo "[train] kernel times $rays rays"
+    bash tools/train_kernel_times.sh $rays fp32 > $O/train_kernel_times_$rays.txt 2>&1
+    cp gpurun_out/tkt.json $O/train_step_under_rocprof_$rays.json
+    python3 tools/train_step_bench.py --skip-autograd --steps 10 --rays $rays > $O/train_step_$rays.json 2> $O/train_step_$rays.err
+  done
+  echo "[train] pmc 65536 rays"
+  bash tools/pmc_train.sh 65536 > $O/pmc_train_65536.txt 2>&1
 fi
 echo done; ls $O

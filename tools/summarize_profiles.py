@@ -99,6 +99,12 @@ if keys:
             e["hbm_bytes_per_launch_corrected"] = (2 * f + w) * 1024
     json.dump(out, open(os.path.join(dst, "pmc_hbm_traffic.json"), "w"), indent=1)
 
+# ---- the training step (tools/collect_profiles.sh train): per-kernel tables, wall-clock lines, the PMC table -------------
+for name in ("train_kernel_times_4096.txt", "train_kernel_times_65536.txt", "train_step_4096.json", "train_step_65536.json",
+             "pmc_train_65536.txt"):
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, name))
+
 # ---- the K = 12 configuration (cfg4_scannet_20m, fp32): bench line, kernel stats, traffic, MFMA busy -------------------
 if os.path.exists(os.path.join(src, "bench_cfg4.json")):
     shutil.copy(os.path.join(src, "bench_cfg4.json"), os.path.join(dst, "bench_cfg4_n1_fp32.json"))
