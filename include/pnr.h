@@ -95,7 +95,8 @@ typedef struct {
     void *d_tape;          /* NULL (default), or the TRAINING workspace (pnr_backward_workspace_bytes(cap_samples, K)
                               bytes of device memory) of the pnr_render_backward call that will follow this render: the
                               render then leaves the post-activation outputs of the four per-pair layers there as it
-                              computes them, and the backward -- given the same workspace and the same opts -- does not
+                              computes them -- with their LeakyReLU masks as bits and every row's density
+                              pre-activation -- and the backward, given the same workspace and the same opts, does not
                               recompute them (four row GEMMs: 6 of its 21 ms at 65 536 rays).  fp32, K <= 10 or 16,
                               early_stop_eps = 0; otherwise ignored (the backward recomputes, as without it).       */
     size_t tape_bytes;     /* size of d_tape                                                                       */
@@ -362,10 +363,13 @@ typedef struct {
 int pnr_point_grads_clear(float *d_embedding, float *d_color, float *d_dir, int64_t N, const int32_t *d_index,
                           int64_t n_index, const int64_t *d_n_index, void *stream);
 
+/* ~10 KB per (sample, neighbour) row of capacity: the activation tapes, the gradients at the four pre-activations of the
+ * per-pair MLPs, the rows' point gradients, the mask bits (+ 250 MB of partial weight-gradient tiles). */
 size_t pnr_backward_workspace_bytes(int64_t cap_samples, int32_t K);
 /* Call after pnr_render / pnr_render_views with the SAME scene, rays, cameras, options, cap_samples and render
  * workspace (its sample lists and neighbour indices are reused; nothing else may have used that workspace in
- * between).  The MLP forward is recomputed with a tape of activations in the arithmetic of opts->precision: FP32 =
+ * between).  The MLP forward is recomputed (or, after a render given this workspace as opts->d_tape, taken from the tape
+ * that render wrote) with a tape of activations in the arithmetic of opts->precision: FP32 =
  * every product in fp32 (gradients agree with fp32 autograd to ~1e-6 relative); BF16X3 = every GEMM on bf16 hi/lo
  * splits (3 products, 2^-16 relative) -- the gradient of the function that mode renders.  d_w / d_b are the
  * raw weights (as given to pnr_weights_pack; `weights` only supplies Rw2c), d_grad_rgb [R,3] is d loss / d rgb.
