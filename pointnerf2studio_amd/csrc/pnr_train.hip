@@ -2446,9 +2446,9 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
     // colour MLP
     hipLaunchKernelGGL(k_train_color_head_bwd, dim3(256), eb, 0, st, tw, d_w[8]);  // C3 <- dZ7
     hipLaunchKernelGGL(k_reduce_rows, dim3((387 + 15) / 16), eb, 0, st, tw.part, 1024, 388, 387, 384, tw.dWp[8], tw.dbp[8]);
-    // exact mode, K = 8: every data gradient goes to its own buffer (nothing is written over an activation a weight
-    // gradient still reads), the seven weight-gradient GEMMs are queued and leave together at the end
-    const bool batched = !bf && K == 8;
+    // exact mode: every data gradient goes to its own buffer (nothing is written over an activation a weight gradient
+    // still reads), the seven weight-gradient GEMMs are queued and leave together at the end
+    const bool batched = !bf;
     WgradQueue wq(tw.part, POOL_FLOATS);
     if (batched) {
         gemm_data(st, bf, tw.C3, LD_C, tw.Wp[7], 128, tw.WT[7], tw.D6, LD_C, 128, 128, 128, n_smp, smp_max, tw.sgC2);   // dZ6
@@ -2471,8 +2471,8 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
                 "%s: sparse point gradients need d_point_index and point_cap", who);
     float *rowgrad = nullptr;
     if (batched) {
-        // exact mode, K = 8 (32-row tiles hold whole samples: the geometry of k_shade_pairs<8>, whose tape writer leaves
-        // the mask bits): the whole data-gradient chain of the pair MLPs in one kernel (pnr_train_chain.hip).  dw4 / db4
+        // exact mode (any K: the chain walks tape rows, 32 per wave, and a row finds its sample as row / K; the mask bits
+        // are indexed by tape row): the whole data-gradient chain of the pair MLPs in one kernel (pnr_train_chain.hip).  dw4 / db4
         // first (the tape G2 is read, nothing is written over it), then the chain: D3..D0 = the gradients at the four
         // pre-activations, rowgrad = the rows' point gradients, pt_cnt = rows per touched point
         if (!taped) launch_tape_bits(tw.cnt, tw.H1, tw.H2, tw.G1, tw.G2, tw.bits_rows, tw.tape_bits, st);
