@@ -362,7 +362,7 @@ int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr,
 // (cap, K); false if the workspace is too small.  tape_supported: the configurations in which a render given
 // opts.d_tape fills them -- pnr_render* and pnr_render_backward must agree on it.
 bool train_tape_ptrs(void *d_train_workspace, size_t bytes, int64_t cap, int K, float *tape[4], size_t tape_bytes[4],
-                     unsigned **tape_bits, size_t *tape_bits_rows, float **tape_rowz);
+                     unsigned **tape_bits, size_t *tape_bits_rows, float **tape_rowz, float *ctape[3], void **tape_sg);
 inline bool tape_supported(const pnr_render_opts_t &o)
 {
     return o.d_tape != nullptr && o.precision == PNR_PRECISION_FP32 && o.early_stop_eps == 0.f &&

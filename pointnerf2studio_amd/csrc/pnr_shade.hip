@@ -380,7 +380,8 @@ int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr,
     if (tape_supported(opts) && !early) {
         float *t4[4];
         size_t b4[4];
-        if (train_tape_ptrs(opts.d_tape, opts.tape_bytes, cap, K, t4, b4, &P.tape_bits, &P.tape_bits_rows, &P.tape_rowz)) {
+        if (train_tape_ptrs(opts.d_tape, opts.tape_bytes, cap, K, t4, b4, &P.tape_bits, &P.tape_bits_rows, &P.tape_rowz, P.ctape,
+                            reinterpret_cast<void **>(&P.tape_sg))) {
             for (int l = 0; l < 4; ++l) {
                 P.tape[l] = t4[l];
                 P.tape_bytes[l] = b4[l];

@@ -128,6 +128,10 @@ struct ShadeParams {
     unsigned *tape_bits;
     size_t tape_bits_rows;
     float *tape_rowz;   // [rows] the density head's pre-activation of every row (the backward's [z > 0])
+    // ... and of the colour MLP (k_shade_color<true>): its three hidden activations C1, C2, C3 [S, 128] and the sigmoid
+    // outputs of the colour head [S] (null: not taped)
+    float *ctape[3];
+    float4 *tape_sg;
 };
 
 __device__ __forceinline__ float4 load_w(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff)

@@ -968,7 +968,7 @@ __device__ __forceinline__ HeadW head_w(__amdgpu_buffer_rsrc_t rsrc, int w8, int
     return w;
 }
 __device__ __forceinline__ void color_head_f32(__amdgpu_buffer_rsrc_t rsrc, int w8, const float *__restrict__ b8, int h,
-                                               HeadW w0, const float (&hC)[64], float (&rgb)[3])
+                                               HeadW w0, const float (&hC)[64], float (&rgb)[3], float (&sgo)[3])
 {
     HeadW wc = w0;
 #pragma unroll
@@ -987,6 +987,7 @@ __device__ __forceinline__ void color_head_f32(__amdgpu_buffer_rsrc_t rsrc, int 
         part += __shfl_xor(part, 32, 64);
         const float z = part + b8[c];
         const float sg = 1.0f / (1.0f + expf(-z));
+        sgo[c] = sg;
         rgb[c] = sg * (1.0f + 2.0f * 0.001f) - 0.001f;
         if (c < 2) wc = wn;
     }
@@ -998,6 +999,11 @@ struct ColorFetch {
     float sigma, dx, dy, dz;
 };
 
+// TAPE (training renders): the three hidden activations leave row-major ([S, 128] each: the colour MLP's part of
+// pnr_render_backward's tape) through the same wave-private LDS blocks as the pair kernel's tape, and the colour head's
+// sigmoid outputs with them -- the backward then recomputes nothing of the colour MLP (three row GEMMs and the head:
+// a dozen launches of latency at the training batch size).
+template <bool TAPE = false>
 __global__ void __launch_bounds__(TPB, 1) k_shade_color(ShadeParams P)
 {
     const int lane = threadIdx.x & 63;
@@ -1006,6 +1012,38 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_color(ShadeParams P)
     const int V0 = P.n_sel[P.i_v0], S_valid = P.n_sel[P.i_v1];
     constexpr int SPT = 32 * WAVES;
     const int ntiles = (S_valid - V0 + SPT - 1) / SPT;
+    extern __shared__ float ctape_lds[];
+    const unsigned tblk = TAPE ? (unsigned)(uintptr_t)ctape_lds + (unsigned)(wave * TAPE_WAVE_B) : 0u;
+    const unsigned t_wr = tblk + (unsigned)(j * TAPE_ROW_B + 16 * h);
+    const unsigned t_rd = tblk + (unsigned)((lane >> 3) * TAPE_ROW_B + (lane & 7) * 16);
+    __amdgpu_buffer_rsrc_t crs[3];
+    // block (layer pl, output tile pt) goes out: 8 lanes per row, whole 128-byte lines
+    auto tape_flush = [&](int pl, int pt) {
+        f32x4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = lds_read4(t_rd, (pt & 1) * TAPE_BLK_B + i * 8 * TAPE_ROW_B);
+        lds_wait();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x4 o;
+            o.x = __float_as_uint(v[i].x);
+            o.y = __float_as_uint(v[i].y);
+            o.z = __float_as_uint(v[i].z);
+            o.w = __float_as_uint(v[i].w);
+            __builtin_amdgcn_raw_buffer_store_b128(o, crs[pl], (8 * i + (lane >> 3)) * 512 + 16 * (lane & 7) + 128 * pt, 0, 0);
+        }
+    };
+    auto tape_tile = [&](int layer, int tile, const float *t) {
+        if (tile > 0)
+            tape_flush(layer, tile - 1);
+        else if (layer > 0)
+            tape_flush(layer - 1, 3);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = {t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
+            lds_write4(t_wr, v, (tile & 1) * TAPE_BLK_B + 32 * q);
+        }
+    };
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.wbuf), 0, (int)P.wbytes, 0x00020000);
     const int voff = lane * 16;
@@ -1078,6 +1116,14 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_color(ShadeParams P)
                 }
         }
         fetch_s(tile + gridDim.x, nxt);   // a tile past the end reads entry 0: harmless
+        if (TAPE) {
+            // the wave's 32 consecutive tape rows; the descriptors end behind the last existing one
+            const int v0w = __builtin_amdgcn_readfirstlane(tile * SPT + wave * 32);
+            const int nv = __builtin_amdgcn_readfirstlane(max(0, min(32, S_valid - V0 - v0w)));
+#pragma unroll
+            for (int l = 0; l < 3; ++l)
+                crs[l] = __builtin_amdgcn_make_buffer_rsrc(P.ctape[l] + (int64_t)v0w * 128, 0, nv * 512, 0x00020000);
+        }
         float hA[64], hB[64];
         Ini ini_next;
         f32x16 acc[4];
@@ -1090,6 +1136,7 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_color(ShadeParams P)
                 if (m > 0) {
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) leaky2(acc[m - 1][r], acc[m - 1][r + 1], hA[16 * (m - 1) + r], hA[16 * (m - 1) + r + 1]);
+                    if (TAPE) tape_tile(0, m - 1, &hA[16 * (m - 1)]);
                 }
                 if (m == 3) ini_next = bias_ini(b6, 0, h);
             });
@@ -1108,9 +1155,11 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_color(ShadeParams P)
                         // values 48..63 are this layer's k-steps 48..63: long after MFMA 0
 #pragma unroll
                         for (int r = 0; r < 16; r += 2) leaky2(last[r], last[r + 1], hA[48 + r], hA[49 + r]);
+                        if (TAPE) tape_tile(0, 3, &hA[48]);
                     } else {
 #pragma unroll
                         for (int r = 0; r < 16; r += 2) leaky2(acc[m - 1][r], acc[m - 1][r + 1], hB[16 * (m - 1) + r], hB[16 * (m - 1) + r + 1]);
+                        if (TAPE) tape_tile(1, m - 1, &hB[16 * (m - 1)]);
                     }
                     if (m == 3) ini_next = bias_ini(b7, 0, h);
                 });
@@ -1128,9 +1177,11 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_color(ShadeParams P)
                     if (m == 0) {
 #pragma unroll
                         for (int r = 0; r < 16; r += 2) leaky2(last[r], last[r + 1], hB[48 + r], hB[49 + r]);
+                        if (TAPE) tape_tile(1, 3, &hB[48]);
                     } else {
 #pragma unroll
                         for (int r = 0; r < 16; r += 2) leaky2(acc[m - 1][r], acc[m - 1][r + 1], hC[16 * (m - 1) + r], hC[16 * (m - 1) + r + 1]);
+                        if (TAPE) tape_tile(2, m - 1, &hC[16 * (m - 1)]);
                     }
                 });
         }
@@ -1138,9 +1189,14 @@ __global__ void __launch_bounds__(TPB, 1) k_shade_color(ShadeParams P)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 16; r += 2) leaky2(acc[3][r], acc[3][r + 1], hC[48 + r], hC[49 + r]);
-        float rgb[3];
-        color_head_f32(rsrc, w8, b8, h, hw0, hC, rgb);
+        if (TAPE) {
+            tape_tile(2, 3, &hC[48]);
+            tape_flush(2, 3);
+        }
+        float rgb[3], sgv[3];
+        color_head_f32(rsrc, w8, b8, h, hw0, hC, rgb, sgv);
         if (cur.ok && h == 0) P.smp_out[cur.s] = make_float4(cur.sigma, rgb[0], rgb[1], rgb[2]);
+        if (TAPE && cur.ok && h == 0) P.tape_sg[cur.v_idx - V0] = make_float4(sgv[0], sgv[1], sgv[2], 0.f);
         cur = nxt;
     }
 }
@@ -1255,7 +1311,10 @@ void launch_pairs_fp32_dense(int su, int tu, dim3 grid, hipStream_t stream, cons
 
 void launch_color_fp32(dim3 grid, hipStream_t stream, const ShadeParams &P)
 {
-    hipLaunchKernelGGL(k_shade_color, grid, dim3(TPB), 0, stream, P);
+    if (P.ctape[0])
+        hipLaunchKernelGGL(k_shade_color<true>, grid, dim3(TPB), (size_t)WAVES * TAPE_WAVE_B, stream, P);
+    else
+        hipLaunchKernelGGL(k_shade_color<false>, grid, dim3(TPB), 0, stream, P);
 }
 
 }  // namespace pnr

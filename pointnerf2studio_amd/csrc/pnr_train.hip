@@ -1114,7 +1114,7 @@ static TrainWs carve_train_ws(void *base, int64_t cap, int K)
 }
 
 bool train_tape_ptrs(void *d_train_workspace, size_t bytes, int64_t cap, int K, float *tape[4], size_t tape_bytes[4],
-                     unsigned **tape_bits, size_t *tape_bits_rows, float **tape_rowz)
+                     unsigned **tape_bits, size_t *tape_bits_rows, float **tape_rowz, float *ctape[3], void **tape_sg)
 {
     if (!d_train_workspace || carve_train_ws(nullptr, cap, K).total > bytes) return false;
     const TrainWs w = carve_train_ws(d_train_workspace, cap, K);
@@ -1122,6 +1122,10 @@ bool train_tape_ptrs(void *d_train_workspace, size_t bytes, int64_t cap, int K, 
     *tape_bits = w.tape_bits;
     *tape_bits_rows = w.bits_rows;
     *tape_rowz = w.row_z;
+    ctape[0] = w.C1;
+    ctape[1] = w.C2;
+    ctape[2] = w.C3;
+    *tape_sg = w.sg;
     tape[0] = w.H1;
     tape[1] = w.H2;
     tape[2] = w.G1;
@@ -1995,13 +1999,13 @@ static void gemm_forward(hipStream_t st, bool bf, const float *A, int lda, const
 // (bf16x3: the B operand is WT = W^T [N, K] with leading dimension K)
 static void gemm_data(hipStream_t st, bool bf, const float *dZ, int lda, const float *W, int ldw, const float *WT,
                       float *C, int ldc, int N, int K, int mask_cols, const int *dev_rows, int64_t rows_max,
-                      const unsigned long long *sign_in = nullptr)
+                      const unsigned long long *sign_in = nullptr, const float *mask_src = nullptr)
 {
     GemmArgs g{};
     g.sign_in = sign_in;
     g.sign_nt = (mask_cols + TN - 1) / TN;
     g.A = dZ; g.B = W; g.C = C; g.lda = lda; g.ldb = ldw; g.ldc = ldc; g.M = 0; g.N = N; g.K = K;
-    g.dev_rows = dev_rows; g.mask = C; g.mask_cols = mask_cols;
+    g.dev_rows = dev_rows; g.mask = mask_src ? mask_src : C; g.mask_cols = mask_cols;
     if (bf) {
         g.B = WT;
         g.ldb = K;
@@ -2435,10 +2439,14 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
         hipLaunchKernelGGL(k_train_head_taped, eg, eb, 0, st, P, tw, reinterpret_cast<const float4 *>(ws.agg), ws.smp_sigma);
     else
         hipLaunchKernelGGL(k_train_head_agg, eg, eb, 0, st, P, tw, d_w[4], d_b[4]);
-    gemm_forward(st, bf, tw.XC, LD_XC, tw.Wp[5], 288, d_b[5], tw.C1, LD_C, 128, 288, n_smp, smp_max, tw.sgC1);
-    gemm_forward(st, bf, tw.C1, LD_C, tw.Wp[6], 128, d_b[6], tw.C2, LD_C, 128, 128, n_smp, smp_max, tw.sgC2);
-    gemm_forward(st, bf, tw.C2, LD_C, tw.Wp[7], 128, d_b[7], tw.C3, LD_C, 128, 128, n_smp, smp_max);
-    hipLaunchKernelGGL(k_train_color_head, eg, eb, 0, st, tw, d_w[8], d_b[8]);
+    if (!taped) {   // (a taped render's colour kernel left C1, C2, C3 and the head's sigmoids as well)
+        gemm_forward(st, bf, tw.XC, LD_XC, tw.Wp[5], 288, d_b[5], tw.C1, LD_C, 128, 288, n_smp, smp_max, tw.sgC1);
+        gemm_forward(st, bf, tw.C1, LD_C, tw.Wp[6], 128, d_b[6], tw.C2, LD_C, 128, 128, n_smp, smp_max, tw.sgC2);
+        gemm_forward(st, bf, tw.C2, LD_C, tw.Wp[7], 128, d_b[7], tw.C3, LD_C, 128, 128, n_smp, smp_max);
+        hipLaunchKernelGGL(k_train_color_head, eg, eb, 0, st, tw, d_w[8], d_b[8]);
+    }
+    // LeakyReLU masks of the colour MLP's data gradients: the sign words of the recompute's epilogues, or the taped floats
+    const unsigned long long *sgC1 = taped ? nullptr : tw.sgC1, *sgC2 = taped ? nullptr : tw.sgC2;
 
     // ---- backward --------------------------------------------------------------------------------
     hipLaunchKernelGGL(k_train_composite_bwd, dim3((unsigned)((R + 255) / 256)), eb, 0, st, cr, *opts, R, ws.ray_cnt,
@@ -2451,8 +2459,8 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
     const bool batched = !bf;
     WgradQueue wq(tw.part, POOL_FLOATS);
     if (batched) {
-        gemm_data(st, bf, tw.C3, LD_C, tw.Wp[7], 128, tw.WT[7], tw.D6, LD_C, 128, 128, 128, n_smp, smp_max, tw.sgC2);   // dZ6
-        gemm_data(st, bf, tw.D6, LD_C, tw.Wp[6], 128, tw.WT[6], tw.D5, LD_C, 128, 128, 128, n_smp, smp_max, tw.sgC1);   // dZ5
+        gemm_data(st, bf, tw.C3, LD_C, tw.Wp[7], 128, tw.WT[7], tw.D6, LD_C, 128, 128, 128, n_smp, smp_max, sgC2, tw.C2);   // dZ6
+        gemm_data(st, bf, tw.D6, LD_C, tw.Wp[6], 128, tw.WT[6], tw.D5, LD_C, 128, 128, 128, n_smp, smp_max, sgC1, tw.C1);   // dZ5
         gemm_data(st, bf, tw.D5, LD_C, tw.Wp[5], 288, tw.WT[5], tw.DAGG, 256, 256, 128, 0, n_smp, smp_max);            // dAGG
         wq.add(tw.C3, LD_C, tw.C2, LD_C, tw.dWp[7], 128, 128, 128, n_smp, smp_max, tw.dbp[7]);
         wq.add(tw.D6, LD_C, tw.C1, LD_C, tw.dWp[6], 128, 128, 128, n_smp, smp_max, tw.dbp[6]);
