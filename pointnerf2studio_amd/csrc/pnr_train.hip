@@ -147,7 +147,10 @@ constexpr int NLD = TK / 8;   // float4 loads per thread and operand per chunk
 // weight gradients: the grid offers gridDim.z splits of the rows (sized for the workspace capacity); a split is worth
 // its fixed costs (prologue, a 64-KB partial tile) only with >= 256 rows, so the kernel and the reducer agree on
 // this number from the row count found on the device
-constexpr int MIN_ROWS_PER_SPLIT = 256;
+#ifndef PNR_MIN_ROWS_PER_SPLIT
+#define PNR_MIN_ROWS_PER_SPLIT 256
+#endif
+constexpr int MIN_ROWS_PER_SPLIT = PNR_MIN_ROWS_PER_SPLIT;
 __device__ __forceinline__ int active_splits(int rows, int nz_grid)
 {
     return min(nz_grid, max(1, (rows + MIN_ROWS_PER_SPLIT - 1) / MIN_ROWS_PER_SPLIT));
@@ -2194,14 +2197,25 @@ __global__ void k_conf_final(const double *__restrict__ part, const long long *_
                              const float *__restrict__ conf, float eps, float *__restrict__ out,
                              long long *__restrict__ slots_out)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // one wavefront: lane l adds the partials l, l + 64, ... in that order, a butterfly adds the lanes (every lane ends
+    // with the same bits: a fixed expression) -- one thread walking 512 dependent loads took 36 us
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
     double s = 0.0;
     long long nf = 0;
-    for (int i = 0; i < nblocks; ++i) {
+    for (int i = lane; i < nblocks; i += 64) {
         s += part[i];
         nf += filled[i];
     }
-    const long long slots = (long long)shard_sum(shards, SH_KEPT) * SR * K;
+    unsigned long long kept = lane < SHARDS ? shards[((size_t)SH_KEPT * SHARDS + lane) * SHARD_STRIDE] : 0ull;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        nf += __shfl_xor(nf, o, 64);
+        kept += __shfl_xor(kept, o, 64);
+    }
+    if (lane != 0) return;
+    const long long slots = (long long)kept * SR * K;
     float d;
     s += (double)(slots - nf) * (double)conf_term(conf[0], eps, d);
     out[0] = (float)(s / (double)slots);     // (no kept ray: 0 / 0 = NaN, as torch.mean of an empty tensor)
@@ -2237,9 +2251,13 @@ __global__ void k_conf_bwd_zero(const double *__restrict__ part, const long long
                                 const long long *__restrict__ slots_in, float *__restrict__ d_conf,
                                 unsigned long long *__restrict__ zero_cnt)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
     long long nf = 0;
-    for (int i = 0; i < nblocks; ++i) nf += filled[i];
+    for (int i = lane; i < nblocks; i += 64) nf += filled[i];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) nf += __shfl_xor(nf, o, 64);
+    if (lane != 0) return;
     const long long slots = *slots_in;
     float d;
     conf_term(conf[0], eps, d);
