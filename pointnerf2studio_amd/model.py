@@ -183,6 +183,24 @@ class _FusedRenderFn(torch.autograd.Function):
         return (None, None, None, None, None, None, *grads)
 
 
+class _MaskedMSEFn(torch.autograd.Function):
+    """MSELoss over the kept rays (studio_model.py:419-424) as a masked sum: mean((image - rgb)^2 over kept rays) + 1e-6.
+    The backward is written out (two small kernels) instead of autograd's dozen for the same expression."""
+
+    @staticmethod
+    def forward(ctx, rgb, image, ray_mask):
+        keep = (ray_mask > 0)[..., None].to(rgb.dtype)
+        diff = (image - rgb) * keep
+        n = 3.0 * torch.sum(keep)
+        ctx.save_for_backward(diff, n)
+        return torch.sum(diff * diff) / n + 1e-6
+
+    @staticmethod
+    def backward(ctx, g):
+        diff, n = ctx.saved_tensors
+        return diff * (-2.0 * g / n), None, None
+
+
 class _ConfLossFn(torch.autograd.Function):
     """mean(log v + log(1 - v)) over the reference's conf_coefficient tensor of the last render (pnr_conf_loss) and its
     gradient w.r.t. points_conf (pnr_conf_loss_backward): studio_model.py:288-292,427-429 without the [1,R'',SR,K] gather."""
@@ -797,9 +815,8 @@ class PointNerf(Model):
         image = batch["image"].to(device)
         # the reference compacts both tensors with masked_select (a device-to-host read each: the sizes) and takes
         # MSELoss over what is left; the same mean as a masked sum, nothing read back
-        keep = (outputs["ray_mask"] > 0)[..., None].to(outputs["coarse_raycolor"].dtype)
-        diff = (image - outputs["coarse_raycolor"]) * keep
-        loss_dict = {"ray_masked_coarse_raycolor_loss": torch.sum(diff * diff) / (3.0 * torch.sum(keep)) + 1e-6}
+        loss_dict = {"ray_masked_coarse_raycolor_loss": _MaskedMSEFn.apply(outputs["coarse_raycolor"], image,
+                                                                           outputs["ray_mask"])}
         if self.training and "conf_coefficient_loss_term" in outputs:
             # (the fused path computed the mean itself: _ConfLossFn)
             loss_dict["conf_coefficient_loss"] = outputs["conf_coefficient_loss_term"] * self.config.zero_one_loss_weights
