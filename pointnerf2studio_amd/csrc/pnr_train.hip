@@ -2064,6 +2064,7 @@ struct WgradQueue {
     size_t pool_floats, used = 0;
     WgradQueue(float *p, size_t n) : pool(p), pool_floats(n) {}
     // dW[M, N] += dZ[rows, M]^T . X[rows, N];  db[M] += column sums of dZ
+    bool overflow = false;   // the pool cannot hold even one split of a job (never with POOL_FLOATS; checked by the caller)
     void add(const float *dZ, int lda, const float *X, int ldx, float *dW, int ldw, int M, int N, const int *dev_rows,
              int64_t rows_max, float *db)
     {
@@ -2074,6 +2075,10 @@ struct WgradQueue {
         int nsplit = (int)std::min<int64_t>(std::max<int64_t>(1, budget / (tx * ty)), (rows_max + 4 * TK - 1) / (4 * TK));
         const size_t per = (size_t)M * ldw + M;   // a split's partial tile and bias row
         const size_t left = pool_floats - used;
+        if (left < per || (narrow ? b.n : a.n) >= MAX_WGRAD_JOBS) {
+            overflow = true;
+            return;
+        }
         nsplit = (int)std::max<size_t>(1, std::min<size_t>((size_t)nsplit, left / per));
         float *part = pool + used, *csum = part + (size_t)nsplit * M * ldw;
         used += (size_t)nsplit * per;
@@ -2536,6 +2541,7 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
         wq.add(tw.D2, LD_H, tw.H2, LD_H2, tw.dWp[2], 264, 256, 264, n_rows, rows_max, tw.dbp[2]);
         wq.add(tw.D1, LD_H, tw.H1, LD_H, tw.dWp[1], 256, 256, 256, n_rows, rows_max, tw.dbp[1]);
         wq.add(tw.D0, LD_H, tw.X0, LD_X0, tw.dWp[0], 288, 256, 288, n_rows, rows_max, tw.dbp[0]);
+        PNR_REQUIRE(!wq.overflow, "%s: the weight-gradient pool is too small for this step's GEMMs", who);
         wq.launch(st);
         rowgrad = tw.rowgrad;
     } else {

@@ -59,6 +59,7 @@ def _compare(name, got, want, bf16x3=False):
     (60000, 80, 8, 12, 24, 24, 35.0, True),      # training composite (no clamp)
     (50000, 32, 8, 12, 32, 32, 200.0, False),    # eval clamp: gradient passes only inside [0, 1]
     (200000, 24, 12, 26, 20, 20, 300.0, True),   # K = 12
+    (60000, 32, 4, 12, 24, 24, 120.0, True),     # K = 4: tape rows = 4 per sample (tiles of 32 rows hold 8 samples)
 ])
 def test_backward_matches_oracle_autograd(oracle, gpu_device, N, SR, K, P, H, W, az, training, precision):
     pts = small_scene(N)
