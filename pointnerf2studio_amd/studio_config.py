@@ -77,7 +77,8 @@ class PointNerfDataManagerMixin:
         raise ValueError("No more eval images")
 
 
-if HAVE_NERFSTUDIO:  # pragma: no cover - nerfstudio is not installable in the build image
+if HAVE_NERFSTUDIO:  # pragma: no cover - nerfstudio is not installable in the build image; the block runs against a
+    # stand-in package in tests/test_studio_config_registration.py
     import typing
 
     from nerfstudio.data.datamanagers.base_datamanager import VanillaDataManager, VanillaDataManagerConfig
