@@ -11,15 +11,16 @@
 //     dX0 = W0^T dZ0  (the 224 embedding columns only: positions are frozen, studio_utils.py:84-103)
 // with the packed W^T streamed L2 -> VGPR as the MFMA A operand (k_pack_chain; one rolling window of loads that never
 // drains), the gradients of a layer feeding the next layer's B operands straight from the accumulators (AGPR / VGPR
-// alternating), the LeakyReLU masks read from the taped activations one output tile ahead, and every dZ leaving once,
-// row-major, through the wave-private LDS blocks of the render's tape writer (whole 128-byte lines) -- they are the A
-// operands of the four weight-gradient GEMMs, which now read tapes nobody overwrites.
+// alternating), the LeakyReLU masks taken from BITS (16 bytes per row, lane half and layer: written by the render's tape
+// writer or by k_tape_bits, loaded once per tile, shifted into vcc value by value), and every dZ leaving once, row-major,
+// through the wave-private LDS blocks of the render's tape writer (whole 128-byte lines) -- they are the A operands of
+// the four weight-gradient GEMMs, which now read tapes nobody overwrites.
 // The last layer's output rows are ORDERED so that a lane ends up with everything one embedding channel needs
 // (d e, d sin / d cos of its three octaves: 7 of 8 consecutive accumulator registers): the chain rule through the
 // positional encoding (k_train_rowgrad before) is 14 multiply-adds on registers, and the 7 extra head inputs
 // (d colour, d dir) come out of a ninth output tile of the W2^T layer.  The kernel also counts the rows of every touched
 // point (integer atomics) for the ordered point sums that follow.
-// 3 328 MFMAs per 32-row tile (the render: 3 360).
+// 4 224 MFMAs per 32-row tile (the render, whose first layer is factorised per point: 3 360).
 #include "pnr_shade_common.h"
 #include "pnr_train_chain.h"
 
