@@ -580,6 +580,7 @@ class PointNerf(Model):
         N = npts.points_xyz.shape[0]
         rnd = self._renderers.get(not self.training) or next(iter(self._renderers.values()))
         out: Dict[str, Optional[torch.Tensor]] = {}
+        clear: Dict[int, list] = {}   # id(row list) -> [index, count, {key: buffer}]: one launch per list for all tensors
         for key, p in (("embedding", npts.points_embeding), ("color", npts.points_color), ("dir", npts.points_dir)):
             if not p.requires_grad:
                 out[key] = None
@@ -590,13 +591,14 @@ class PointNerf(Model):
                 self._gdirty[key] = []
             if p.grad is None:
                 for index, count in self._gdirty[key]:
-                    rnd.clear_point_grads(buf if key == "embedding" else None, buf if key == "color" else None,
-                                          buf if key == "dir" else None, N, index, count)
+                    clear.setdefault(id(index), [index, count, {}])[2][key] = buf
                 self._gdirty[key] = []
                 p.grad = buf
             elif p.grad.data_ptr() != buf.data_ptr() and not (p.grad.is_contiguous() and p.grad.dtype == torch.float32):
                 raise RuntimeError(f"points_{key}.grad is not a contiguous float32 tensor")
             out[key] = p.grad
+        for index, count, bufs in clear.values():
+            rnd.clear_point_grads(bufs.get("embedding"), bufs.get("color"), bufs.get("dir"), N, index, count)
         return out
 
     def _after_point_backward(self, rnd: RendererHIP, targets) -> None:
