@@ -353,8 +353,9 @@ __device__ __forceinline__ unsigned long long shard_sum(const unsigned long long
 int launch_select_expand(const GridView &g, const CamRef &cr, const float *d_dirs, const float *d_raypos,
                          int64_t R, int D, int SR, int64_t cap, RenderWs &ws, int64_t *d_counters,
                          hipStream_t stream);
+// R (the call's ray count) and P (the scene's points per voxel) let small batches take the cooperative search
 int launch_knn(const GridView &g, int K, float radius_limit, RenderWs &ws, int64_t cap, int64_t *d_counters,
-               hipStream_t stream, int64_t N = 0);
+               hipStream_t stream, int64_t N = 0, int64_t R = 0, int P = 0);
 int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr, const float *d_dirs,
                  const pnr_render_opts_t &opts, int64_t R, RenderWs &ws, int64_t cap, int64_t *d_counters,
                  hipStream_t stream, hipEvent_t ev_points, hipEvent_t ev_between);

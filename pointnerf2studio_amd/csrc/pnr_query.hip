@@ -13,6 +13,8 @@
 // (layer -> x -> y -> z -> slot), same replace-the-farthest rule, same fp32 distance expression.
 #include <algorithm>
 
+#include <stdlib.h>
+
 #include "pnr_internal.h"
 
 namespace pnr {
@@ -607,6 +609,144 @@ __global__ void __launch_bounds__(TPB, KMAX <= 8 ? 6 : 4) k_knn3(GridView g, int
     }
 }
 
+// The same search for SMALL batches (a training step draws 4096 rays: ~9 k samples, 150 waves -- k_knn3 then takes the
+// 150 us of one thread's chain of ~30 dependent loads whatever the batch).  Here 32 lanes share a sample, lane l < 27
+// owns cell l = 9 (x + 1) + 3 (y + 1) + (z + 1) of the 3 x 3 x 3 neighbourhood: the 27 brick records are loaded at once,
+// then the 27 list bounds, then every cell's (at most COOP_P) candidates -- five dependent levels instead of thirty.  The
+// candidates then pass through the reference's sequential insertion in the reference's order (layer 0 = the centre
+// cell, layer 1 = the others by x, y, z; a list in slot order; the search stops behind layer 0 once K were found): the
+// insertion state is replicated over the half wave, a candidate's distance and index are broadcast from its owner, so the
+// lists -- and the tested-candidate counts -- are the ones k_knn3 and the oracle produce.
+constexpr int COOP_P = 12;   // candidates a lane keeps (the scene's P must not exceed it)
+template <int KMAX>
+__global__ void __launch_bounds__(TPB) k_knn3_coop(GridView g, int K, float radius_limit2,
+                                                   const float4 *__restrict__ smp_loc, const int *__restrict__ smp_ray,
+                                                   const int *__restrict__ n_sel, int *__restrict__ smp_pidx,
+                                                   int *__restrict__ smp_valid, int *__restrict__ ray_flag,
+                                                   unsigned long long *__restrict__ shards, int *__restrict__ pt_flag)
+{
+    const int S = n_sel[0];
+    const int lane = threadIdx.x & 63, half = lane >> 5, l = lane & 31;
+    const int hbase = half << 5;                                    // first lane of this half wave
+    const int64_t pair0 = ((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6, npairs = ((int64_t)gridDim.x * TPB) >> 6;
+    const int nlayers = (g.kernel_size[0] + 1) / 2;                 // 1 or 2
+    const int x = l / 9 - 1, sl9 = l - 9 * (l / 9), y = sl9 / 3 - 1, z = sl9 - 3 * (sl9 / 3) - 1;
+    const int my_layer = l < 27 ? max(abs(z), max(abs(x), abs(y))) : 99;
+    for (int64_t wp = pair0; 2 * wp < S; wp += npairs) {
+        const int64_t s = 2 * wp + half;
+        const bool live = s < S;
+        const float4 c = smp_loc[live ? s : 0];
+        int fx, fy, fz;
+        cell_of(g, c.x, c.y, c.z, fx, fy, fz);
+        // ---- this lane's cell: brick record -> list bounds -> candidates ----------------------------------------------
+        const bool on = live && my_layer < nlayers && fx + x >= 0 && fx + x < g.dims[0] && fy + y >= 0 &&
+                        fy + y < g.dims[1] && fz + z >= 0 && fz + z < g.dims[2];
+        int q0 = 0, q1 = 0;
+        if (on) {
+            int brick, bit;
+            brick_of(g, fx + x, fy + y, fz + z, brick, bit);
+            const BrickRec rec = g.rec[brick];
+            const unsigned long long mbit = 1ull << bit;
+            if (rec.bits & mbit) {
+                const int v = (int)rec.rank + __popcll(rec.bits & (mbit - 1ull));
+                q0 = g.vox_start[v];
+                q1 = g.vox_start[v + 1];
+            }
+        }
+        const int cnt = min(q1 - q0, COOP_P);
+        float dd[COOP_P];
+        int pi[COOP_P];
+        unsigned pass = 0;
+        {
+            // all of the lane's candidate loads in flight together (branch-free: a predicated load is its own basic block
+            // and is waited for before the next one is issued); record 0 stands in for the ones that do not exist
+            float4 pc[COOP_P];
+#pragma unroll
+            for (int b = 0; b < COOP_P; ++b) pc[b] = g.cand[b < cnt ? q0 + b : 0];
+#pragma unroll
+            for (int b = 0; b < COOP_P; ++b) {
+                const float xv = pc[b].x - c.x, yv = pc[b].y - c.y, zv = pc[b].z - c.z;
+                dd[b] = xv * xv + yv * yv + zv * zv;   // left-to-right, unfused
+                pi[b] = __float_as_int(pc[b].w);
+                if (b < cnt && (radius_limit2 == 0.0f || dd[b] <= radius_limit2)) pass |= 1u << b;
+            }
+        }
+        // ---- the reference's insertion, cell by cell in its order; state replicated over the half wave ---------------
+        int kid = 0, far_ind = 0;
+        float far2 = 0.0f;
+        float buf[KMAX];
+        int out[KMAX];
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) {
+            buf[i] = 0.f;
+            out[i] = -1;
+        }
+        unsigned tested = 0;
+        for (int layer = 0; layer < nlayers; ++layer) {
+            for (int cl = 0; cl < 27; ++cl) {
+                if ((cl == 13) != (layer == 0)) continue;            // layer 0: the centre cell; layer 1: the 26 others
+                const int n_c = __shfl(cnt, hbase + cl, 64);
+                const unsigned pm = (unsigned)__shfl((int)pass, hbase + cl, 64);
+                tested += (unsigned)n_c;
+                if (pm == 0) continue;
+#pragma unroll
+                for (int b = 0; b < COOP_P; ++b) {
+                    if (!(pm & (1u << b))) continue;
+                    const float d2 = __shfl(dd[b], hbase + cl, 64);
+                    const int pidx = __shfl(pi[b], hbase + cl, 64);
+                    if (kid++ < K) {
+                        const int slot = kid - 1;
+#pragma unroll
+                        for (int i = 0; i < KMAX; ++i)
+                            if (i == slot) {
+                                out[i] = pidx;
+                                buf[i] = d2;
+                            }
+                        if (d2 > far2) {
+                            far2 = d2;
+                            far_ind = slot;
+                        }
+                    } else if (d2 < far2) {
+#pragma unroll
+                        for (int i = 0; i < KMAX; ++i)
+                            if (i == far_ind) {
+                                out[i] = pidx;
+                                buf[i] = d2;
+                            }
+                        far2 = d2;
+#pragma unroll
+                        for (int i = 0; i < KMAX; ++i)
+                            if (i < K && buf[i] > far2) {
+                                far2 = buf[i];
+                                far_ind = i;
+                            }
+                    }
+                }
+            }
+            if (kid >= K) break;
+        }
+        if (!live) continue;
+        // lane i < K of the half wave writes neighbour i
+        int mine = -1;
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i)
+            if (i == l) mine = out[i];
+        if (l < K) {
+            smp_pidx[s * K + l] = mine;
+            if (pt_flag && mine >= 0) pt_flag[mine] = 1;
+        }
+        if (l == 0) {
+            const int nn = min(kid, K);
+            smp_valid[s] = nn > 0;
+            if (nn > 0) {
+                ray_flag[smp_ray[s]] = 1;  // every writer stores the same value
+                shard_add(shards, SH_PAIRS, (unsigned long long)nn);
+            }
+            shard_add(shards, SH_CAND, (unsigned long long)tested);
+        }
+    }
+}
+
 // vs_list[voff[s]] = s for samples with >= 1 neighbour; publishes S_valid
 __global__ void __launch_bounds__(TPB) k_compact_valid(const int *__restrict__ smp_valid,
                                                         const int *__restrict__ smp_voff, int *__restrict__ n_sel,
@@ -703,7 +843,7 @@ __global__ void __launch_bounds__(TPB) k_list_points(int64_t N, const int *__res
 }
 
 int launch_knn(const GridView &g, int K, float radius_limit, RenderWs &ws, int64_t cap, int64_t *d_counters,
-               hipStream_t stream, int64_t N)
+               hipStream_t stream, int64_t N, int64_t R, int P)
 {
     unsigned long long *acc = acc_ptr(ws);
     int *pt_flag = (N > 0) ? ws.pt_flag : nullptr;
@@ -712,7 +852,22 @@ int launch_knn(const GridView &g, int K, float radius_limit, RenderWs &ws, int64
     // grid-stride over the device-side sample count; enough workgroups to fill the chip
     const unsigned grid = (unsigned)std::min<int64_t>(nblk(cap), 256 * 32);
     const bool batched = g.kernel_size[0] <= 3;
-    if (batched && K <= 8)
+    // small batches (R: the call's rays, 0 = unknown): 32 lanes per sample, see k_knn3_coop
+    static const int coop_max_rays = [] {
+        const char *e = getenv("PNR_KNN_COOP_MAX_RAYS");
+        return e ? atoi(e) : 16384;
+    }();
+    const bool coop = batched && g.kernel_size[1] <= 3 && g.kernel_size[2] <= 3 && K <= 16 && P >= 1 && P <= COOP_P &&
+                      R >= 1 && R <= coop_max_rays;
+    if (coop) {
+        const unsigned cgrid = (unsigned)std::min<int64_t>((cap + 7) / 8, 256 * 32);   // 8 samples per workgroup pass
+        if (K <= 8)
+            hipLaunchKernelGGL(k_knn3_coop<8>, dim3(cgrid), dim3(TPB), 0, stream, g, K, r2, ws.smp_loc, ws.smp_ray, ws.n_sel,
+                               ws.smp_pidx, ws.smp_valid, ws.ray_flag, acc, pt_flag);
+        else
+            hipLaunchKernelGGL(k_knn3_coop<16>, dim3(cgrid), dim3(TPB), 0, stream, g, K, r2, ws.smp_loc, ws.smp_ray, ws.n_sel,
+                               ws.smp_pidx, ws.smp_valid, ws.ray_flag, acc, pt_flag);
+    } else if (batched && K <= 8)
         hipLaunchKernelGGL(k_knn3<8>, dim3(grid), dim3(TPB), 0, stream, g, K, r2, ws.smp_loc, ws.smp_ray, ws.n_sel,
                            ws.smp_pidx, ws.smp_valid, ws.ray_flag, acc, pt_flag);
     else if (batched && K <= 16)
@@ -781,7 +936,7 @@ extern "C" int pnr_query_raypos(const pnr_scene_t *scene, const float *d_raypos,
     cr.D = D;
     int rc = launch_select_expand(scene->grid, cr, nullptr, d_raypos, R, D, SR, cap, ws, d_counters, stream);
     if (rc != PNR_OK) return rc;
-    rc = launch_knn(scene->grid, K, radius_limit, ws, cap, d_counters, stream);
+    rc = launch_knn(scene->grid, K, radius_limit, ws, cap, d_counters, stream, 0, R, scene->params.P);
     if (rc != PNR_OK) return rc;
     // rank of every kept ray = exclusive scan of the keep flags (reuses smp_voff as scratch: [R+1] <= [cap+1])
     int *ray_rank = ws.smp_voff;

@@ -390,7 +390,7 @@ static int render_views(const pnr_scene_t *scene, const pnr_weights_t *weights, 
     if (rc != PNR_OK) return rc;
     if (prof) PNR_HIP_CHECK(hipEventRecord(g_ev[1], stream));
     rc = launch_knn(scene->grid, opts->K, opts->radius_limit, ws, cap_samples, d_counters, stream,
-                    factored ? scene->N : 0);
+                    factored ? scene->N : 0, R, scene->params.P);
     if (rc != PNR_OK) return rc;
     // bound point tensors (pnr_points_bind, a training loop): the rows this call reads are re-packed from them first
     rc = launch_refresh_rows(scene, ws.pt_list, ws.n_sel + 3, ws.u_cap, stream);
