@@ -855,7 +855,7 @@ int launch_knn(const GridView &g, int K, float radius_limit, RenderWs &ws, int64
     // small batches (R: the call's rays, 0 = unknown): 32 lanes per sample, see k_knn3_coop
     static const int coop_max_rays = [] {
         const char *e = getenv("PNR_KNN_COOP_MAX_RAYS");
-        return e ? atoi(e) : 16384;
+        return e ? atoi(e) : 12288;   // (measured at cfg 1: 53 / 85 / 138 us at 4096 / 8192 / 16 384 rays against k_knn3's 140-157)
     }();
     const bool coop = batched && g.kernel_size[1] <= 3 && g.kernel_size[2] <= 3 && K <= 16 && P >= 1 && P <= COOP_P &&
                       R >= 1 && R <= coop_max_rays;
