@@ -1,6 +1,10 @@
 """ctypes binding of libpnr_hip.so (include/pnr.h).  Tensors in, tensors out; no torch C++ ABI.
 
-There is NO fallback: if the HIP library is missing or a call fails, a RuntimeError is raised.
+There is NO fallback: if the HIP library is missing and cannot be built, or a call fails, a RuntimeError is raised.
+Where the library is looked for (`find_library`): $PNR_LIB, then next to this file (a source tree after
+`python -m pointnerf2studio_amd.build`, or a wheel that was packaged with the library), then the per-user cache an
+earlier first-use build wrote.  An installed copy without a library builds it ONCE on first use from the HIP sources it
+ships (pyproject.toml: package-data) when hipcc is present -- $PNR_NO_AUTOBUILD=1 turns that off.
 """
 from __future__ import annotations
 
@@ -85,16 +89,40 @@ class GradsC(C.Structure):
 _lib: Optional[C.CDLL] = None
 
 
+def find_library() -> str:
+    """Path of libpnr_hip.so, building it on first use where that is possible; raises (never falls back) otherwise."""
+    import sys
+    from . import build
+    if os.path.exists(LIB_PATH):
+        return LIB_PATH
+    default = os.path.join(PKG_DIR, "libpnr_hip.so")
+    why = f"{LIB_PATH} is missing"
+    if LIB_PATH == default and not os.environ.get("PNR_LIB"):
+        cached = os.path.join(build.cache_dir(), "libpnr_hip.so")
+        if os.path.exists(cached):
+            return cached
+        if os.environ.get("PNR_NO_AUTOBUILD"):
+            why += " and PNR_NO_AUTOBUILD is set"
+        elif not build.sources_present():
+            why += f" and the HIP sources are not under {build.CSRC}"
+        elif build.find_hipcc() is None:
+            why += " and there is no hipcc to build it with"
+        else:
+            out_dir = build.default_out_dir()
+            print(f"pointnerf2studio_amd: building libpnr_hip.so for gfx950 into {out_dir} (first use, ~1-2 min)",
+                  file=sys.stderr, flush=True)
+            return build.build_library(out_dir=None if out_dir == PKG_DIR else out_dir)
+    raise RuntimeError(
+        f"{why}: build it with `python -m pointnerf2studio_amd.build` "
+        "(hipcc --offload-arch=gfx950). There is no CPU or PyTorch fallback for the render path.")
+
+
 def load() -> C.CDLL:
-    """Loads libpnr_hip.so; raises (never falls back) when it is absent."""
+    """Loads libpnr_hip.so (find_library); raises (never falls back) when it is absent and cannot be built."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(
-            f"{LIB_PATH} is missing: build it with `python -m pointnerf2studio_amd.build` "
-            "(hipcc --offload-arch=gfx950). There is no CPU or PyTorch fallback for the render path.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(find_library())
     vp, i64, i32, f32, sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
     lib.pnr_last_error.restype = C.c_char_p
     lib.pnr_last_error.argtypes = []

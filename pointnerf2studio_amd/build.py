@@ -1,8 +1,10 @@
-"""Builds libpnr_hip.so (the C-ABI HIP library, gfx950 only) in-tree with hipcc.
+"""Builds libpnr_hip.so (the C-ABI HIP library, gfx950 only) with hipcc.
 
 `python -m pointnerf2studio_amd.build` or `build_library()`; hipcc cross-compiles for gfx950
-without a GPU.  The library is NOT built lazily at import on a GPU box: `_lib.load()` fails
-loudly when it is missing (no CPU fallback exists or is wanted).
+without a GPU.  In a source tree the library is built next to the package (in-tree, so it travels with the tree);
+an INSTALLED copy (pip install: HIP sources and the header ship as package data, pyproject.toml) that holds no
+library builds it on first use -- `_lib.load()` -- into the package directory, or into a per-user cache when that
+is read-only, and fails loudly where there is no hipcc (no CPU fallback exists or is wanted).
 """
 from __future__ import annotations
 
@@ -15,7 +17,10 @@ from concurrent.futures import ThreadPoolExecutor
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
+# the C-ABI header: include/pnr.h of the source tree, or the copy setup.py puts into an installed package
 INCLUDE = os.path.join(ROOT, "include")
+if not os.path.exists(os.path.join(INCLUDE, "pnr.h")):
+    INCLUDE = os.path.join(PKG_DIR, "include")
 LIB_NAME = "libpnr_hip.so"
 LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
 OBJ_DIR = os.path.join(PKG_DIR, "csrc", "_obj")
@@ -40,11 +45,50 @@ FILE_FLAGS = {"pnr_shade_fp32.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
               "pnr_train_chain.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
+def find_hipcc():
+    exe = shutil.which("hipcc") or os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "bin", "hipcc")
+    return exe if os.path.exists(exe) else None
+
+
 def hipcc() -> str:
-    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(exe):
+    exe = find_hipcc()
+    if exe is None:
         raise RuntimeError("hipcc not found; a ROCm toolchain is required to build libpnr_hip.so")
     return exe
+
+
+def sources_present() -> bool:
+    return (all(os.path.exists(os.path.join(CSRC, s)) for s in SOURCES)
+            and os.path.exists(os.path.join(INCLUDE, "pnr.h")))
+
+
+def _writable(d: str) -> bool:
+    try:
+        os.makedirs(d, exist_ok=True)
+        probe = os.path.join(d, f".pnr_write_probe_{os.getpid()}")
+        with open(probe, "w"):
+            pass
+        os.remove(probe)
+        return True
+    except OSError:
+        return False
+
+
+def cache_dir() -> str:
+    """Where an installed copy in a read-only location keeps its library: $PNR_CACHE_DIR, else
+    ~/.cache/pointnerf2studio_amd/<hash of the sources>: a new release never loads an old build."""
+    import hashlib
+    h = hashlib.sha256()
+    for s in sorted(SOURCES) + ["pnr_internal.h", "pnr_shade_common.h", "pnr_train_chain.h"]:
+        p = os.path.join(CSRC, s)
+        if os.path.exists(p):
+            h.update(open(p, "rb").read())
+    base = os.environ.get("PNR_CACHE_DIR") or os.path.join(os.path.expanduser("~"), ".cache", "pointnerf2studio_amd")
+    return os.path.join(base, h.hexdigest()[:16])
+
+
+def default_out_dir() -> str:
+    return PKG_DIR if _writable(PKG_DIR) else cache_dir()
 
 
 def _stale(target: str, deps) -> bool:
@@ -54,8 +98,12 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    os.makedirs(OBJ_DIR, exist_ok=True)
+def build_library(force: bool = False, verbose: bool = False, out_dir: str = None) -> str:
+    """Compiles the nine .hip files and links libpnr_hip.so into `out_dir` (default: the package directory).  Returns
+    the library's path."""
+    lib_path = LIB_PATH if out_dir is None else os.path.join(out_dir, LIB_NAME)
+    obj_dir = OBJ_DIR if out_dir is None else os.path.join(out_dir, "_obj")
+    os.makedirs(obj_dir, exist_ok=True)
     headers = [os.path.join(CSRC, "pnr_internal.h"), os.path.join(CSRC, "pnr_shade_common.h"),
                os.path.join(CSRC, "pnr_train_chain.h"),
                os.path.join(INCLUDE, "pnr.h"), os.path.abspath(__file__)]
@@ -63,7 +111,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        o = os.path.join(obj_dir, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + headers):
             jobs.append([cc, *FLAGS, *FILE_FLAGS.get(src, []), "-c", s, "-o", o])
 
@@ -86,10 +134,13 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    objs = [os.path.join(OBJ_DIR, s.replace(".hip", ".o")) for s in SOURCES]
-    if force or jobs or _stale(LIB_PATH, objs):
-        run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs])
-    return LIB_PATH
+    objs = [os.path.join(obj_dir, s.replace(".hip", ".o")) for s in SOURCES]
+    if force or jobs or _stale(lib_path, objs):
+        # (linked under a temporary name and renamed: a second process never loads a half-written library)
+        tmp = f"{lib_path}.{os.getpid()}.tmp"
+        run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs])
+        os.replace(tmp, lib_path)
+    return lib_path
 
 
 if __name__ == "__main__":

@@ -17,7 +17,8 @@ from dataclasses import dataclass, field
 from typing import Any, Dict, Optional, Type
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+if not os.environ.get("PNR_TEST_INSTALLED_COPY"):     # (tests/test_packaging.py imports an INSTALLED copy instead)
+    sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 from torch import nn  # noqa: E402
