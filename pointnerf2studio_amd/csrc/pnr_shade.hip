@@ -405,7 +405,9 @@ int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr,
         const char *e = getenv("PNR_DENSE_UNITS");
         return e ? atoi(e) : 1;     // 0: never, 1: where it fills more rows, 2: also for K = 8 and 16
     }();
-    const bool dense_all = dense_mode == 2 && (K == 8 || K == 16);
+    // (a render asked for the tape keeps the DPP kernels, the only ones that write it: pnr_render_backward derives "taped"
+    // from the same opts -- tape_supported -- and must find what it expects)
+    const bool dense_all = dense_mode == 2 && (K == 8 || K == 16) && !taped;
     if (!bf && ((K >= 11 && K != 16 && dense_mode != 0) || dense_all)) {   // (K >= 11, or K = 8 / 16 aligned to the
         // tiles: at most four samples touch a tile, see the kernel)
         double best = (double)K / (seg ? seg : K * (32 / K)) * 1.0001;   // what the segment form fills

@@ -1043,7 +1043,8 @@ struct TrainWs {
     float *D3, *D2, *D1, *D0;
     float *rowgrad;
     float *chainW;
-    float *D6, *D5;        // [cap, 128] gradients at the colour MLP's pre-activations 6 and 5 (C3 holds the 7th)
+    float *D7, *D6, *D5;   // [cap, 128] gradients at the colour MLP's three pre-activations (exact mode: no taped
+                           // activation is overwritten, so a backward may be repeated on the same taped render)
     float *DAGG;           // [cap, 256] gradient of the aggregated features
     unsigned *tape_bits;   // [4 layers: H1, H2, G1, G2][rows][2 lane halves][4]: LeakyReLU masks as bits (ShadeParams.tape_bits)
     size_t bits_rows;      // rows per layer
@@ -1112,6 +1113,7 @@ static TrainWs carve_train_ws(void *base, int64_t cap, int K)
     w.DAGG = (float *)take(smp * 256 * 4);
     w.tape_bits = (unsigned *)take(rows * 128);
     w.bits_rows = rows;
+    w.D7 = (float *)take(smp * LD_C * 4);
     w.total = off;
     return w;
 }
@@ -1660,8 +1662,9 @@ __global__ void __launch_bounds__(256) k_train_composite_bwd(CamRef cr, pnr_rend
 }
 
 // colour head backwards: dz8 = d rgb * 1.002 * sg (1 - sg); dW8 += dz8 (x) C3; db8 += dz8;
-// C3 <- (dz8 . W8) * LeakyReLU'(C3)   (the gradient at the colour MLP's last pre-activation, in place)
-__global__ void __launch_bounds__(256) k_train_color_head_bwd(TrainWs w, const float *__restrict__ w8)
+// dz7 <- (dz8 . W8) * LeakyReLU'(C3)   (the gradient at the colour MLP's last pre-activation; dz7 == C3: in place -- the
+// bf16x3 recompute chain -- or a buffer of its own, which leaves a render's tape intact)
+__global__ void __launch_bounds__(256) k_train_color_head_bwd(TrainWs w, const float *__restrict__ w8, float *dz7)
 {
     const int lane = threadIdx.x & 63;
     const int wv = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwv = (gridDim.x * blockDim.x) >> 6;
@@ -1677,7 +1680,8 @@ __global__ void __launch_bounds__(256) k_train_color_head_bwd(TrainWs w, const f
         const float4 sg = w.sg[v], go = w.d_out[v];
         const float dz[3] = {go.y * 1.002f * sg.x * (1.0f - sg.x), go.z * 1.002f * sg.y * (1.0f - sg.y),
                              go.w * 1.002f * sg.z * (1.0f - sg.z)};
-        float *c3 = w.C3 + (int64_t)v * LD_C;
+        const float *c3 = w.C3 + (int64_t)v * LD_C;
+        float *d7 = dz7 + (int64_t)v * LD_C;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const float a = c3[64 * q + lane];
@@ -1687,7 +1691,7 @@ __global__ void __launch_bounds__(256) k_train_color_head_bwd(TrainWs w, const f
                 dw[c][q] += dz[c] * a;
                 g += dz[c] * wr[c][q];
             }
-            c3[64 * q + lane] = g * (a > 0.f ? 1.0f : 0.1f);
+            d7[64 * q + lane] = g * (a > 0.f ? 1.0f : 0.1f);
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) db[c] += dz[c];
@@ -2475,17 +2479,18 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
     hipLaunchKernelGGL(k_train_composite_bwd, dim3((unsigned)((R + 255) / 256)), eb, 0, st, cr, *opts, R, ws.ray_cnt,
                        ws.ray_off, ws.ray_flag, ws.smp_loc, ws.n_sel, tw, d_grad_rgb, d_rgb_recomputed);
     // colour MLP
-    hipLaunchKernelGGL(k_train_color_head_bwd, dim3(256), eb, 0, st, tw, d_w[8]);  // C3 <- dZ7
-    hipLaunchKernelGGL(k_reduce_rows, dim3((387 + 15) / 16), eb, 0, st, tw.part, 1024, 388, 387, 384, tw.dWp[8], tw.dbp[8]);
     // exact mode: every data gradient goes to its own buffer (nothing is written over an activation a weight gradient
-    // still reads), the seven weight-gradient GEMMs are queued and leave together at the end
+    // still reads -- or over anything a taped render left: a second pnr_render_backward on the same render finds the tape
+    // as the first did), the seven weight-gradient GEMMs are queued and leave together at the end
     const bool batched = !bf;
+    hipLaunchKernelGGL(k_train_color_head_bwd, dim3(256), eb, 0, st, tw, d_w[8], batched ? tw.D7 : tw.C3);  // dZ7
+    hipLaunchKernelGGL(k_reduce_rows, dim3((387 + 15) / 16), eb, 0, st, tw.part, 1024, 388, 387, 384, tw.dWp[8], tw.dbp[8]);
     WgradQueue wq(tw.part, POOL_FLOATS);
     if (batched) {
-        gemm_data(st, bf, tw.C3, LD_C, tw.Wp[7], 128, tw.WT[7], tw.D6, LD_C, 128, 128, 128, n_smp, smp_max, sgC2, tw.C2);   // dZ6
+        gemm_data(st, bf, tw.D7, LD_C, tw.Wp[7], 128, tw.WT[7], tw.D6, LD_C, 128, 128, 128, n_smp, smp_max, sgC2, tw.C2);   // dZ6
         gemm_data(st, bf, tw.D6, LD_C, tw.Wp[6], 128, tw.WT[6], tw.D5, LD_C, 128, 128, 128, n_smp, smp_max, sgC1, tw.C1);   // dZ5
         gemm_data(st, bf, tw.D5, LD_C, tw.Wp[5], 288, tw.WT[5], tw.DAGG, 256, 256, 128, 0, n_smp, smp_max);            // dAGG
-        wq.add(tw.C3, LD_C, tw.C2, LD_C, tw.dWp[7], 128, 128, 128, n_smp, smp_max, tw.dbp[7]);
+        wq.add(tw.D7, LD_C, tw.C2, LD_C, tw.dWp[7], 128, 128, 128, n_smp, smp_max, tw.dbp[7]);
         wq.add(tw.D6, LD_C, tw.C1, LD_C, tw.dWp[6], 128, 128, 128, n_smp, smp_max, tw.dbp[6]);
         wq.add(tw.D5, LD_C, tw.XC, LD_XC, tw.dWp[5], 288, 128, 288, n_smp, smp_max, tw.dbp[5]);
     } else {
@@ -2536,7 +2541,10 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
         C.dirs = d_dirs;
         for (int i = 0; i < 9; ++i) C.Rw2c[i] = weights->Rw2c[i];
         C.K = K;
-        launch_pairs_bwd(C, rows_max, st);
+        {
+            const int rcc = launch_pairs_bwd(C, rows_max, st);
+            if (rcc != PNR_OK) return rcc;
+        }
         wq.add(tw.D3, LD_H, tw.G1, LD_H, tw.dWp[3], 256, 256, 256, n_rows, rows_max, tw.dbp[3]);
         wq.add(tw.D2, LD_H, tw.H2, LD_H2, tw.dWp[2], 264, 256, 264, n_rows, rows_max, tw.dbp[2]);
         wq.add(tw.D1, LD_H, tw.H1, LD_H, tw.dWp[1], 256, 256, 256, n_rows, rows_max, tw.dbp[1]);

@@ -43,7 +43,7 @@ struct ChainParams {
 // dst: CHAIN_W_FLOATS + 256 floats (the chain's weight stream, then w4 in accumulator order)
 void launch_pack_chain(const float *w0, const float *w1, const float *w2, const float *w3, const float *w4, float *dst,
                        hipStream_t st);
-void launch_pairs_bwd(const ChainParams &P, int64_t rows_max, hipStream_t st);
+int launch_pairs_bwd(const ChainParams &P, int64_t rows_max, hipStream_t st);   // PNR_OK or a pnr_status_t
 // the mask bits from row-major tapes (a backward that recomputed the MLP chain instead of receiving the render's tape)
 void launch_tape_bits(const int *cnt, const float *H1, const float *H2, const float *G1, const float *G2, size_t bits_rows,
                       unsigned *bits, hipStream_t st);

@@ -21,6 +21,8 @@
 // (d colour, d dir) come out of a ninth output tile of the W2^T layer.  The kernel also counts the rows of every touched
 // point (integer atomics) for the ordered point sums that follow.
 // 4 224 MFMAs per 32-row tile (the render, whose first layer is factorised per point: 3 360).
+#include <mutex>
+
 #include "pnr_shade_common.h"
 #include "pnr_train_chain.h"
 
@@ -502,19 +504,32 @@ void launch_pack_chain(const float *w0, const float *w1, const float *w2, const 
     hipLaunchKernelGGL(k_pack_chain, dim3(264), dim3(256), 0, st, w0, w1, w2, w3, w4, dst);
 }
 
-void launch_pairs_bwd(const ChainParams &P, int64_t rows_max, hipStream_t st)
+int launch_pairs_bwd(const ChainParams &P, int64_t rows_max, hipStream_t st)
 {
-    static const int cus = [] {
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        return n > 0 ? n : 256;
-    }();
+    // per DEVICE: the CU count, and the kernel's dynamic-LDS limit raised once (a process may drive several devices)
+    struct PerDevice { int cus = 0; bool lds_set = false; };
+    static PerDevice per_device[64];
+    static std::mutex mu;
+    int dev = 0;
+    PNR_HIP_CHECK(hipGetDevice(&dev));
+    int cus;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        PerDevice &pd = per_device[dev & 63];
+        if (!pd.lds_set) {
+            int n = 0;
+            PNR_HIP_CHECK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+            PNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_train_pairs_bwd),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_B));
+            pd.cus = n > 0 ? n : 256;
+            pd.lds_set = true;
+        }
+        cus = pd.cus;
+    }
     const int64_t tiles = (rows_max + 127) / 128;
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cus, tiles));
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(k_train_pairs_bwd),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_B);
-    (void)attr;
     hipLaunchKernelGGL(k_train_pairs_bwd, dim3(grid), dim3(TPB), (size_t)CHAIN_LDS_B, st, P);
+    return PNR_OK;
 }
 
 void launch_tape_bits(const int *cnt, const float *H1, const float *H2, const float *G1, const float *G2, size_t bits_rows,

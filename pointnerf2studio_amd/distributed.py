@@ -370,7 +370,10 @@ class GradExchange:
         accumulated its rows into the dense tensors `targets` = {'embedding' [.., N, 32], 'color' [.., N, 3], 'dir'
         [.., N, 3]} (None = not trainable); `index` (int32, padded) / `count` (int64 [1], device) are the rows it touched
         (RendererHIP.touched).  Only those rows travel (reduce_points); returns the union of all ranks' rows in the same
-        padded form, which is what the caller has to clean before the tensors are reused.  One host read (the count)."""
+        padded form, which is what the caller has to clean before the tensors are reused.  One host read (the count).
+        The rows are sent as the tensors hold them: they must hold THIS step's contribution only.  Gradient accumulation
+        over several backward calls and DDP's no_sync are not supported on this path -- PointNerf._point_grad_targets
+        raises when a point tensor's .grad is already set before a data-parallel backward."""
         n = int(count.item())
         touched = index[:n].to(torch.long)
         ref = next(t for t in targets.values() if t is not None)

@@ -227,6 +227,8 @@ class _ConfLossFn(torch.autograd.Function):
 class PointNerf(Model):
     """studio_model.py:121-505."""
     config: PointNerfConfig
+    _ALL_ROWS = "all rows"              # marker in _gdirty: clear the whole buffer instead of listed rows
+    _MAX_PENDING_ROW_LISTS = 4
 
     def __init__(self, config: PointNerfConfig, cameras=None, point_state_dict: Optional[Dict] = None,
                  **kwargs) -> None:
@@ -590,10 +592,20 @@ class PointNerf(Model):
                 buf = self._gbuf[key] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 self._gdirty[key] = []
             if p.grad is None:
-                for index, count in self._gdirty[key]:
-                    clear.setdefault(id(index), [index, count, {}])[2][key] = buf
+                if self._gdirty[key] is self._ALL_ROWS:
+                    buf.zero_()     # (see _after_point_backward: too many row lists were pending)
+                else:
+                    for index, count in self._gdirty[key]:
+                        clear.setdefault(id(index), [index, count, {}])[2][key] = buf
                 self._gdirty[key] = []
                 p.grad = buf
+            elif self.grad_exchange is not None and self.grad_exchange.world > 1:
+                # the row exchange sends what the touched rows of .grad hold AFTER the local accumulation: with an earlier
+                # backward's sums still in there, rows already exchanged would be sent again (wrong scale, ranks diverge)
+                raise RuntimeError(
+                    f"points_{key}.grad is set before a data-parallel backward: gradient accumulation over several "
+                    "backward calls (and no_sync) is not supported with the sparse row exchange -- call "
+                    "zero_grad(set_to_none=True) between steps")
             elif p.grad.data_ptr() != buf.data_ptr() and not (p.grad.is_contiguous() and p.grad.dtype == torch.float32):
                 raise RuntimeError(f"points_{key}.grad is not a contiguous float32 tensor")
             out[key] = p.grad
@@ -611,7 +623,16 @@ class PointNerf(Model):
         for key, t in targets.items():
             buf = self._gbuf.get(key)
             if t is not None and buf is not None and t.data_ptr() == buf.data_ptr():
-                self._gdirty[key].append((index, count))
+                pending = self._gdirty[key]
+                if pending is self._ALL_ROWS:
+                    continue
+                # the caller keeps `.grad` set (zero_grad(set_to_none=False), or accumulation over several backwards):
+                # nothing consumes the lists meanwhile.  Bounded: beyond a few pending lists (each an int32 tensor of up
+                # to min(points in voxel lists, cap * K) entries) the whole buffer is zeroed when it is next handed out
+                if len(pending) >= self._MAX_PENDING_ROW_LISTS:
+                    self._gdirty[key] = self._ALL_ROWS
+                else:
+                    pending.append((index, count))
 
     def _get_outputs_fused_grad(self, ray_bundle):
         """With autograd: pnr_render_views forwards (the reference's 0.3 jitter with a fresh seed per call; clamped only

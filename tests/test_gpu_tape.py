@@ -83,3 +83,50 @@ def test_taped_step_against_the_oracles_autograd(oracle, gpu_device):
         scale = want.abs().max().item()
         err = (got[name].cpu() - want).abs().max().item()
         assert err <= NORTH_STAR["grad_rel"] * scale + 1e-12, f"{name}: {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("K,dense_env", [(8, None), (16, None), (8, "2")])
+def test_backward_twice_on_one_taped_render_returns_the_same_bits(oracle, gpu_device, K, dense_env):
+    """A backward must not consume the tape: the colour MLP's last data gradient used to be written over the taped C3, so a
+    second pnr_render_backward on the same render (loss.backward(retain_graph=True) and another backward) differentiated
+    its own dZ7 as if it were the activation.  Every data gradient has its own buffer now; two backwards return the same
+    bits, also with a different cotangent in between.  dense_env: PNR_DENSE_UNITS=2 would route K = 8 / 16 to the dense
+    pair kernel, which writes no tape -- a render that was asked for the tape keeps the kernels that write it (the
+    library reads the variable once per process: the case runs in a child interpreter)."""
+    if dense_env is not None:
+        import os
+        import subprocess
+        import sys
+        env = dict(os.environ, PNR_DENSE_UNITS=dense_env)
+        p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu",
+                            f"{__file__}::test_backward_twice_on_one_taped_render_returns_the_same_bits[8-None]"],
+                           env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+        return
+    pts = small_scene(80000)
+    P = 12 if K == 8 else 26
+    cfg = oracle_cfg(oracle, SR=32, K=K, P=P)
+    w = synthetic.make_weights(0, sigma_scale=300.0, bias_scale=0.1)
+    campos, camrot, dirs = camera_rays(28, 36, az=75.0)
+    scene, wh, hyp, info = build_hip(pts, cfg, gpu_device, weights=w)
+    dev = gpu_device
+    N = pts["xyz"].shape[0]
+    gen = torch.Generator().manual_seed(3)
+    G = torch.randn(dirs.shape[0], 3, generator=gen).to(dev)
+    G2 = torch.randn(dirs.shape[0], 3, generator=gen).to(dev)
+    wd = {k: v.to(dev) for k, v in w.items()}
+    rnd = RendererHIP(scene, wh, SR=32, K=K, eval_clamp=False, tape=True)
+    rnd.render(dirs.to(dev), campos, camrot, 2.0, 6.0)
+    first = {k: v.clone() for k, v in rnd.backward(G, wd, N).items()}
+    rnd.backward(G2, wd, N)
+    again = rnd.backward(G, wd, N)
+    assert first["mlp_color.layers.2.weight"].abs().max().item() > 0
+    for k, v in first.items():
+        assert torch.equal(v, again[k]), f"{k}: a repeated backward on the same taped render differs"
+    # ... and the tape is what the recompute path computes (the taped step is not merely self-consistent)
+    ref = RendererHIP(scene, wh, SR=32, K=K, eval_clamp=False, tape=False)
+    ref.render(dirs.to(dev), campos, camrot, 2.0, 6.0)
+    want = ref.backward(G, wd, N)
+    for k in ("mlp_color.layers.2.weight", "mlp_color.layers.1.weight", "field_output_color.net.weight"):
+        rel = ((again[k] - want[k]).double().norm() / want[k].double().norm()).item()
+        assert rel <= 1e-2, f"{k}: {rel:.3e}"

@@ -41,24 +41,3 @@ for jitter, seed, az in [(0.3, 5, 75.0), (0.0, 5, 75.0), (0.3, 6, 75.0), (0.3, 7
     e0 = (res[False][k] - want[k]).abs().max().item() / sc
     e1 = (res[True][k] - want[k]).abs().max().item() / sc
     print(f"   {k:30s} recompute-vs-oracle {e0:.2e}   taped-vs-oracle {e1:.2e}")
-import sys; sys.exit(0)
-pts_g = dict(pts); pts_g["embedding"] = pts["embedding"].clone().requires_grad_(True)
-w_g = {k: v.clone().requires_grad_(True) for k, v in w.items()}
-ref = O.render(pts_g, w_g, cfg, campos[None].expand(R, 3), dirs, 2.0, 6.0, camrot, jitter=jitter, u=u, training=True)
-(ref["coarse_raycolor"] * G).sum().backward()
-scene, wh, hyp, info = build_hip(pts, cfg, dev, weights=w)
-N = pts["xyz"].shape[0]
-wd = {k: v.to(dev) for k, v in w.items()}
-res = {}
-for tape in (False, True):
-    rnd = RendererHIP(scene, wh, SR=SR, K=K, eval_clamp=False, tape=tape, jitter=jitter, seed=5)
-    rnd.render(dirs.to(dev), campos, camrot, 2.0, 6.0)
-    res[tape] = {k: v.cpu() for k, v in rnd.backward(G.to(dev), wd, N).items()}
-want = {"embedding": pts_g["embedding"].grad.reshape(-1, 32)}
-want.update({k: v.grad for k, v in w_g.items()})
-for k in ["embedding", "mlp_base.layers.0.weight", "mlp_base.layers.1.weight", "mlp_head.layers.0.weight", "mlp_head.layers.1.weight", "mlp_color.layers.0.weight"]:
-    sc = want[k].abs().max().item()
-    e0 = (res[False][k] - want[k]).abs().max().item() / sc
-    e1 = (res[True][k] - want[k]).abs().max().item() / sc
-    e01 = (res[True][k] - res[False][k]).abs().max().item() / sc
-    print(f"{k:30s} recompute-vs-oracle {e0:.2e}   taped-vs-oracle {e1:.2e}   taped-vs-recompute {e01:.2e}")
