@@ -12,9 +12,10 @@ Every body of get_outputs is the fused HIP path (include/pnr.h):
     into persistent dense buffers handed out as `.grad` (no 768-MB zero fill per step), the packed point rows are
     refreshed by the render itself from the bound parameters (no O(N) re-pack per step), and a step contains ONE
     device-to-host read (the bundle's camera, near and far).
-The reference's own op sequence under torch autograd survives as `_get_outputs_autograd`, reachable only with
-`hip_allow_torch_fallback=True` (the fused-vs-autograd comparison test); a configuration the fused path does not cover
-raises instead of landing on rocBLAS silently.  There is no CPU path anywhere.
+There is no PyTorch-op render in this package and no CPU path anywhere: a configuration the fused kernels do not cover
+(or hip_fused_training=False) raises.  The reference's op sequence under torch autograd, which the fused training step is
+compared with, is test infrastructure (tests/autograd_reference_path.py) and reaches the model only through the
+`unfused_outputs_fn` hook a test installs.
 """
 from __future__ import annotations
 
@@ -119,8 +120,6 @@ class PointNerfConfig(ModelConfig):
     # training: a render workspace sized for the worst case (every ray selects SR samples) cannot overflow, so a step
     # needs no host read of the counters; used while render + backward workspaces stay below this many GiB
     hip_train_workspace_gb: float = 48.0
-    # the reference's op sequence under torch autograd (rocBLAS GEMMs) instead of the fused kernels: only when asked
-    hip_allow_torch_fallback: bool = False
     # renders that a backward follows write the backward's activation tape themselves (pnr_render_opts_t.d_tape): the
     # backward skips its four recompute GEMMs
     hip_tape_from_render: bool = True
@@ -227,6 +226,9 @@ class _ConfLossFn(torch.autograd.Function):
 class PointNerf(Model):
     """studio_model.py:121-505."""
     config: PointNerfConfig
+    # hook: (model, ray_bundle) -> outputs for calls the fused path does not serve.  None in the product; the tests that
+    # compare the fused training step with torch autograd install tests/autograd_reference_path.get_outputs_autograd
+    unfused_outputs_fn = None
     _ALL_ROWS = "all rows"              # marker in _gdirty: clear the whole buffer instead of listed rows
     _MAX_PENDING_ROW_LISTS = 4
 
@@ -727,89 +729,13 @@ class PointNerf(Model):
             return self._get_outputs_fused(ray_bundle)
         if self._fusable() and (getattr(c, "hip_fused_training", True) or not self.training):
             return self._get_outputs_fused_grad(ray_bundle)
-        if not getattr(c, "hip_allow_torch_fallback", False):
+        if self.unfused_outputs_fn is None:
             why = ("hip_fused_training is off" if self._fusable() else
                    "the fused kernels cover the default network shape only (32 features, 3/5/4 frequencies, "
                    "agg_dist_pers 20, 256/128 hidden units, 2+2+3 layers, colour and dir inputs, unit axis weights)")
-            raise RuntimeError(f"PointNerf.get_outputs: {why}; the reference's op sequence under torch autograd runs only "
-                               f"with hip_allow_torch_fallback=True")
-        return self._get_outputs_autograd(ray_bundle)
-
-    # ---- the reference's op sequence under torch autograd (hip_allow_torch_fallback only) -----------------------
-    def _get_outputs_autograd(self, ray_bundle):
-        """studio_model.py:263-399 on device tensors; the query inside neural_points() is the HIP op.  Not a product
-        path: the cross-check of the fused training step (tests/test_gpu_plugin.py) and the only way to run a network
-        shape the fused kernels do not cover."""
-        (sampled_color, sampled_Rw2c, sampled_dir, sampled_embedding, sampled_xyz_pers, sampled_xyz, sampled_conf,
-         sample_loc_tensor, sample_loc_w_tensor, sample_pnt_mask, sample_ray_dirs_tensor, vsize_np,
-         ray_mask_tensor) = self.neural_points(ray_bundle)
-        dev = sample_loc_w_tensor.device
-        sample_valid = torch.any(sample_pnt_mask, dim=-1).view(-1)
-        total_len = len(sample_valid)
-        in_shape = sample_loc_w_tensor.shape
-        B, R, SR, K = sample_pnt_mask.shape
-        if R > 0:
-            xdist = sampled_xyz_pers[..., 0] * sampled_xyz_pers[..., 2] - (sample_loc_tensor[..., 0] * sample_loc_tensor[..., 2])[..., None]
-            ydist = sampled_xyz_pers[..., 1] * sampled_xyz_pers[..., 2] - (sample_loc_tensor[..., 1] * sample_loc_tensor[..., 2])[..., None]
-            zdist = sampled_xyz_pers[..., 2] - sample_loc_tensor[..., 2][..., None]
-            dists = torch.cat([sampled_xyz - sample_loc_w_tensor[..., None, :], torch.stack([xdist, ydist, zdist], -1)], -1)
-        else:
-            dists = torch.zeros([B, R, SR, K, 6], device=dev)
-        axis_weight = torch.as_tensor(self.config.axis_weight, dtype=torch.float32, device=dev)[None, None, None, None, :]
-        weight = self.linear(dists, sample_pnt_mask, axis_weight=axis_weight)
-        weight = weight / torch.clamp(torch.sum(weight, dim=-1, keepdim=True), min=1e-8)
-        conf_coefficient = None
-        if self.training:
-            conf = sampled_conf[..., 0]
-            conf_coefficient = conf - (conf - torch.clamp(conf, min=0.0001, max=1)).detach()
-
-        flat = sample_pnt_mask.view(-1)
-        Rt = sampled_Rw2c.transpose(-1, -2)
-        viewdirs = self.direction_encoding(sample_ray_dirs_tensor.reshape(-1, 3) @ Rt)
-        ori_viewdirs, viewdirs = viewdirs[..., :3], viewdirs[..., 3:]
-        viewdirs = viewdirs[sample_valid, :]
-        d = dists.view(-1, 6)[flat, :]
-        d = torch.cat([d[..., :3] @ Rt, d[..., 3:]], dim=-1)
-        feat = sampled_embedding.reshape(-1, sampled_embedding.shape[-1])[flat, :]
-        feat = torch.cat([feat, self.feature_encoding(feat), self.dists_encoding(d)], dim=-1)
-        weight = weight.view(B * R * SR, K, 1)
-        feat = self.mlp_base(feat)
-        col = sampled_color.reshape(-1, 3)[flat, :]
-        sdir = sampled_dir.reshape(-1, 3)[flat, :] @ Rt
-        ov = ori_viewdirs[..., None, :].repeat(1, K, 1).view(-1, 3)[flat, :]
-        feat = torch.cat([feat, col, sdir - ov, torch.sum(sdir * ov, dim=-1, keepdim=True)], dim=-1)
-        feat = self.mlp_head(feat)
-        alpha = self.field_output_density(feat)
-        holder = torch.zeros([B * R * SR * K, 1], dtype=torch.float32, device=dev)
-        holder[flat, :] = alpha
-        alpha = torch.sum(holder.view(B * R * SR, K, 1) * weight, dim=-2).view(-1, 1)[sample_valid, :]
-        holder = torch.zeros([B * R * SR * K, feat.shape[-1]], dtype=torch.float32, device=dev)
-        holder[flat, :] = feat
-        feat = torch.sum(holder.view(B * R * SR, K, -1) * weight, dim=-2).view(-1, feat.shape[-1])[sample_valid, :]
-        color = self.field_output_color(self.mlp_color(torch.cat([feat, viewdirs], dim=-1)))
-        color = color * (1 + 2 * 0.001) - 0.001
-        decoded = torch.zeros([total_len, 4], dtype=torch.float32, device=dev)
-        decoded[sample_valid] = torch.cat([alpha, color], dim=-1)
-        decoded = decoded.view(in_shape[:-1] + (4,))
-        sample_valid = sample_valid.view(in_shape[:-1])
-
-        ray_dist = torch.cummax(sample_loc_tensor[..., 2], dim=-1)[0]
-        ray_dist = torch.cat([ray_dist[..., 1:] - ray_dist[..., :-1],
-                              torch.full((B, R, 1), vsize_np[2], device=dev)], dim=-1)
-        m = torch.logical_or(ray_dist < 1e-8, ray_dist > 2 * vsize_np[2]).to(torch.float32)
-        ray_dist = (ray_dist * (1.0 - m) + m * vsize_np[2]) * sample_valid.float()
-        sigma = decoded[..., 0] * sample_valid.float()
-        opacity = 1 - torch.exp(-sigma * ray_dist)
-        acc_t = torch.cumprod(1. - opacity + 1e-10, dim=-1)
-        acc_t = torch.cat([torch.ones((B, R, 1), device=dev), acc_t[:, :, :-1]], dim=-1)
-        blend_weight = (opacity * acc_t).unsqueeze(-1)
-        output = {"coarse_raycolor": self.rgb_renderer(rgb=decoded[..., 1:4], weights=blend_weight),
-                  "ray_mask": ray_mask_tensor}
-        output = self.fill_invalid(output)
-        output["ray_mask"] = output["ray_mask"].squeeze(0)
-        if self.training:
-            output["conf_coefficient"] = conf_coefficient
-        return output
+            raise RuntimeError(f"PointNerf.get_outputs: {why}; this package holds no PyTorch-op render to fall back to "
+                               f"(PointNerf.unfused_outputs_fn is the hook the comparison tests install)")
+        return self.unfused_outputs_fn(self, ray_bundle)
 
     # ---- the rest of the plugin surface ---------------------------------------------------------------------
     def get_param_groups(self) -> Dict[str, List[Parameter]]:

@@ -91,7 +91,8 @@ def test_fused_training_step_equals_autograd_path(oracle, gpu_device):
     model.train()
     model.neural_points.jitter = 0.0
     model.config.hip_mlp_mode = "fp32"
-    model.config.hip_allow_torch_fallback = True     # the autograd side of this comparison IS the fenced fallback
+    from autograd_reference_path import get_outputs_autograd
+    model.unfused_outputs_fn = get_outputs_autograd  # the autograd side of this comparison: test infrastructure, hooked in
     torch.manual_seed(3)
     image = torch.rand(bundle.directions.shape[0], 3, device=gpu_device)
 

@@ -114,21 +114,27 @@ def test_training_callbacks_invalidate_packed_copies():
 
 
 def test_unfusable_configuration_raises_instead_of_falling_back_to_torch():
-    """No run lands on the PyTorch-op restatement silently: a network shape the fused kernels do not cover, or
-    hip_fused_training = False, raises unless hip_allow_torch_fallback is set (checked before any device work)."""
+    """The product holds no PyTorch-op render: a network shape the fused kernels do not cover, or hip_fused_training =
+    False, raises (checked before any device work).  The op sequence the comparison tests use lives under tests/ and reaches
+    the model only through the unfused_outputs_fn hook."""
     from pointnerf2studio_amd.ns_compat import RayBundle
     m = _cpu_model()
     b = RayBundle(origins=torch.zeros(4, 3), directions=torch.zeros(4, 3), nears=torch.full((4, 1), 2.0),
                   fars=torch.full((4, 1), 6.0), metadata={"camrotc2w": torch.eye(3)})
     m.train()
     m.config.hip_fused_training = False
-    with pytest.raises(RuntimeError, match="hip_allow_torch_fallback"):
+    with pytest.raises(RuntimeError, match="no PyTorch-op render"):
         m.get_outputs(b)
     m.config.hip_fused_training = True
     m.config.num_dist_freqs = 4          # not the shape the kernels are built for
-    with pytest.raises(RuntimeError, match="hip_allow_torch_fallback"):
+    with pytest.raises(RuntimeError, match="no PyTorch-op render"):
         m.get_outputs(b)
-    assert PointNerfConfig().hip_allow_torch_fallback is False
+    assert type(m).unfused_outputs_fn is None and not hasattr(PointNerfConfig(), "hip_allow_torch_fallback")
+    import pointnerf2studio_amd.model as pm
+    assert "cumprod" not in open(pm.__file__).read()       # the composite as torch ops is not in the product
+    seen = []
+    m.unfused_outputs_fn = lambda model, bundle: seen.append((model, bundle)) or {"hooked": True}
+    assert m.get_outputs(b) == {"hooked": True} and seen == [(m, b)]
 
 
 def test_weighted_conf_loss_equals_the_references_mean():

@@ -34,9 +34,12 @@ def main():
     sd = {"neural_points.xyz": pts["xyz"], "neural_points.points_embeding": pts["embedding"],
           "neural_points.points_conf": pts["conf"], "neural_points.points_dir": pts["dir"],
           "neural_points.points_color": pts["color"], "neural_points.Rw2c": pts["Rw2c"]}
-    cfg = PointNerfConfig(ranges=list(synthetic.CHAIR_RANGES), max_o=410000, enable_collider=False, hip_mlp_mode=args.mode,
-                          hip_allow_torch_fallback=True)   # (the autograd leg IS the fenced fallback)
+    cfg = PointNerfConfig(ranges=list(synthetic.CHAIR_RANGES), max_o=410000, enable_collider=False, hip_mlp_mode=args.mode)
     model = PointNerf(cfg, point_state_dict=sd).to(dev)
+    # the autograd leg: the reference's op sequence under torch autograd (test infrastructure, hooked in)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from autograd_reference_path import get_outputs_autograd
+    model.unfused_outputs_fn = get_outputs_autograd
     model.load_state_dict(synthetic.make_weights(0, sigma_scale=300.0, bias_scale=0.1), strict=False)
     model.train()
     campos, camrot = synthetic.make_camera(35.0, 30.0)
