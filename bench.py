@@ -35,8 +35,13 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
+# Runtime environment defaults, set before torch (and with it the HIP / HSA runtime) is even imported: a value set after
+# the first HIP call is never read.  dmabuf IPC is the only form the pool's host driver supports (RCCL and tensor
+# sharing across processes fail with `hipIpcGetMemHandle: invalid argument` under the legacy mode).
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -54,6 +59,7 @@ MFMA_FLOPS_PER_PAIR_BF16 = 1_302_528   # executed: 1272 x v_mfma_f32_32x32x16_bf
 FLOPS_PER_SAMPLE = 137_984     # 2 * (280*128 + 2*128*128 + 128*3)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X dense bf16 matrix peak (no 2:1 sparsity)
+PEAK_HBM_GBS = 8000.0           # MI355X HBM3E, ~8 TB/s (MI355X_MICROARCH.md)
 
 VSCALE = [2, 2, 2]
 KSIZE = [3, 3, 3]
@@ -62,7 +68,42 @@ KSIZE = [3, 3, 3]
 REF_CHUNK = 2304   # eval_num_rays_per_chunk of the reference (studio_config.py:25)
 
 
-def cpu_baseline(points, weights, cfgd, n_side, view, passes=5, budget_s=270.0):
+def host_cpu():
+    """(model name, physical cores, logical CPUs) of this box from /proc/cpuinfo: physical = distinct (package, core id)."""
+    model, cores, logical = "", set(), 0
+    try:
+        with open("/proc/cpuinfo") as f:
+            pkg = None
+            for ln in f:
+                key, _, val = ln.partition(":")
+                key, val = key.strip(), val.strip()
+                if key == "processor":
+                    logical += 1
+                elif key == "model name" and not model:
+                    model = val
+                elif key == "physical id":
+                    pkg = val
+                elif key == "core id":
+                    cores.add((pkg, val))
+    except OSError:
+        pass
+    logical = logical or (os.cpu_count() or 1)
+    return model, (len(cores) or logical), logical
+
+
+def cpu_threads(requested: int) -> int:
+    """Threads of the CPU-baseline legs: --cpu-threads, default (0) one per PHYSICAL core (BASELINE.md section 2 /
+    SURVEY.md section 8d: "all physical cores"; the GEMM-bound oracle gains nothing from the SMT siblings), capped by the
+    CPUs this process may run on (a container's share)."""
+    _, physical, logical = host_cpu()
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = logical
+    return max(1, min(requested or physical, allowed))
+
+
+def cpu_baseline(points, weights, cfgd, n_side, view, passes=5, budget_s=270.0, threads=0):
     """Times the CPU oracle (a port of the reference's PyTorch path) on an n_side x n_side centre window of the
     workload, as BASELINE.md section 2 specifies: wall clock, median of `passes` after one warm-up, in two flavours --
     (ii) the voxel grid built once for the sample (`value`: the stricter baseline) and (i) "as written": the sample
@@ -81,8 +122,7 @@ def cpu_baseline(points, weights, cfgd, n_side, view, passes=5, budget_s=270.0):
     y0, x0 = (H - n_side) // 2, (W - n_side) // 2
     dirs = synthetic.make_rays(H, W, campos, camrot, cfgd["angle_x"], y0=y0, y1=y0 + n_side, x0=x0, x1=x0 + n_side)
     n = dirs.shape[0]
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    torch.set_num_threads(cpu_threads(threads))
 
     def one(d):
         return O.render(points, weights, cfg, campos[None].expand(d.shape[0], 3), d, near, far, camrot)
@@ -103,13 +143,9 @@ def cpu_baseline(points, weights, cfgd, n_side, view, passes=5, budget_s=270.0):
                 one(dirs[c0:c0 + REF_CHUNK].contiguous())
             dt_written = time.time() - t0
     dt = sorted(times)[len(times) // 2]
-    cpu_model = ""
-    try:
-        with open("/proc/cpuinfo") as f:
-            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
-    except OSError:
-        pass
-    return dict(value=n / dt, unit="rays/s", cores=torch.get_num_threads(), kind="port",
+    cpu_model, physical, logical = host_cpu()
+    return dict(value=n / dt, unit="rays/s", cores=torch.get_num_threads(), threads=torch.get_num_threads(),
+                physical_cores=physical, logical_cpus=logical, kind="port",
                 sample=f"{n_side}x{n_side} centre window of view {view} ({n} rays) against the full "
                        f"{points['xyz'].shape[0]}-point cloud, jitter 0, voxel grid built once for the sample; median of "
                        f"{len(times)} passes after a warm-up ({', '.join(f'{t:.1f}' for t in times)} s)",
@@ -139,6 +175,98 @@ def pmc_traffic(kernel, workload_key):
             except (OSError, KeyError, ValueError):
                 continue
     return None
+
+
+QUERY_STAGE_KERNELS = ("k_select", "k_expand", "k_knn3", "k_knn3_coop", "k_knn", "k_compact_valid", "k_list_points",
+                       "k_pair_weights")
+
+
+def pmc_traffic_sum(kernels, workload_key):
+    """Sum of hbm_bytes_per_launch_corrected over the named kernels (every template instance of each) in the newest
+    committed PMC pass collected on THIS workload; (bytes, {kernel: bytes}, path, collected_at) or None."""
+    import glob
+    for rnd in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", rnd, "pmc_hbm_traffic*.json"))):
+            try:
+                with open(path) as f:
+                    d = json.load(f)
+                if d.get("workload_key") != workload_key:
+                    continue
+                per = {n: v["hbm_bytes_per_launch_corrected"] for n, v in d["kernels"].items()
+                       if n.split("<")[0].split("::")[-1] in kernels}
+                if per:
+                    return sum(per.values()), per, os.path.relpath(path, ROOT), d.get("collected_at", "")
+            except (OSError, KeyError, ValueError):
+                continue
+    return None
+
+
+def cfg0_leg(args, dev):
+    """BASELINE cfg[0] -- 50 k-point chair cloud, 64 x 64 image, SR 32, K 8: "the reference's CPU-runnable case" -- rendered
+    WHOLE by both sides: the CPU oracle on the host cores (median of --cpu-passes after a warm-up; grid built once per
+    frame) and the HIP path through the C ABI on the same rays at jitter 0, with the parity of the two images."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pnr_oracle as O
+    O.build_c_oracle()
+    c = dict(synthetic.SCENE_CONFIGS["cfg0_chair_50k"])
+    H, W, SR, K = c["H"], c["W"], c["SR"], c["K"]
+    points = synthetic.make_scene_points(c, seed=1234)
+    weights = synthetic.make_weights(0, sigma_scale=args.sigma_scale, bias_scale=0.1)
+    cfg = O.OracleConfig()
+    cfg.SR, cfg.K, cfg.P, cfg.max_o, cfg.ranges, cfg.vsize = SR, K, c["P"], c["max_o"], list(c["ranges"]), [c["vsize"]] * 3
+    campos, camrot = synthetic.make_scene_camera(c, 0)
+    dirs = synthetic.make_rays(H, W, campos, camrot, c["angle_x"])
+    n = dirs.shape[0]
+    torch.set_num_threads(cpu_threads(args.cpu_threads))
+
+    def one():
+        return O.render(points, weights, cfg, campos[None].expand(n, 3), dirs, c["near"], c["far"], camrot)
+    one()
+    times = []
+    for _ in range(max(args.cpu_passes, 1)):
+        t0 = time.time()
+        ref = one()
+        times.append(time.time() - t0)
+    dt = sorted(times)[len(times) // 2]
+    # the same frame on the GPU
+    xyz = points["xyz"].to(dev)
+    vs = [c["vsize"]] * 3
+    hyp = grid_hyperparameters(xyz, vs, VSCALE, KSIZE, c["ranges"])
+    scene = SceneHIP()
+    scene.build(xyz, hyp.ranges, hyp.scaled_vsize, hyp.scaled_vdim, KSIZE, KSIZE, c["P"], c["max_o"], True)
+    scene.pack_points(xyz, points["embedding"].to(dev), points["conf"].to(dev), points["dir"].to(dev), points["color"].to(dev))
+    wh = WeightsHIP()
+    wh.pack(weights, points["Rw2c"], dev)
+    rnd = RendererHIP(scene, wh, SR=SR, K=K, D=400, radius_limit=4 * c["vsize"], vsize_z=c["vsize"], precision=args.precision)
+    d_dev = dirs.to(dev)
+    out = rnd.render(d_dev, campos, camrot, c["near"], c["far"])
+    cap = int(out["counters"]["samples_selected"] * 1.05) + 4096
+    for _ in range(5):
+        rnd.render(d_dev, campos, camrot, c["near"], c["far"], cap_samples=cap, sync_counters=False, out=out)
+    torch.cuda.synchronize()
+    iters = 50
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        rnd.render(d_dev, campos, camrot, c["near"], c["far"], cap_samples=cap, sync_counters=False, out=out)
+    torch.cuda.synchronize()
+    g_dt = (time.perf_counter() - t0) / iters
+    diff = out["rgb"].cpu() - ref["coarse_raycolor"]
+    cpu_model, physical, logical = host_cpu()
+    return {
+        "workload": f"cfg0_chair_50k: N={c['N']}, {H}x{W}, D=400, SR={SR}, K={K}, P={c['P']}, jitter 0, view 0, the WHOLE frame "
+                    f"({n} rays) on both sides",
+        "cpu": {"value": n / dt, "unit": "rays/s", "kind": "port", "seconds": dt, "passes": times,
+                "threads": torch.get_num_threads(), "physical_cores": physical, "logical_cpus": logical,
+                "cpu_model": cpu_model},
+        "gpu": {"value": n / g_dt, "unit": "rays/s", "ms_per_frame": g_dt * 1e3, "mode": args.precision,
+                "note": "one pnr_render call per frame, 50 frames back to back; a 4096-ray frame is launch-bound (about "
+                        "twenty kernel launches), not a throughput figure"},
+        "parity": {"max_abs_rgb_err": diff.abs().max().item(),
+                   "ray_mask_equal": bool(torch.equal(out["ray_mask"].cpu(), ref["ray_mask"])),
+                   "psnr_vs_oracle_db": float(-10 * torch.log10((diff ** 2).mean() + 1e-20)),
+                   "rays_kept": int(ref["stats"]["rays_kept"]), "valid_pairs": int(ref["stats"]["valid_pairs"])},
+        "speedup": (n / g_dt) / (n / dt),
+    }
 
 
 def plugin_legs(args, cfgd, points, weights, cams, dev, near, far):
@@ -253,6 +381,10 @@ def main():
     ap.add_argument("--cpu-passes", type=int, default=5, help="timed passes of the CPU baseline (median is reported)")
     ap.add_argument("--cpu-budget-s", type=float, default=270.0, help="wall-clock budget of the CPU-baseline leg: no "
                     "further pass is started once one more would exceed it")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU-baseline legs (0 = one per physical "
+                    "core of the box)")
+    ap.add_argument("--no-cfg0", action="store_true", help="skip the BASELINE cfg[0] leg (50 k points, 64x64: the whole "
+                    "frame on the CPU oracle and on the GPU)")
     ap.add_argument("--sigma-scale", type=float, default=300.0)
     ap.add_argument("--no-other-mode", action="store_true", help="skip the side legs (other arithmetic mode, early "
                     "termination, training step)")
@@ -283,12 +415,27 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rccl_world = None
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if rehearse:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+        # what the collective library itself says about the job (the line's n_gpus is the launcher's WORLD_SIZE): an
+        # all_reduce of ones counts the ranks that took part, an all_gather collects every rank's device
+        ones = torch.ones(1, dtype=torch.int32, device="cpu" if rehearse else dev)
+        dist.all_reduce(ones)
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": local_rank, "device": f"cuda:{local_rank}", "name": props.name,
+                "gcn_arch": getattr(props, "gcnArchName", ""), "pci_bus_id": getattr(props, "pci_bus_id", None),
+                "uuid": str(getattr(props, "uuid", ""))}
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        rccl_world = {"all_reduce_of_ones": int(ones.item()), "backend": dist.get_backend(),
+                      "equals_n_gpus": int(ones.item()) == world, "ranks": every,
+                      "distinct_devices": len({(e["uuid"], e["pci_bus_id"], e["device"]) for e in every})}
+        if int(ones.item()) != world:
+            raise SystemExit(f"the collective saw {int(ones.item())} ranks, WORLD_SIZE says {world}")
     emulate = args.emulate_world > 1 and world == 1
     if emulate:   # per-rank work of an N-rank run, without the collectives (local copy instead of all_gather)
         world, rank = args.emulate_world, args.emulate_rank
@@ -462,6 +609,42 @@ def main():
             "reference_equivalent_tflops": pairs * FLOPS_PER_PAIR / t_both / 1e12 if t_both > 0 else 0.0,
         }
 
+    def roofline_hbm(mode, acc_ms, cnt, n_launch):
+        """The second regime of SURVEY.md section 8(d): stage Q (sample selection + neighbour search: k_select, the scans,
+        k_expand, k_knn3, the valid-sample / distinct-point lists [+ k_pair_weights on the dense-unit path]) is priced
+        against HBM.  achieved = section 8(d)'s ALGORITHMIC bytes of the stage -- R x 40 (ray in, pixel out) + R x D / 8
+        (one occupancy bit per coarse sample) + S x 27 x 8 (cell probes of a shading sample) + C_cand x 16 (candidates
+        distance-tested) -- / the stage's device time (HIP events on the render stream: select + knn)."""
+        rays = n_local
+        S, cand = cnt[3] / n_launch, cnt[5] / n_launch
+        parts = {"rays x 40": rays * 40.0, "rays x D / 8": rays * 400 / 8.0, "valid samples x 216": S * 216.0,
+                 "candidates x 16": cand * 16.0}
+        alg = sum(parts.values())
+        t = (acc_ms[0] + acc_ms[1]) / n_launch / 1e3
+        achieved = alg / t / 1e9 if t > 0 else 0.0
+        key = workload_key.replace(f":{args.precision}:", f":{mode}:")
+        tr = pmc_traffic_sum(QUERY_STAGE_KERNELS, key)
+        out = {
+            "bound": "hbm", "stage": "Q = select + knn (k_select, scans, k_expand, k_knn3, sample / point lists)",
+            "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
+            "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_parts": parts,
+            "algorithmic_bytes_formula": "R*40 + R*D/8 + S*216 + C_cand*16 (SURVEY.md section 8d; S = valid samples)",
+            "avg_stage_ms": t * 1e3, "select_ms": acc_ms[0] / n_launch, "knn_ms": acc_ms[1] / n_launch,
+            "traffic": tr[0] if tr else None,
+            "traffic_per_kernel": tr[1] if tr else None,
+            "traffic_source": (f"{tr[2]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this workload, collected at "
+                               f"{tr[3]}; the scan kernels, which the file averages together with the scene build's, are "
+                               f"not in the sum)" if tr else
+                               "no committed PMC pass matches this workload"),
+            "note": "latency-bound, not bandwidth-bound: the stage moves a few hundred MB per frame in ~1.3 ms through "
+                    "chains of dependent probes (brick record -> list bounds -> candidates); its PMC traffic exceeds the "
+                    "algorithmic bytes mainly by the K x 4-byte neighbour lists and 16-byte sample records it WRITES "
+                    "for the shading stage, which section 8(d)'s formula does not count",
+        }
+        if tr:
+            out["traffic_frac_of_peak"] = tr[0] / t / 1e9 / PEAK_HBM_GBS if t > 0 else None
+        return out
+
     run_steps(rnd, 0, args.warmup)
     elapsed, acc_ms, acc_cnt, n_launch = timed(rnd, args.steps, args.warmup)
     rays_per_step = world * H * W
@@ -586,12 +769,15 @@ def main():
                         "generated in the kernels from pose + intrinsics + pixel ids (pnr_render_camera)",
             },
             "roofline": roofline(args.precision, acc_ms, acc_cnt, n_launch),
+            "roofline_hbm": roofline_hbm(args.precision, acc_ms, acc_cnt, n_launch),
             "stages_ms_per_launch": {n: acc_ms[i] / n_launch for i, n in enumerate(_lib.STAGE_NAMES)},
             "counters_per_launch": {n: acc_cnt[i] / n_launch for i, n in enumerate(_lib.COUNTER_NAMES)},
             "color_mlp_tflops": (samples * FLOPS_PER_SAMPLE / (acc_ms[3] / 1e3) / 1e12) if acc_ms[3] > 0 else None,
             "scene": {"occupied_voxels": info["occupied_voxels"], "points_in_voxel_lists": info["points_in_lists"],
                       "structure_bytes": info["device_bytes"], "build_s": build_s, "cap_samples": cap},
         }
+        if rccl_world is not None:
+            result["rccl_world"] = rccl_world
         if alt is not None:
             result["other_mode"] = alt
         if early is not None:
@@ -604,19 +790,24 @@ def main():
             result["plugin_training_step"] = plugin["train"]
         if world == 1 and not emulate and args.cpu_rays_side > 0:
             cb, ref, dirs, campos, camrot = cpu_baseline(points, weights, cfgd, args.cpu_rays_side, azimuths[0], args.cpu_passes,
-                                                         args.cpu_budget_s)
+                                                         args.cpu_budget_s, args.cpu_threads)
             # parity on the very same rays: HIP render vs the oracle that was just timed
             out = RendererHIP(scene, wh, SR=SR, K=K, D=400, radius_limit=4 * max(VSIZE[0], VSIZE[1]),
                               vsize_z=VSIZE[2], precision=args.precision).render(dirs.to(dev), campos, camrot, near, far)
             # (jitter 0 on both sides: the oracle pass that was timed and this render see the same sample positions)
             err = (out["rgb"].cpu() - ref["coarse_raycolor"]).abs().max().item()
-            result["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "seconds",
-                                                         "cpu_model", "as_written", "counts")}
+            result["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "threads", "physical_cores",
+                                                         "logical_cpus", "kind", "sample", "seconds", "cpu_model",
+                                                         "as_written", "counts")}
             result["parity_on_cpu_sample"] = {
                 "max_abs_rgb_err": err, "ray_mask_equal": bool(torch.equal(out["ray_mask"].cpu(), ref["ray_mask"])),
                 "psnr_vs_oracle_db": float(-10 * torch.log10(((out["rgb"].cpu() - ref["coarse_raycolor"]) ** 2).mean()
                                                              + 1e-20))}
             result["speedup_vs_cpu_baseline"] = value / cb["value"]
+            # BASELINE cfg[0] whole, on both sides (the one configuration defined as the CPU reference path's)
+            if not args.no_cfg0 and args.config == "cfg1_chair_6m":
+                del out
+                result["cfg0_whole_frame"] = cfg0_leg(args, dev)
         print(json.dumps(result), flush=True)
     if world > 1 and not emulate:
         dist.destroy_process_group()

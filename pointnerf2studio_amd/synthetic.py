@@ -172,8 +172,9 @@ SCENE_CONFIGS = {
     # configs[1]: ~6M points, 800x800, 80 samples/ray, K = 8 (the metric's configuration)
     "cfg1_chair_6m": dict(N=6_000_000, H=800, W=800, SR=80, K=8, ranges=CHAIR_RANGES, max_o=410000, P=12, vsize=0.004,
                           near=2.0, far=6.0, points="chair", camera="orbit", angle_x=0.6911112070083618),
-    # configs[2]: lego-like, ~6M points, 800x800, K = 8 (lego bbox and P = 9 of dev_scripts/w_n360/lego_points.sh:59)
-    "cfg2_lego_6m": dict(N=6_000_000, H=800, W=800, SR=80, K=8, ranges=LEGO_RANGES, max_o=410000, P=9, vsize=0.004,
+    # configs[2]: lego-like, ~6M points, 800x800, K = 8 (the lego script's own numbers: bbox dev_scripts/w_n360/
+    # lego_points.sh:59, max_o = 830000 :58, P = 9 :62)
+    "cfg2_lego_6m": dict(N=6_000_000, H=800, W=800, SR=80, K=8, ranges=LEGO_RANGES, max_o=830000, P=9, vsize=0.004,
                          near=2.0, far=6.0, points="lego", camera="orbit", angle_x=0.6911112070083618),
     # configs[3]: DTU-like dense MVSNet cloud, ~10M points, 1600x1200 (W x H: a 4:3 frame), K = 8
     "cfg3_dtu_10m": dict(N=10_000_000, H=1200, W=1600, SR=80, K=8, ranges=CHAIR_RANGES, max_o=410000, P=12, vsize=0.004,

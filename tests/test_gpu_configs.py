@@ -4,10 +4,11 @@ SCENE_CONFIGS; datasets are not reachable):
   * at REDUCED point counts against the CPU oracle, both arithmetic modes: cfg[2] lego-like (lego box, P = 9),
     cfg[3] DTU-like (1600 x 1200 frame: W != H, off-centre windows), cfg[4] ScanNet-like (room shell, camera inside the
     cloud, K = 12, SR = 24, P = 26, vsize 0.008, near 0.1 / far 8);
-  * at FULL size (cfg[1] 6 M / 800 x 800, cfg[3] 10 M / 1600 x 1200, cfg[4] 20 M / 1296 x 968) through size-independent
+  * at FULL size (cfg[1] 6 M / 800 x 800, cfg[2] 6 M lego-like / 800 x 800 with the lego script's max_o = 830000 and
+    P = 9, cfg[3] 10 M / 1600 x 1200, cfg[4] 20 M / 1296 x 968) through size-independent
     properties: bitwise-equal re-render, tiling invariance (the frame rendered in two halves), background rays exactly
     the background colour, accumulated opacity in [0, 1], counter consistency, no capacity overflow, the opt-in bf16x3
-    mode within 1e-4 of the default fp32 mode -- and, for cfg[1] and cfg[3], a window of the full-size frame against the
+    mode within 1e-4 of the default fp32 mode -- and, for cfg[1], cfg[2] and cfg[3], a window of the full-size frame against the
     CPU oracle run on the full-size cloud.
 cfg[0] (50 k points, 64 x 64, SR 32) is in test_gpu_render.py; the 8-GPU form of cfg[2]-[4] is the same per-rank code on
 a tile shard (tests/test_distributed_gloo.py)."""
@@ -154,6 +155,18 @@ def test_cfg1_full_size(oracle, gpu_device):
     ref_0 = oracle.render(pts, _against_oracle.w, cfg, campos[None].expand(dirs.shape[0], 3), dirs, c["near"], c["far"],
                           camrot)
     assert (ref_j["coarse_raycolor"] - ref_0["coarse_raycolor"]).abs().max().item() > 1e-4   # the jitter moved samples
+
+
+def test_cfg2_lego_full_size(oracle, gpu_device):
+    """BASELINE cfg[2]: lego-like, 6 M points, 800 x 800, K 8 with the reference's own numbers for the scene
+    (dev_scripts/w_n360/lego_points.sh:58-62: max_o = 830000, P = 9, the lego box) -- one GPU's view of the 8-GPU
+    configuration: properties at full size + one window against the oracle run on the full 6 M-point cloud."""
+    c, pts, cfg, scene, wh, info = _full_scene(oracle, gpu_device, "cfg2_lego_6m")
+    assert (c["max_o"], c["P"]) == (830000, 9) and info["N"] == 6_000_000 and info["max_o_overflow"] == 0
+    assert info["occupied_voxels"] <= c["max_o"]
+    cnt = _properties(gpu_device, c, scene, wh, cfg, oracle)
+    assert cnt["pairs_valid"] > 5_000_000
+    _against_oracle(oracle, gpu_device, c, pts, scene, wh, cfg, 0, (392, 408, 392, 408), min_kept=100)
 
 
 def test_cfg3_dtu_full_size(oracle, gpu_device):
