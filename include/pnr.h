@@ -404,6 +404,39 @@ int pnr_conf_loss_backward(const pnr_scene_t *scene, const pnr_render_opts_t *op
                            void *d_scratch, const float *d_fwd_out, const float *d_upstream, float *d_grad_conf,
                            void *stream);
 
+/* ---- the optimiser half of the training step: row-sparse Adam for the point tensors --------------------------------
+ * The reference trains the `neural_points` parameter group with Adam at lr 2e-3 (studio_config.py:41-47; nerfstudio's
+ * AdamOptimizerConfig -> torch.optim.Adam, eps 1e-8, no weight decay, no amsgrad).  torch's dense Adam sweeps all N rows
+ * of every point tensor per step although a 4096-ray batch gives ~60 k of 6 M rows a gradient.  A row whose gradient has
+ * been zero since the optimiser was created has exp_avg = exp_avg_sq = 0 and dense Adam moves it by
+ * -step_size * 0 / (0 + eps) = 0: Adam over the rows that EVER had a gradient is exactly dense Adam.
+ *
+ * pnr_rows_merge keeps that set on the device: d_flags [num_rows] int32 (zero-initialised by the caller once),
+ * d_ever [ever_cap >= num_rows] the rows in order of first appearance, *d_ever_count their number (int64, zeroed once).
+ * d_rows / rows_cap / d_n_rows: this step's rows -- rows_cap entries, of which the first min(*d_n_rows, rows_cap) count
+ * when d_n_rows is given (what pnr_render_touched returns); entries outside [0, num_rows) are ignored.
+ *
+ * pnr_adam_rows applies one Adam step to the listed rows of up to PNR_ADAM_MAX_TENSORS tensors that share their row
+ * count (embedding [N,32], color [N,3], dir [N,3], conf [N,1]: ONE launch), in torch.optim.Adam's arithmetic:
+ *   exp_avg    += (1 - beta1) (grad - exp_avg);   exp_avg_sq = exp_avg_sq beta2 + (1 - beta2) grad grad;
+ *   param      -= step_size * exp_avg / (sqrt(exp_avg_sq) / bias_correction2_sqrt + eps)
+ * with step_size = lr / (1 - beta1^step) and bias_correction2_sqrt = sqrt(1 - beta2^step) evaluated by the caller (in
+ * double, as torch does) for the step count AFTER its increment.  d_rows == NULL: every row (rows_cap = num_rows).
+ * Neither call synchronises or reads anything back. */
+#define PNR_ADAM_MAX_TENSORS 8
+typedef struct {
+    float *d_param;          /* [num_rows, width] */
+    const float *d_grad;     /* [num_rows, width] */
+    float *d_exp_avg;        /* [num_rows, width] */
+    float *d_exp_avg_sq;     /* [num_rows, width] */
+    int32_t width;           /* floats per row */
+} pnr_adam_tensor_t;
+int pnr_rows_merge(int32_t *d_flags, int64_t num_rows, int32_t *d_ever, int64_t *d_ever_count, int64_t ever_cap,
+                   const int32_t *d_rows, int64_t rows_cap, const int64_t *d_n_rows, void *stream);
+int pnr_adam_rows(const pnr_adam_tensor_t *tensors, int32_t n_tensors, int64_t num_rows, const int32_t *d_rows,
+                  int64_t rows_cap, const int64_t *d_n_rows, float beta1, float beta2, float eps, float step_size,
+                  float bias_correction2_sqrt, void *stream);
+
 /* ---- probing outputs (point growing) ------------------------------------------------------------------
  * What the reference's legacy model returns with `opt.prob == 1` (models/neural_points_volumetric_model.py:331-352)
  * and run/train_studio.py:335-444 turns into new points: per ray, the shading sample of largest opacity

@@ -564,10 +564,27 @@ def render(points, w, cfg: OracleConfig, origins, directions, near, far, camrotc
     acc[keep] = acc_hit[0]
     out.update(depth=depth, acc=acc, decoded=decoded, sample_valid=sample_valid, sample_pidx=None,
                sample_loc_w=loc_w, blend_weight=bw, pnt_mask=pnt_mask, agg_weight=weight)
+    if training:
+        out["conf_coefficient"] = conf_coefficient(s_conf)      # studio_model.py:288-292,396-397
     if probe:
         out["probe"] = probe_outputs(decoded, sample_valid, loc, loc_w, vsize, weight, s_conf, s_xyz, s_color, s_dir,
                                      s_emb, pnt_mask, ray_mask, R)
     return out
+
+
+def get_loss_dict(outputs, image, training: bool = True, zero_epsilon: float = 1e-3,
+                  zero_one_loss_weights: float = 1e-4) -> Dict[str, torch.Tensor]:
+    """PointNerf.get_loss_dict (studio_model.py:415-431; config defaults :117-118): MSELoss (mean over the elements of
+    the kept rays) + 1e-6, and in training mean(log v + log(1 - v)) * zero_one_loss_weights over the clamped
+    conf_coefficient tensor.  loss_coefficients is nerfstudio's default (every key 1.0) [ns-mem]."""
+    keep = (outputs["ray_mask"] > 0)[..., None].expand(-1, 3)
+    masked_output = torch.masked_select(outputs["coarse_raycolor"], keep).reshape(-1, 3)
+    masked_gt = torch.masked_select(image, keep).reshape(-1, 3)
+    loss = {"ray_masked_coarse_raycolor_loss": torch.mean((masked_gt - masked_output) ** 2) + 1e-6}
+    if training:
+        val = torch.clamp(outputs["conf_coefficient"], zero_epsilon, 1 - zero_epsilon)
+        loss["conf_coefficient_loss"] = torch.mean(torch.log(val) + torch.log(1 - val)) * zero_one_loss_weights
+    return loss
 
 
 # --------------------------------------------------------------------------------------

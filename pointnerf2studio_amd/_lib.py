@@ -36,6 +36,7 @@ EXPORTED_SYMBOLS = [
     "pnr_render_taps",
     "pnr_backward_workspace_bytes", "pnr_render_backward",
     "pnr_conf_loss_workspace_bytes", "pnr_conf_loss", "pnr_conf_loss_backward",
+    "pnr_rows_merge", "pnr_adam_rows",
     "pnr_profile_enable", "pnr_profile_calls", "pnr_profile_read",
 ]
 NUM_STAGES = 6
@@ -85,6 +86,14 @@ class GradsC(C.Structure):
                 ("d_w", C.c_void_p * 9), ("d_b", C.c_void_p * 9),
                 ("d_point_grads", C.c_void_p), ("d_point_index", C.c_void_p), ("point_cap", C.c_int64)]
 
+
+class AdamTensorC(C.Structure):
+    """pnr_adam_tensor_t"""
+    _fields_ = [("d_param", C.c_void_p), ("d_grad", C.c_void_p), ("d_exp_avg", C.c_void_p), ("d_exp_avg_sq", C.c_void_p),
+                ("width", C.c_int32)]
+
+
+ADAM_MAX_TENSORS = 8
 
 _lib: Optional[C.CDLL] = None
 
@@ -176,6 +185,8 @@ def load() -> C.CDLL:
     lib.pnr_conf_loss_workspace_bytes.argtypes = []
     lib.pnr_conf_loss.argtypes = [vp, C.POINTER(RenderOpts), i64, vp, sz, i64, vp, f32, vp, vp, vp]
     lib.pnr_conf_loss_backward.argtypes = [vp, C.POINTER(RenderOpts), i64, vp, sz, i64, vp, f32, vp, vp, vp, vp, vp]
+    lib.pnr_rows_merge.argtypes = [vp, i64, vp, vp, i64, vp, i64, vp, vp]
+    lib.pnr_adam_rows.argtypes = [C.POINTER(AdamTensorC), i32, i64, vp, i64, vp, f32, f32, f32, f32, f32, vp]
     lib.pnr_profile_enable.argtypes = [C.c_int]
     lib.pnr_profile_calls.restype = C.c_int64
     lib.pnr_profile_calls.argtypes = []

@@ -26,7 +26,7 @@ LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
 OBJ_DIR = os.path.join(PKG_DIR, "csrc", "_obj")
 
 SOURCES = ["pnr_scan.hip", "pnr_scene.hip", "pnr_query.hip", "pnr_shade.hip", "pnr_shade_fp32.hip", "pnr_shade_bf16.hip",
-           "pnr_render.hip", "pnr_train.hip", "pnr_train_chain.hip"]
+           "pnr_render.hip", "pnr_train.hip", "pnr_train_chain.hip", "pnr_optim.hip"]
 
 # -ffp-contract=off: the voxel coordinate, the sample position (o + d*t) and the neighbour distance
 # must be evaluated exactly as the reference / oracle do (no FMA contraction); the MLP runs on fp32

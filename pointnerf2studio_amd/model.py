@@ -36,6 +36,7 @@ from .neural_points import NeuralPoints, PointNeRFEncoding
 from .ns_compat import (MLP, DensityFieldHead, Model, ModelConfig, MSELoss, RGBFieldHead, RGBRenderer,
                         TrainingCallback, TrainingCallbackAttributes, TrainingCallbackLocation, WHITE)
 from ._lib import MAX_CAMS
+from .optim import publish_rows
 from .renderer import MLP_TENSOR_ORDER, RendererHIP, WeightsHIP
 
 
@@ -622,6 +623,9 @@ class PointNerf(Model):
         if self.grad_exchange is not None and self.grad_exchange.world > 1:
             index, count = self.grad_exchange.exchange_dense_rows(index, count, targets)
             self.host_reads += 1
+        # the optimiser half of the step: PointRowAdam (optim.py) moves only rows that ever had a gradient -- these ones
+        npts = self.neural_points
+        publish_rows((npts.points_embeding, npts.points_color, npts.points_dir, npts.points_conf), index, count)
         for key, t in targets.items():
             buf = self._gbuf.get(key)
             if t is not None and buf is not None and t.data_ptr() == buf.data_ptr():

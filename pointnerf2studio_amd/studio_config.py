@@ -3,7 +3,8 @@ pointnerf/nerfstudio/studio_{config,pipeline,datamanager}.py:
 
   entry point   nerfstudio.method_configs: pointnerf2studio = pointnerf2studio_amd.studio_config:pointnerf_original
   method name   "pointnerf-original"                                          (studio_config.py:14)
-  optimisers    "fields" Adam 5e-4, "neural_points" Adam 2e-3, exp decay 0.1 / 1e6 steps (studio_config.py:33-48)
+  optimisers    "fields" Adam 5e-4, "neural_points" Adam 2e-3 (as optim.PointRowAdam: the same update over the rows that
+                ever had a gradient), exp decay 0.1 / 1e6 steps                 (studio_config.py:33-48)
   datamanager   one image per batch, `metadata["camrotc2w"]` = c2w[:3,:3]      (studio_datamanager.py:62-110)
 
 The datamanager's logic (one image per batch, the camera rotation in the bundle's metadata) lives in
@@ -24,6 +25,7 @@ from torch.optim import lr_scheduler
 
 from .model import PointNerf, PointNerfConfig
 from .ns_compat import HAVE_NERFSTUDIO
+from .optim import PointRowAdam
 
 METHOD_NAME = "pointnerf-original"
 EXPERIMENT_NAME = "pointnerf2studio"
@@ -137,8 +139,12 @@ if HAVE_NERFSTUDIO:  # pragma: no cover - nerfstudio is not installable in the b
                                                                     find_unused_parameters=True))
                 dist.barrier(device_ids=[local_rank])
 
-    def _opt(lr):
-        return {"optimizer": AdamOptimizerConfig(lr=lr),
+    def _opt(name, lr):
+        # the reference: AdamOptimizerConfig(lr) for both groups (studio_config.py:33-48).  The point tensors take the
+        # same Adam through optim.PointRowAdam -- torch.optim.Adam's update applied to the rows that ever had a gradient
+        # (all others have zero moments and would move by exactly 0): no O(N) sweep per step
+        target = {"_target": PointRowAdam} if name == "neural_points" else {}
+        return {"optimizer": AdamOptimizerConfig(lr=lr, **target),
                 "scheduler": PointNerfSchedulerConfig(lr_decay_exp=0.1, lr_decay_iters=1000000)}
 
     pointnerf_config = TrainerConfig(
@@ -157,7 +163,7 @@ if HAVE_NERFSTUDIO:  # pragma: no cover - nerfstudio is not installable in the b
         steps_per_eval_batch=1000,
         steps_per_eval_image=2000,
         steps_per_eval_all_images=100000,
-        optimizers={name: _opt(lr) for name, lr in OPTIMIZER_GROUPS.items()},
+        optimizers={name: _opt(name, lr) for name, lr in OPTIMIZER_GROUPS.items()},
     )
     pointnerf_original = MethodSpecification(config=pointnerf_config,
                                              description="Point-NeRF for nerfstudio, MI355X-native render path.")

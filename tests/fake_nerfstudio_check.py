@@ -82,9 +82,18 @@ def install_stand_in():
             return 7
 
     @dataclass
-    class AdamOptimizerConfig:
+    class AdamOptimizerConfig:      # nerfstudio.engine.optimizers [ns-mem]: _target, lr, eps, max_norm, weight_decay
+        _target: Type = torch.optim.Adam
         lr: float = 1e-3
         eps: float = 1e-8
+        max_norm: Optional[float] = None
+        weight_decay: float = 0
+
+        def setup(self, params):
+            kwargs = vars(self).copy()
+            kwargs.pop("_target")
+            kwargs.pop("max_norm")
+            return self._target(params, **kwargs)
 
     @dataclass
     class SchedulerConfig(InstantiateConfig):
@@ -149,6 +158,14 @@ def main():
     assert cfg.experiment_name == "pointnerf2studio"
     assert set(cfg.optimizers) == {"fields", "neural_points"}                                # studio_config.py:33-48
     assert cfg.optimizers["fields"]["optimizer"].lr == 0.0005 and cfg.optimizers["neural_points"]["optimizer"].lr == 0.002
+    # both groups are Adam; the point tensors' through the row-sparse form of the same update, constructed the way
+    # nerfstudio's Optimizers does (config.setup(params))
+    from pointnerf2studio_amd.optim import PointRowAdam
+    assert cfg.optimizers["fields"]["optimizer"]._target is torch.optim.Adam
+    assert cfg.optimizers["neural_points"]["optimizer"]._target is PointRowAdam
+    o = cfg.optimizers["neural_points"]["optimizer"].setup([nn.Parameter(torch.zeros(1, 5, 3))])
+    assert isinstance(o, PointRowAdam) and o.defaults["lr"] == 0.002 and o.defaults["eps"] == 1e-8
+    assert o.defaults["betas"] == (0.9, 0.999)
     for group in cfg.optimizers.values():
         sch = group["scheduler"]
         assert (sch.lr_decay_exp, sch.lr_decay_iters) == (0.1, 1000000)

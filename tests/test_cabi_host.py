@@ -193,3 +193,26 @@ def test_backward_workspace_size_and_grads_struct(lib):
     assert 9500 < per_row < 11500, per_row
     assert lib.pnr_backward_workspace_bytes(0, 0) == lib.pnr_backward_workspace_bytes(1, 1)   # clamped, never 0
     assert C.sizeof(_lib.GradsC) == 24 * C.sizeof(C.c_void_p)
+
+
+def test_row_sparse_adam_entry_points_validate_arguments(lib):
+    """pnr_rows_merge / pnr_adam_rows (the optimiser half of the training step): host-side validation, struct layout."""
+    from pointnerf2studio_amd import _lib
+    assert C.sizeof(_lib.AdamTensorC) == 4 * C.sizeof(C.c_void_p) + 8     # four pointers + width, padded to 8
+    assert lib.pnr_rows_merge(None, 10, None, None, 10, None, 4, None, None) == -1 and b"null" in lib.pnr_last_error()
+    one = (_lib.AdamTensorC * 1)()
+    assert lib.pnr_adam_rows(one, 0, 10, None, 10, None, 0.9, 0.999, 1e-8, 1e-3, 1.0, None) == -1
+    assert b"n_tensors" in lib.pnr_last_error()
+    assert lib.pnr_adam_rows(one, 1, 10, None, 5, None, 0.9, 0.999, 1e-8, 1e-3, 1.0, None) == -1
+    assert b"every row" in lib.pnr_last_error()
+    assert lib.pnr_adam_rows(one, 1, 10, None, 10, None, 0.9, 0.999, 1e-8, 1e-3, 1.0, None) == -1
+    assert b"null pointer" in lib.pnr_last_error()
+    assert lib.pnr_adam_rows(one, 1, 10, None, 10, None, 0.4, 0.999, 1e-8, 1e-3, 1.0, None) == -1
+    assert b"beta1" in lib.pnr_last_error()
+    from pointnerf2studio_amd.optim import PointRowAdam
+    with pytest.raises(ValueError, match="weight decay"):
+        PointRowAdam([torch.nn.Parameter(torch.zeros(1, 4, 3))], weight_decay=0.1)
+    opt = PointRowAdam([torch.nn.Parameter(torch.zeros(1, 4, 3))], lr=2e-3)
+    opt.param_groups[0]["params"][0].grad = torch.zeros(1, 4, 3)
+    with pytest.raises(RuntimeError, match="GPU"):
+        opt.step()
