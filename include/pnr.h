@@ -421,7 +421,8 @@ int pnr_conf_loss_backward(const pnr_scene_t *scene, const pnr_render_opts_t *op
  *   exp_avg    += (1 - beta1) (grad - exp_avg);   exp_avg_sq = exp_avg_sq beta2 + (1 - beta2) grad grad;
  *   param      -= step_size * exp_avg / (sqrt(exp_avg_sq) / bias_correction2_sqrt + eps)
  * with step_size = lr / (1 - beta1^step) and bias_correction2_sqrt = sqrt(1 - beta2^step) evaluated by the caller (in
- * double, as torch does) for the step count AFTER its increment.  d_rows == NULL: every row (rows_cap = num_rows).
+ * double, as torch does) for the step count AFTER its increment; the scalars travel as doubles and are cast to float once,
+ * where torch casts them (1 - beta1 is formed in double first).  d_rows == NULL: every row (rows_cap = num_rows).
  * Neither call synchronises or reads anything back. */
 #define PNR_ADAM_MAX_TENSORS 8
 typedef struct {
@@ -434,8 +435,8 @@ typedef struct {
 int pnr_rows_merge(int32_t *d_flags, int64_t num_rows, int32_t *d_ever, int64_t *d_ever_count, int64_t ever_cap,
                    const int32_t *d_rows, int64_t rows_cap, const int64_t *d_n_rows, void *stream);
 int pnr_adam_rows(const pnr_adam_tensor_t *tensors, int32_t n_tensors, int64_t num_rows, const int32_t *d_rows,
-                  int64_t rows_cap, const int64_t *d_n_rows, float beta1, float beta2, float eps, float step_size,
-                  float bias_correction2_sqrt, void *stream);
+                  int64_t rows_cap, const int64_t *d_n_rows, double beta1, double beta2, double eps, double step_size,
+                  double bias_correction2_sqrt, void *stream);
 
 /* ---- probing outputs (point growing) ------------------------------------------------------------------
  * What the reference's legacy model returns with `opt.prob == 1` (models/neural_points_volumetric_model.py:331-352)

@@ -186,7 +186,8 @@ def load() -> C.CDLL:
     lib.pnr_conf_loss.argtypes = [vp, C.POINTER(RenderOpts), i64, vp, sz, i64, vp, f32, vp, vp, vp]
     lib.pnr_conf_loss_backward.argtypes = [vp, C.POINTER(RenderOpts), i64, vp, sz, i64, vp, f32, vp, vp, vp, vp, vp]
     lib.pnr_rows_merge.argtypes = [vp, i64, vp, vp, i64, vp, i64, vp, vp]
-    lib.pnr_adam_rows.argtypes = [C.POINTER(AdamTensorC), i32, i64, vp, i64, vp, f32, f32, f32, f32, f32, vp]
+    lib.pnr_adam_rows.argtypes = [C.POINTER(AdamTensorC), i32, i64, vp, i64, vp, C.c_double, C.c_double, C.c_double,
+                                  C.c_double, C.c_double, vp]
     lib.pnr_profile_enable.argtypes = [C.c_int]
     lib.pnr_profile_calls.restype = C.c_int64
     lib.pnr_profile_calls.argtypes = []

@@ -46,14 +46,18 @@ __global__ void __launch_bounds__(256) k_adam_rows(AdamTensors T, int64_t num_ro
         const int64_t at = r * T.width[t] + (c - T.first[t]);
         const float g = T.g[t][at];
         float m = T.m[t][at], v = T.v[t][at];
-        // torch: exp_avg.lerp_(grad, 1 - beta1) (weight < 0.5: a + w (b - a)); exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
-        m = m + w1 * (g - m);
+        // torch.optim.Adam's foreach form, kernel by kernel, with the roundings its device code has (this file is built with
+        // -ffp-contract=off, torch's kernels with the compiler's default contraction: every `a + s * x` there is one fma):
+        //   _foreach_lerp_(exp_avg, grad, 1 - beta1)              a + w (b - a)            (weight < 0.5)
+        //   _foreach_mul_(exp_avg_sq, beta2); _foreach_addcmul_(exp_avg_sq, grad, grad, 1 - beta2)      a + s (b c)
+        //   sqrt; _foreach_div_(., bias_correction2_sqrt); _foreach_add_(., eps); _foreach_addcdiv_(param, exp_avg, ., -step_size)
+        m = fmaf(w1, g - m, m);
         v = v * beta2;
-        v = v + w2 * g * g;
+        v = fmaf(w2, g * g, v);
         const float denom = sqrtf(v) / bc2_sqrt + eps;
         T.m[t][at] = m;
         T.v[t][at] = v;
-        T.p[t][at] = T.p[t][at] - step_size * (m / denom);
+        T.p[t][at] = fmaf(-step_size, m / denom, T.p[t][at]);
     }
 }
 
@@ -101,8 +105,8 @@ extern "C" int pnr_rows_merge(int32_t *d_flags, int64_t num_rows, int32_t *d_eve
 }
 
 extern "C" int pnr_adam_rows(const pnr_adam_tensor_t *tensors, int32_t n_tensors, int64_t num_rows, const int32_t *d_rows,
-                             int64_t rows_cap, const int64_t *d_n_rows, float beta1, float beta2, float eps,
-                             float step_size, float bias_correction2_sqrt, void *stream_)
+                             int64_t rows_cap, const int64_t *d_n_rows, double beta1, double beta2, double eps,
+                             double step_size, double bias_correction2_sqrt, void *stream_)
 {
     PNR_REQUIRE(tensors != nullptr && n_tensors >= 1 && n_tensors <= PNR_ADAM_MAX_TENSORS,
                 "pnr_adam_rows: n_tensors=%d not in [1,%d]", n_tensors, PNR_ADAM_MAX_TENSORS);
@@ -112,11 +116,11 @@ extern "C" int pnr_adam_rows(const pnr_adam_tensor_t *tensors, int32_t n_tensors
                 "pnr_adam_rows: d_rows == NULL means every row: rows_cap must be num_rows and d_n_rows NULL");
     PNR_REQUIRE(rows_cap >= 0 && rows_cap <= num_rows, "pnr_adam_rows: rows_cap=%lld not in [0, num_rows]",
                 (long long)rows_cap);
-    PNR_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f && bias_correction2_sqrt > 0.f,
+    PNR_REQUIRE(beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1. && eps >= 0. && bias_correction2_sqrt > 0.,
                 "pnr_adam_rows: betas (%g, %g) / eps %g / bias_correction2_sqrt %g out of range", beta1, beta2, eps,
                 bias_correction2_sqrt);
     // torch's lerp takes the a + w (b - a) form for weights below one half only
-    PNR_REQUIRE(beta1 > 0.5f, "pnr_adam_rows: beta1=%g <= 0.5 is not supported", beta1);
+    PNR_REQUIRE(beta1 > 0.5, "pnr_adam_rows: beta1=%g <= 0.5 is not supported", beta1);
     AdamTensors T{};
     T.n = n_tensors;
     int col = 0;
@@ -138,8 +142,10 @@ extern "C" int pnr_adam_rows(const pnr_adam_tensor_t *tensors, int32_t n_tensors
     // the grid covers the CAPACITY; the threads beyond the device-side count leave at their first loop test
     const unsigned blocks = (unsigned)std::min<int64_t>((rows_cap * T.total + 255) / 256, 256 * 32);
     hipLaunchKernelGGL(k_adam_rows, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, T, num_rows, d_rows, rows_cap,
-                       reinterpret_cast<const long long *>(d_n_rows), 1.0f - beta1, beta2, 1.0f - beta2, step_size,
-                       bias_correction2_sqrt, eps);
+                       reinterpret_cast<const long long *>(d_n_rows),
+                       // the scalars as torch hands them to its kernels: evaluated in double on the host, then one cast
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)step_size,
+                       (float)bias_correction2_sqrt, (float)eps);
     PNR_HIP_CHECK(hipGetLastError());
     return PNR_OK;
 }

@@ -29,14 +29,22 @@ def _compare(oracle, prob, losses_h, model, losses_o, pts_o, w_o, device, first_
     assert max(drift[:10]) <= first_tol, f"first 10 steps: {max(drift[:10]):.3e}"
     assert max(drift) <= last_tol, f"all {len(drift)} steps: {max(drift):.3e}"
     pts_h, w_h = T.hip_state(model)
-    worst = 0.0
-    for name in list(T.POINT_KEYS):
-        d = (pts_h[name] - pts_o[name]).abs().max().item()
-        worst = max(worst, d / max(pts_o[name].abs().max().item(), 1e-12))
-    for name, t in w_o.items():
-        d = (w_h[name] - t).abs().max().item()
-        worst = max(worst, d / max(t.abs().max().item(), 1e-12))
-    assert worst <= param_tol, f"parameters after {len(losses_h)} steps: {worst:.3e} of a tensor's largest entry"
+    # parameters: Adam normalises every element's step to ~lr whatever the size of its gradient, so an element whose
+    # gradient is rounding noise around zero (its sign decided by the summation order) walks +-lr per step on either side:
+    # single entries may sit up to steps x lr apart while the tensors agree in the mean.  Both are held: the relative L2
+    # distance of every tensor and its largest single deviation in units of the tensor's largest entry
+    worst_l2, worst_max, who = 0.0, 0.0, ("", "")
+    pairs = [(n, pts_h[n], pts_o[n]) for n in T.POINT_KEYS] + [(n, w_h[n], t) for n, t in w_o.items()]
+    for name, a, b in pairs:
+        l2 = ((a - b).double().norm() / b.double().norm().clamp(min=1e-30)).item()
+        mx = (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
+        if l2 > worst_l2:
+            worst_l2, who = l2, (name, who[1])
+        if mx > worst_max:
+            worst_max, who = mx, (who[0], name)
+    assert worst_l2 <= param_tol[0], f"parameters after {len(losses_h)} steps: relative L2 {worst_l2:.3e} ({who[0]})"
+    assert worst_max <= param_tol[1], f"parameters after {len(losses_h)} steps: largest deviation {worst_max:.3e} ({who[1]})"
+    worst = (worst_l2, worst_max, who)
     # matched PSNR: eval images (jitter 0, clamp) of the two trained students against the teacher's
     img_h = T.hip_eval_images(model, prob, device)
     img_o = T.eval_images(oracle, prob, pts_o, w_o)
@@ -55,8 +63,8 @@ def test_fifty_training_steps_follow_the_oracle(oracle, gpu_device):
     assert seeds == list(range(STEPS)) and model.host_reads <= 1    # (the collider's planes, once)
     losses_o, pts_o, w_o = T.run_oracle(oracle, prob, STEPS, seeds)
     drift, worst, ps_h, ps_o = _compare(oracle, prob, losses_h, model, losses_o, pts_o, w_o, gpu_device,
-                                        first_tol=1e-4, last_tol=1e-2, param_tol=2e-2)
-    print(f"loss drift: first 10 steps {max(drift[:10]):.2e}, all {max(drift):.2e}; parameters {worst:.2e}; "
+                                        first_tol=1e-4, last_tol=1e-2, param_tol=(1e-2, 1e-1))
+    print(f"loss drift: first 10 steps {max(drift[:10]):.2e}, all {max(drift):.2e}; parameters: L2 {worst[0]:.2e} ({worst[2][0]}), largest entry {worst[1]:.2e} ({worst[2][1]}); "
           f"PSNR vs teacher {ps_0} -> HIP {ps_h} / oracle {ps_o} dB")
     assert losses_h[-1] < 0.1 * losses_h[0]
     for a, b in zip(ps_h, ps_0):
@@ -82,5 +90,5 @@ def test_training_through_a_prune_and_a_grow(oracle, gpu_device):
         "the two sides pruned a different set (a confidence within rounding of the threshold)"
     assert torch.equal(model.neural_points.points_xyz.detach().cpu(), pts_o["xyz"])
     drift, worst, ps_h, ps_o = _compare(oracle, prob, losses_h, model, losses_o, pts_o, w_o, gpu_device,
-                                        first_tol=1e-4, last_tol=1e-2, param_tol=2e-2)
-    print(f"prune + grow: loss drift {max(drift):.2e}, parameters {worst:.2e}, PSNR HIP {ps_h} / oracle {ps_o} dB")
+                                        first_tol=1e-4, last_tol=1e-2, param_tol=(1e-2, 1e-1))
+    print(f"prune + grow: loss drift {max(drift):.2e}, parameters L2 {worst[0]:.2e} ({worst[2][0]}) / largest entry {worst[1]:.2e} ({worst[2][1]}), PSNR HIP {ps_h} / oracle {ps_o} dB")
