@@ -314,6 +314,7 @@ struct RenderWs {
     float *ray_dirs;   // [R,3] pnr_render_camera: directions of the rays that have samples (written by k_expand)
     float *smp_wgt;    // [cap, K] normalised inverse-distance weight of every neighbour slot (k_pair_weights; the pair
                        // kernel on dense units reads its row's weight instead of summing over the sample's rows)
+    bool wgt_from_knn; // this call's neighbour search wrote smp_wgt itself (k_knn3<16, true>): no k_pair_weights pass
     int *n_sel;        // device ints: [0]=S_sel (clamped to cap), [1]=S_valid, [2]=R, [3]=U unique neighbour points,
                        // [4],[5] = first / one-past-last position of the current shading pass in vs_all, [6] = 0
     unsigned long long *shards;  // statistics counters, SHARDS x 128-byte lines per counter (see shard_add)

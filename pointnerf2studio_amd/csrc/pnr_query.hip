@@ -474,12 +474,17 @@ __global__ void __launch_bounds__(TPB) k_knn(GridView g, int K, float radius_lim
 // (occupancy is what this latency-bound kernel lives on: batches of 12 candidates at 133 VGPRs = 3 waves per SIMD ran
 // 0.91 ms on cfg 1; batches of 4 with the allocation capped for 6 waves per SIMD -- a few spilled registers included --
 // 0.68 ms; slab records fetched three cells at a time for 8 waves: 0.72)
-template <int KMAX>
+// WGT (the pair kernel on dense units follows, K = 11..15): the search also leaves the sample's normalised
+// inverse-distance weights (studio_model.py:285-286,467-475) -- it holds the K squared distances in registers; a separate
+// pass (k_pair_weights) re-reads one point row per neighbour slot for them: 7.3 GB of scattered 16-byte reads per frame at
+// BASELINE cfg[4].  Same expression, same order, same bits as that pass.
+template <int KMAX, bool WGT = false>
 __global__ void __launch_bounds__(TPB, KMAX <= 8 ? 6 : 4) k_knn3(GridView g, int K, float radius_limit2,
                                                const float4 *__restrict__ smp_loc, const int *__restrict__ smp_ray,
                                                const int *__restrict__ n_sel, int *__restrict__ smp_pidx,
                                                int *__restrict__ smp_valid, int *__restrict__ ray_flag,
-                                               unsigned long long *__restrict__ shards, int *__restrict__ pt_flag)
+                                               unsigned long long *__restrict__ shards, int *__restrict__ pt_flag,
+                                               float *__restrict__ smp_wgt = nullptr)
 {
     constexpr int CB = KMAX <= 8 ? 4 : 8;  // candidates fetched per batch
     const int S = n_sel[0];
@@ -600,6 +605,21 @@ __global__ void __launch_bounds__(TPB, KMAX <= 8 ? 6 : 4) k_knn3(GridView g, int
 #pragma unroll
             for (int i = 0; i < KMAX; ++i)
                 if (i < K && out[i] >= 0) pt_flag[out[i]] = 1;
+        }
+        if (WGT) {
+            // w_k = mask_k / clamp(||p_k - s||, 1e-6), divided by clamp(sum_k w_k, 1e-8): buf[k] IS ||p_k - s||^2 as
+            // k_pair_weights forms it (the same subtraction, squares summed left to right, unfused)
+            float wsum = 0.f;
+#pragma unroll
+            for (int i = 0; i < KMAX; ++i)
+                if (i < K) {
+                    buf[i] = out[i] >= 0 ? 1.0f / fmaxf(sqrtf(buf[i]), 1e-6f) : 0.f;
+                    wsum += buf[i];
+                }
+            const float den = fmaxf(wsum, 1e-8f);
+#pragma unroll
+            for (int i = 0; i < KMAX; ++i)
+                if (i < K) smp_wgt[s * K + i] = buf[i] / den;
         }
         const int nn = min(kid, K);
         smp_valid[s] = nn > 0;
@@ -859,6 +879,7 @@ int launch_knn(const GridView &g, int K, float radius_limit, RenderWs &ws, int64
                hipStream_t stream, int64_t N, int64_t R, int P)
 {
     unsigned long long *acc = acc_ptr(ws);
+    ws.wgt_from_knn = false;
     int *pt_flag = (N > 0) ? ws.pt_flag : nullptr;
     if (pt_flag) PNR_HIP_CHECK(hipMemsetAsync(pt_flag, 0, (size_t)N * sizeof(int), stream));
     const float r2 = radius_limit * radius_limit;  // fp32, as cu:410
@@ -869,6 +890,11 @@ int launch_knn(const GridView &g, int K, float radius_limit, RenderWs &ws, int64
     static const int coop_max_rays = [] {
         const char *e = getenv("PNR_KNN_COOP_MAX_RAYS");
         return e ? atoi(e) : 12288;   // (measured at cfg 1: 53 / 85 / 138 us at 4096 / 8192 / 16 384 rays against k_knn3's 140-157)
+    }();
+    // (PNR_WGT_FROM_KNN=0 in the environment: the separate k_pair_weights pass, for A/B runs and the equality test)
+    static const bool wgt_in_search = [] {
+        const char *e = getenv("PNR_WGT_FROM_KNN");
+        return !(e && atoi(e) == 0);
     }();
     const bool coop = batched && g.kernel_size[1] <= 3 && g.kernel_size[2] <= 3 && K <= 16 && P >= 1 && P <= COOP_P &&
                       R >= 1 && R <= coop_max_rays;
@@ -882,10 +908,15 @@ int launch_knn(const GridView &g, int K, float radius_limit, RenderWs &ws, int64
                                ws.smp_pidx, ws.smp_valid, ws.ray_flag, acc, pt_flag);
     } else if (batched && K <= 8)
         hipLaunchKernelGGL(k_knn3<8>, dim3(grid), dim3(TPB), 0, stream, g, K, r2, ws.smp_loc, ws.smp_ray, ws.n_sel,
-                           ws.smp_pidx, ws.smp_valid, ws.ray_flag, acc, pt_flag);
-    else if (batched && K <= 16)
+                           ws.smp_pidx, ws.smp_valid, ws.ray_flag, acc, pt_flag, (float *)nullptr);
+    else if (batched && K >= 11 && K <= 15 && ws.smp_wgt && wgt_in_search) {
+        // (the K for which the fp32 pair kernel runs on dense units and reads per-slot weights: launch_shade)
+        hipLaunchKernelGGL((k_knn3<16, true>), dim3(grid), dim3(TPB), 0, stream, g, K, r2, ws.smp_loc, ws.smp_ray, ws.n_sel,
+                           ws.smp_pidx, ws.smp_valid, ws.ray_flag, acc, pt_flag, ws.smp_wgt);
+        ws.wgt_from_knn = true;
+    } else if (batched && K <= 16)
         hipLaunchKernelGGL(k_knn3<16>, dim3(grid), dim3(TPB), 0, stream, g, K, r2, ws.smp_loc, ws.smp_ray, ws.n_sel,
-                           ws.smp_pidx, ws.smp_valid, ws.ray_flag, acc, pt_flag);
+                           ws.smp_pidx, ws.smp_valid, ws.ray_flag, acc, pt_flag, (float *)nullptr);
     else if (K <= 8)
         hipLaunchKernelGGL(k_knn<8>, dim3(grid), dim3(TPB), 0, stream, g, K, r2, ws.smp_loc, ws.smp_ray, ws.n_sel,
                            ws.smp_pidx, ws.smp_valid, ws.ray_flag, acc, pt_flag);
@@ -945,6 +976,7 @@ extern "C" int pnr_query_raypos(const pnr_scene_t *scene, const float *d_raypos,
     }
     const int64_t cap = R * (int64_t)SR;
     RenderWs ws = carve_render_ws(d_workspace, R, cap, K);
+    ws.smp_wgt = nullptr;   // (shade-only: behind the query workspace's end -- the search must not write weights there)
     CamRef cr{};  // explicit positions: no camera involved
     cr.D = D;
     int rc = launch_select_expand(scene->grid, cr, nullptr, d_raypos, R, D, SR, cap, ws, d_counters, stream);

@@ -445,9 +445,12 @@ int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr,
             launch_pairs_bf16(seg, dim3(grid), stream, P);
         else if (taped && !su && launch_pairs_fp32_tape(seg, dim3(grid), stream, P)) {
         } else if (su) {
-            hipLaunchKernelGGL(k_pair_weights, dim3((unsigned)std::min<int64_t>((cap + 255) / 256, 256 * 16)), dim3(256), 0,
-                               stream, ws.n_sel, P.i_v0, P.i_v1, P.vs_list, ws.smp_pidx, ws.smp_loc, P.point_rows, K,
-                               ws.smp_wgt);
+            // the rows' weights: left by the neighbour search (k_knn3<16, true>, the full-frame form for K = 11..15), else
+            // by a pass of their own
+            if (!ws.wgt_from_knn)
+                hipLaunchKernelGGL(k_pair_weights, dim3((unsigned)std::min<int64_t>((cap + 255) / 256, 256 * 16)), dim3(256),
+                                   0, stream, ws.n_sel, P.i_v0, P.i_v1, P.vs_list, ws.smp_pidx, ws.smp_loc, P.point_rows, K,
+                                   ws.smp_wgt);
             launch_pairs_fp32_dense(su, tu, dim3(grid), stream, P);
         }
         else

@@ -186,3 +186,44 @@ def test_cfg4_scannet_full_size(oracle, gpu_device):
     del pts
     cnt = _properties(gpu_device, c, scene, wh, cfg, oracle)
     assert cnt["rays_kept"] > 0.9 * c["H"] * c["W"] and cnt["pairs_valid"] > 50_000_000
+
+
+def test_pair_weights_from_the_neighbour_search_equal_the_separate_pass(oracle, gpu_device, tmp_path):
+    """K = 11..15 on the fp32 dense-unit pair kernel: the rows' normalised inverse-distance weights are written by the
+    neighbour search (k_knn3<16, true>, which holds the K squared distances in registers) instead of a pass that re-reads
+    one point row per slot (k_pair_weights: 7.3 GB per frame at cfg[4]).  Same expression in the same order: the frame must
+    be bit-identical to a render with PNR_WGT_FROM_KNN=0 (the library reads the variable once: a child interpreter)."""
+    import os
+    import subprocess
+    import sys
+    script = """
+import sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import pnr_oracle as O
+from helpers import build_hip
+from pointnerf2studio_amd import synthetic
+from pointnerf2studio_amd.renderer import RendererHIP
+O.build_c_oracle()
+c = dict(synthetic.SCENE_CONFIGS["cfg4_scannet_20m"])
+pts = synthetic.make_scene_points(c, N=400000)
+cfg = O.OracleConfig()
+cfg.SR, cfg.K, cfg.P, cfg.max_o, cfg.ranges, cfg.vsize = c["SR"], c["K"], c["P"], c["max_o"], list(c["ranges"]), [c["vsize"]] * 3
+dev = torch.device("cuda:0")
+scene, wh, hyp, info = build_hip(pts, cfg, dev, weights=synthetic.make_weights(0, sigma_scale=300.0, bias_scale=0.1))
+campos, camrot = synthetic.make_scene_camera(c, 0)
+d = synthetic.make_rays(c["H"], c["W"], campos, camrot, c["angle_x"], y0=400, y1=528, x0=500, x1=756).to(dev)
+rnd = RendererHIP(scene, wh, SR=c["SR"], K=c["K"], D=cfg.z_depth_dim, radius_limit=float(O.radius_limit(cfg)), vsize_z=cfg.vsize[2])
+out = rnd.render(d, campos, camrot, c["near"], c["far"])
+torch.save({"rgb": out["rgb"].cpu(), "depth": out["depth"].cpu(), "pairs": out["counters"]["pairs_valid"]}, sys.argv[1])
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)),
+       os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    got = {}
+    for flag in ("1", "0"):
+        out = tmp_path / f"wgt{flag}.pt"
+        p = subprocess.run([sys.executable, "-c", script, str(out)], env=dict(os.environ, PNR_WGT_FROM_KNN=flag),
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        got[flag] = torch.load(out)
+    assert got["1"]["pairs"] == got["0"]["pairs"] > 100_000
+    assert torch.equal(got["1"]["rgb"], got["0"]["rgb"]) and torch.equal(got["1"]["depth"], got["0"]["depth"])
+    assert float((got["1"]["rgb"] < 1).float().mean()) > 0.5
