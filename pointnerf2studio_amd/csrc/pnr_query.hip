@@ -79,6 +79,36 @@ RenderWs carve_render_ws(void *base, int64_t R, int64_t cap, int K, int64_t N, i
 // cumsum accumulates float32 in double and rounds every prefix); + near; mid-points of consecutive end points.
 // `carry` (running double sum) and `e_prev` (end point of sample 64w - 1) flow from word to word.
 // jkey: jitter_key(cr, ray), computed ONCE per ray by the caller (it holds a division)
+//
+// The running sum over a wavefront's 64 segments: an inclusive scan of doubles on DPP moves (row shifts inside the rows
+// of 16 lanes, then the two row broadcasts: the GCN wavefront scan) -- 14 register moves and 7 adds where six rounds of
+// __shfl_up cost twelve ds_bpermute round trips through the LDS crossbar, per 64 samples of every hit ray, in k_select
+// and again in k_expand.  Lanes without a source read 0.0 and add it.  The segments are float32 values of one magnitude:
+// every partial sum of <= 512 of them is EXACT in double (24 + 9 significant bits), so the order of the additions does
+// not change a bit of any prefix (the oracle adds sequentially).
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double dpp_mov_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, BANK_MASK, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, BANK_MASK, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_incl_scan_f64(double s)
+{
+    constexpr int ROW_SHR = 0x110, ROW_BCAST15 = 0x142, ROW_BCAST31 = 0x143;
+    double a = s + dpp_mov_f64<ROW_SHR + 1, 0xf, 0xf>(s);
+    a += dpp_mov_f64<ROW_SHR + 2, 0xf, 0xf>(s);
+    a += dpp_mov_f64<ROW_SHR + 3, 0xf, 0xf>(s);          // lanes' last four inside their row of 16
+    a += dpp_mov_f64<ROW_SHR + 4, 0xf, 0xe>(a);          // lanes 4..15 of a row: + the four before
+    a += dpp_mov_f64<ROW_SHR + 8, 0xf, 0xc>(a);          // lanes 8..15: + the eight before -- rows are scanned
+    a += dpp_mov_f64<ROW_BCAST15, 0xa, 0xf>(a);          // rows 1, 3: + the total of the row before
+    a += dpp_mov_f64<ROW_BCAST31, 0xc, 0xf>(a);          // rows 2, 3: + the total of the first 32 lanes
+    return a;
+}
+__device__ __forceinline__ double bcast_f64(double v, int L)   // L wave-uniform
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), L), __builtin_amdgcn_readlane(__double2loint(v), L));
+}
 __device__ __forceinline__ float sample_t(const CamRef &cr, const float *__restrict__ tab, float near_plane,
                                           unsigned jkey, int D, int w, int lane, double &carry, float &e_prev)
 {
@@ -89,18 +119,13 @@ __device__ __forceinline__ float sample_t(const CamRef &cr, const float *__restr
         const float u = pnr_uniform(cr.seed, jkey, (unsigned)j);
         seg = tab[D + j] * (1.0f + cr.jitter * (u - 0.5f));
     }
-    double s = (double)seg;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const double o = __shfl_up(s, d, 64);
-        if (lane >= d) s += o;
-    }
+    double s = wave_incl_scan_f64((double)seg);
     s += carry;
-    carry = __shfl(s, 63, 64);
+    carry = bcast_f64(s, 63);
     const float e = near_plane + (float)s;          // end point of sample j
     float e_left = __shfl_up(e, 1, 64);
     if (lane == 0) e_left = e_prev;
-    e_prev = __shfl(e, 63, 64);
+    e_prev = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), 63));
     return (e_left + e) / 2.0f;
 }
 
