@@ -2,12 +2,13 @@
 # Runs ON THE GPU BOX (gpurun -- 'bash tools/collect_profiles.sh [what]'): the bench line, the rocprofv3 kernel trace of
 # the same command, the HBM-traffic PMC passes and the MFMA-busy PMC pass, into gpurun_out/prof_rNN/.
 # tools/summarize_profiles.py then condenses them into profiles/<round>/ (run on the host).
-#   what = all (default) | bench | trace | pmc | cfg4 (trace + PMC passes of the K = 12 configuration, fp32)
+#   what = all (default) | bench | trace | pmc | cfg2 (the lego-like configuration's bench line, fp32)
+#          | cfg4 (trace + PMC passes of the K = 12 configuration, fp32)
 #          | train (per-kernel times and a PMC pass of the training step, tools/train_step_bench.py, 4096 and 65 536 rays)
 set -e -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 WHAT=${1:-all}
-O=gpurun_out/prof_r03
+O=${PROF_DIR:-gpurun_out/prof_r04}
 mkdir -p $O
 if [ "$WHAT" = all ] || [ "$WHAT" = bench ]; then
   echo "[bench] default flags (fp32 headline, all side legs, CPU baseline)"
@@ -36,6 +37,11 @@ if [ "$WHAT" = all ] || [ "$WHAT" = pmc ]; then
     rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/pmc_mfma_$mode -- python bench.py \
         --steps 3 --warmup 1 --cpu-rays-side 0 --no-other-mode --precision $mode > $O/bench_pmc_mfma_$mode.json 2> $O/pmc_mfma_$mode.err
   done
+fi
+if [ "$WHAT" = all ] || [ "$WHAT" = cfg2 ]; then
+  echo "[cfg2] bench line (lego-like: max_o 830000, P 9)"
+  python bench.py --config cfg2_lego_6m --cpu-rays-side 0 --no-other-mode --precision fp32 --steps 4 --warmup 1 \
+      > $O/bench_cfg2.json 2> $O/bench_cfg2.err
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = cfg4 ]; then
   C="--config cfg4_scannet_20m --cpu-rays-side 0 --no-other-mode --precision fp32"

@@ -1,5 +1,5 @@
 """Host side of tools/collect_profiles.sh: condenses gpurun_out/prof_rNN/ into the files kept under profiles/<round>/.
-Usage: python tools/summarize_profiles.py gpurun_out/prof_r03 profiles/r03 [git-sha]"""
+Usage: python tools/summarize_profiles.py gpurun_out/prof_r04 profiles/r04 [git-sha]"""
 import csv
 import glob
 import json
@@ -104,6 +104,10 @@ for name in ("train_kernel_times_4096.txt", "train_kernel_times_65536.txt", "tra
              "pmc_train_65536.txt"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, name))
+
+# ---- the lego-like configuration (cfg2_lego_6m with the lego script's max_o = 830000, P = 9): its bench line ---------------
+if os.path.exists(os.path.join(src, "bench_cfg2.json")):
+    shutil.copy(os.path.join(src, "bench_cfg2.json"), os.path.join(dst, "bench_cfg2_n1_fp32.json"))
 
 # ---- the K = 12 configuration (cfg4_scannet_20m, fp32): bench line, kernel stats, traffic, MFMA busy -------------------
 if os.path.exists(os.path.join(src, "bench_cfg4.json")):
