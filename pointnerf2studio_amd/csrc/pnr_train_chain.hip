@@ -31,11 +31,6 @@ namespace pnr {
 #ifndef PNR_CPFS
 #define PNR_CPFS 6
 #endif
-#ifdef PNR_CHAIN_EXP_NO_X0   // (timing experiments: results are wrong)
-#define PNR_CHAIN_X0_FIRST 32
-#else
-#define PNR_CHAIN_X0_FIRST 0
-#endif
 constexpr int CPFS = PNR_CPFS;
 static_assert(CNG_TILE % CPFS == 0, "the window slot of a group must not depend on the tile");
 constexpr int CT_ROW_B = 144, CT_BLK_B = 32 * CT_ROW_B, CT_WAVE_B = 2 * CT_BLK_B;   // as the render's tape writer
@@ -54,6 +49,12 @@ __device__ __forceinline__ f32x4 c_lds_read4(unsigned addr, int off)
 {
     f32x4 v;
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(off));
+    return v;
+}
+__device__ __forceinline__ f32x2 c_lds_read2(unsigned addr, int off)
+{
+    f32x2 v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(off));
     return v;
 }
 __device__ __forceinline__ void c_lds_wait()
@@ -95,10 +96,13 @@ __device__ __forceinline__ void chain_layer(__amdgpu_buffer_rsrc_t rsrc, int vof
 }
 }  // namespace
 
-// LDS of a wave: the tape writer's two staging blocks | the taped (sin, cos) pairs of the tile's rows (X0 columns 32..223,
-// 768 bytes per row, rows 784 bytes apart: conflict-free 16-byte reads) | the rows' point gradients (160 bytes per row,
-// rows 176 apart)
-constexpr int CX_ROW_B = 784, CX_BLK_B = 32 * CX_ROW_B;
+// LDS of a wave: the tape writer's two staging blocks | the EMBEDDINGS of the tile's rows (X0 columns 0..31: 128 bytes per
+// row, rows 144 bytes apart) | the rows' point gradients (160 bytes per row, rows 176 apart).
+// (Round 3 staged the taped (sin, cos) pairs of the positional encoding instead -- X0 columns 32..223, 768 bytes per row,
+// one load + LDS write per row: 0.50 of the kernel's 5.3 ms at 65 536 rays.  The chain rule through the encoding needs
+// sin / cos of e 2^f for the lane's two channels per output tile: one branch-free sincos per channel and two double-angle
+// steps on registers (~35 instructions against 14 multiply-adds + the staging of 48 bytes) from a sixth of the bytes.)
+constexpr int CX_ROW_B = 144, CX_BLK_B = 32 * CX_ROW_B;
 constexpr int CG_ROW_B = 176, CG_BLK_B = 32 * CG_ROW_B;
 constexpr int CHAIN_WAVE_B = CT_WAVE_B + CX_BLK_B + CG_BLK_B;   // 39 936
 constexpr int CHAIN_LDS_B = WAVES * CHAIN_WAVE_B + 1024;        // + the density head in accumulator order, shared
@@ -118,7 +122,7 @@ __global__ void __launch_bounds__(TPB, 1) k_train_pairs_bwd(ChainParams P)
     const unsigned t_rd = tblk + (unsigned)((lane >> 3) * CT_ROW_B + (lane & 7) * 16);   // + block + 8 i rows
     const unsigned xblk = tblk + CT_WAVE_B, gblk = xblk + CX_BLK_B;
     const unsigned w4lds = (unsigned)(uintptr_t)chain_lds + (unsigned)(WAVES * CHAIN_WAVE_B) + 64u * (unsigned)h;   // + 128 m + 16 q
-    const unsigned x_rd = xblk + (unsigned)(j * CX_ROW_B + 48 * h);                      // + 96 m: 48 bytes of the lane
+    const unsigned x_rd = xblk + (unsigned)(j * CX_ROW_B + 8 * h);                       // + 16 m: the lane's two channels
     const unsigned g_wr = gblk + (unsigned)(j * CG_ROW_B);
 
     const __amdgpu_buffer_rsrc_t rsrc =
@@ -159,19 +163,16 @@ __global__ void __launch_bounds__(TPB, 1) k_train_pairs_bwd(ChainParams P)
 #pragma unroll
         for (int l = 0; l < 4; ++l)
             sb[l] = *reinterpret_cast<const u32x4 *>(P.tape_bits + (((size_t)l * P.bits_rows + (size_t)row) * 2 + h) * 4);
-        // the taped (sin, cos) pairs of the rows' embedding channels -> LDS: one row (48 float4) per instruction, every
-        // address one lane term plus a scalar (a 64-lane linear walk needs 24 per-lane address pairs, which the compiler
-        // keeps live across the whole tile loop and spills)
+        // the rows' embeddings (X0 columns 0..31) -> LDS: 8 lanes per row, 8 rows per instruction
         {
-            const int l48 = min(lane, 47);
-            const float *x0l = P.X0 + (int64_t)row0c * 288 + 32 + 4 * l48;
-            const unsigned xw = xblk + 16u * (unsigned)l48;
+            const int r8 = lane >> 3, c4 = lane & 7;
+            const unsigned xw = xblk + (unsigned)(r8 * CX_ROW_B + 16 * c4);
 #pragma unroll
-            for (int rr = PNR_CHAIN_X0_FIRST; rr < 32; ++rr) {
-                const int rrc = min(row0 + rr, n_rows - 1) - row0c;   // uniform
-                const float4 x = *reinterpret_cast<const float4 *>(x0l + rrc * 288);
+            for (int i = 0; i < 4; ++i) {
+                const int rrc = min(row0 + r8 + 8 * i, n_rows - 1) - row0c;
+                const float4 x = *reinterpret_cast<const float4 *>(P.X0 + (int64_t)(row0c + rrc) * 288 + 4 * c4);
                 const f32x4 xv = {x.x, x.y, x.z, x.w};
-                asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(xw), "v"(xv), "n"(rr * CX_ROW_B));
+                asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(xw), "v"(xv), "n"(i * 8 * CX_ROW_B));
             }
         }
         const float wk = live ? P.row_w[row] : 0.f;
@@ -348,30 +349,36 @@ __global__ void __launch_bounds__(TPB, 1) k_train_pairs_bwd(ChainParams P)
         }
         // ---- W0^T: dZ0 -> d embedding.  Output tile m, lane half h: channels 4 m + 2 h and + 1, eight registers each
         //      [d e | d sin, d cos of octave 0 | 1 | 2 | -]; the taped (sin, cos) pairs come from the LDS block ------------
-        f32x4 xs[3];
+        f32x2 xe;     // the embedding values of the lane's two channels of the output tile in flight
         auto emb_store = [&](int tt, const f32x16 &a) {
-            const float s[12] = {xs[0].x, xs[0].y, xs[0].z, xs[0].w, xs[1].x, xs[1].y,
-                                 xs[1].z, xs[1].w, xs[2].x, xs[2].y, xs[2].z, xs[2].w};
             float g[2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
+                // sin / cos of e 2^f, f = 0..2: the base octave by the forward's branch-free sincos, the others by the
+                // double-angle identities (1e-7: far below what a gradient is held to)
+                float sn[3], cs[3];
+                fast_sincos_nb(xe[e], sn[0], cs[0]);
+#pragma unroll
+                for (int f = 1; f < 3; ++f) {
+                    sn[f] = 2.0f * sn[f - 1] * cs[f - 1];
+                    cs[f] = fmaf(-2.0f * sn[f - 1], sn[f - 1], 1.0f);
+                }
                 // d/de [e, sin(e 2^f), cos(e 2^f)] = [1, 2^f cos, -2^f sin]
                 float gg = a[8 * e];
 #pragma unroll
                 for (int f = 0; f < 3; ++f)
-                    gg += (float)(1 << f) * (s[6 * e + 2 * f + 1] * a[8 * e + 1 + 2 * f] - s[6 * e + 2 * f] * a[8 * e + 2 + 2 * f]);
+                    gg += (float)(1 << f) * (cs[f] * a[8 * e + 1 + 2 * f] - sn[f] * a[8 * e + 2 + 2 * f]);
                 g[e] = gg;
             }
             const f32x2 g2 = {g[0], g[1]};
             asm volatile("ds_write_b64 %0, %1" ::"v"(g_wr + (unsigned)(16 * tt + 8 * h)), "v"(g2));
         };
-        // (the wait names the registers the reads fill: arithmetic on them must not be scheduled in front of it)
+        // (the wait names the registers the read fills: arithmetic on them must not be scheduled in front of it)
         auto xs_wait = [&]() {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xs[0]), "+v"(xs[1]), "+v"(xs[2])::"memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xe)::"memory");
         };
         auto xs_issue = [&](int tt) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) xs[q] = c_lds_read4(x_rd + (unsigned)(96 * tt), 16 * q);
+            xe = c_lds_read2(x_rd + (unsigned)(16 * tt), 0);
         };
         {
             const f32x16 last = acc[7];
@@ -391,7 +398,7 @@ __global__ void __launch_bounds__(TPB, 1) k_train_pairs_bwd(ChainParams P)
                             emb_store(m - 1, acc[m - 1]);
                         }
                     }
-                    if (i == 120) xs_issue(m);   // the (sin, cos) pairs of output tile m, a few MFMAs before they are used
+                    if (i == 120) xs_issue(m);   // the embedding values of output tile m, a few MFMAs before they are used
                 });
         }
         xs_wait();

@@ -197,3 +197,14 @@ def run_hip(prob, steps, device, edit_at=None, prune_thresh=0.25, model=None, ho
             cb.run_callback(step=i)
         losses.append(loss.detach())
     return [float(x) for x in torch.stack(losses).cpu()], seeds, model
+
+
+def perturbed(prob, eps=1e-7, seed=3):
+    """The same problem with every embedding value moved by eps relative (half a float32 ulp): what a different but equally
+    valid float32 evaluation order amounts to.  Used to measure how far two such runs drift apart BY THEMSELVES."""
+    g = torch.Generator().manual_seed(seed)
+    pts = {k: v.clone() for k, v in prob["points"].items()}
+    pts["embedding"] = pts["embedding"] * (1 + eps * (torch.rand(pts["embedding"].shape, generator=g) - 0.5))
+    out = dict(prob)
+    out["points"] = pts
+    return out
