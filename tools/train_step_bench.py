@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", default="fp32", choices=["fp32", "bf16x3"])
     ap.add_argument("--skip-autograd", action="store_true")
+    ap.add_argument("--no-sync", action="store_true", help="no host synchronisation between steps (events are read at the "
+                    "end): the device never idles, as in a training loop whose host runs ahead")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     pts = synthetic.make_points(args.points)
@@ -57,22 +59,28 @@ def main():
         model.config.hip_fused_training = fused
         fw, bw = [], []
         counters = None
+        events = []
         for it in range(args.warmup + args.steps):
             model.zero_grad(set_to_none=True)
             e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-            torch.cuda.synchronize()
+            if not args.no_sync:
+                torch.cuda.synchronize()
             e[0].record()
             out = model(bundle)
             loss = sum(model.get_loss_dict(out, {"image": image}).values())
             e[1].record()
             loss.backward()
             e[2].record()
-            torch.cuda.synchronize()
+            if not args.no_sync:
+                torch.cuda.synchronize()
             if it >= args.warmup:
-                fw.append(e[0].elapsed_time(e[1]))
-                bw.append(e[1].elapsed_time(e[2]))
+                events.append(e)
             if fused:
                 counters = model._renderer_train.last_counters
+        torch.cuda.synchronize()
+        for e in events:
+            fw.append(e[0].elapsed_time(e[1]))
+            bw.append(e[1].elapsed_time(e[2]))
         fw.sort()
         bw.sort()
         return {"forward_ms": fw[len(fw) // 2], "backward_ms": bw[len(bw) // 2],
