@@ -185,3 +185,93 @@ def test_two_rank_plugin_step_equals_single_process(gpu_device):
         ref = whole[k]
         scale = ref.abs().max().item()
         assert (torch.from_numpy(v) - ref).abs().max().item() <= 2e-3 * scale + 1e-12, k
+
+
+# ---- several optimiser steps, data-parallel, with the optimisers studio_config registers --------------------------------
+DP_STEPS = 6
+
+
+def _dp_train(model_or_ddp, model, bundle, G, sel, R_total, world):
+    """DP_STEPS steps of torch Adam (MLPs) + PointRowAdam (points) on the rank's rays `sel`; the loss is this rank's share of
+    a mean over ALL rays, so that DDP's average over ranks is the whole batch's gradient."""
+    from pointnerf2studio_amd.optim import PointRowAdam
+    groups = model.get_param_groups()
+    opt_f = torch.optim.Adam(groups["fields"], lr=5e-4, eps=1e-8)
+    opt_p = PointRowAdam(groups["neural_points"], lr=2e-3, eps=1e-8)
+    callbacks = model.get_training_callbacks(None)
+    losses = []
+    for it in range(DP_STEPS):
+        opt_f.zero_grad(set_to_none=True)
+        opt_p.zero_grad(set_to_none=True)
+        out = model_or_ddp(bundle(sel))
+        conf = out["conf_coefficient_loss_term"] * out["conf_coefficient_slots"] * 1e-6
+        loss = ((out["coarse_raycolor"] * G[sel]).sum() + conf) * (world / R_total)
+        loss.backward()
+        opt_f.step()
+        opt_p.step()
+        for cb in callbacks:
+            cb.run_callback(step=it)
+        losses.append(float(loss.detach()) / world)
+    assert opt_p.dense_steps == 0
+    return losses, opt_p
+
+
+def _dp_steps_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pointnerf2studio_amd.distributed import wrap_data_parallel
+        dev = torch.device("cuda:0")
+        model, bundle, G, R = _plugin_model(dev)
+        ddp = wrap_data_parallel(model)                       # DDP's own semantics: the average over ranks
+        sel = torch.arange(rank, R, world, device=dev)
+        losses, opt_p = _dp_train(ddp, model, bundle, G, sel, R, world)
+        params = {n: p.detach().cpu() for n, p in model.named_parameters() if p.requires_grad}
+        # every rank must hold the same bits after every step: compare a checksum of all parameters across the ranks
+        flat = torch.cat([p.reshape(-1).double() for p in params.values()])
+        mine = torch.stack([flat.sum(), (flat * flat).sum()])
+        both = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(both, mine)
+        same = all(torch.equal(b, both[0]) for b in both)
+        total = torch.tensor([sum(losses)], dtype=torch.float64)
+        dist.all_reduce(total)                                # the ranks' loss shares add up to the batch's loss
+        if rank == 0:
+            q.put({"params": {n: p.numpy() for n, p in params.items()}, "same_on_all_ranks": same,
+                   "loss_sum": float(total), "ever": opt_p.ever_touched()})
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_training_steps_with_the_registered_optimisers(gpu_device):
+    """Six optimiser steps under wrap_data_parallel on two ranks (torch Adam for the MLPs through DDP's all-reduce,
+    PointRowAdam for the point tensors over the UNION of the ranks' rows -- what the row exchange returns and publishes):
+    the ranks stay bit-identical to each other, and end where one process training on the whole batch ends."""
+    model, bundle, G, R = _plugin_model(gpu_device)
+    losses, opt_p = _dp_train(model, model, bundle, G, torch.arange(R, device=gpu_device), R, 1)
+    whole = {n: p.detach().cpu() for n, p in model.named_parameters() if p.requires_grad}
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [ctx.Process(target=_dp_steps_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=420)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got["same_on_all_ranks"], "the ranks' parameters drifted apart"
+    assert abs(got["loss_sum"] - sum(losses)) <= 1e-4 * abs(sum(losses)), (got["loss_sum"], sum(losses))
+    assert got["ever"] == opt_p.ever_touched()                # the union of the ranks' rows = the whole batch's rows
+    assert set(got["params"]) == set(whole)
+    for k, v in got["params"].items():
+        ref = whole[k]
+        rel = ((torch.from_numpy(v) - ref).double().norm() / ref.double().norm().clamp(min=1e-30)).item()
+        assert rel <= 1e-4, f"{k}: relative L2 {rel:.3e} after {DP_STEPS} steps"
+    moved = (whole["neural_points.points_embeding"] - _plugin_model(gpu_device)[0].neural_points.points_embeding.detach().cpu()).abs().max()
+    assert moved.item() > 1e-3                                # (the steps did train something)
