@@ -25,16 +25,31 @@ from torch.utils.weak import WeakTensorKeyDictionary
 from . import _lib
 
 # parameter -> row lists [(index int32 [cap] device, count int64 [1] device or None)] published since its last step
-# (keyed by identity and held weakly: tensors compare elementwise, a plain WeakKeyDictionary cannot hold them)
+# (keyed by identity and held weakly: tensors compare elementwise, a plain WeakKeyDictionary cannot hold them).  Only
+# parameters a PointRowAdam owns are tracked (_SUBSCRIBED): under any other optimiser publish_rows is a no-op and nothing
+# accumulates.  A list nobody consumed for MAX_PENDING publications (an optimiser that is never stepped) collapses into
+# UNKNOWN_ROWS, which the next step treats like an unlisted gradient: a dense sweep, exact.
 _PENDING = WeakTensorKeyDictionary()
+_SUBSCRIBED = WeakTensorKeyDictionary()
+MAX_PENDING = 16
+UNKNOWN_ROWS = "unknown rows"
 
 
 def publish_rows(params, index: torch.Tensor, count: Optional[torch.Tensor]) -> None:
     """The rows (dim -2 of every tensor in `params`) a backward just wrote gradients into: `index` int32 on the device,
     of which the first min(count, len(index)) entries count (`count`: int64 [1] device tensor, or None = all)."""
     for p in params:
-        if p is not None:
-            _PENDING.setdefault(p, []).append((index, count))
+        if p is None or p not in _SUBSCRIBED:
+            continue
+        pending = _PENDING.get(p)
+        if pending is UNKNOWN_ROWS:
+            continue
+        if pending is None:
+            pending = _PENDING[p] = []
+        if len(pending) >= MAX_PENDING:
+            _PENDING[p] = UNKNOWN_ROWS      # (the index tensors are released: up to tens of MB each)
+        else:
+            pending.append((index, count))
 
 
 def _rows_of(p: torch.Tensor) -> Tuple[int, int]:
@@ -75,6 +90,9 @@ class PointRowAdam(torch.optim.Optimizer):
         # always_rows: rows that may receive a gradient without being listed -- the confidence regulariser reads point 0
         # through every unfilled neighbour slot (studio_utils.py:193-199)
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0.0))
+        for group in self.param_groups:
+            for p in group["params"]:
+                _SUBSCRIBED[p] = True
         self._always = tuple(int(r) for r in always_rows)
         self._ever: Dict[Tuple[int, str], _EverRows] = {}
         self._rebuild = False      # load_state_dict: recover the ever-touched set from the loaded second moments
@@ -145,8 +163,9 @@ class PointRowAdam(torch.optim.Optimizer):
                 ev = self._ever_for(p)
                 stream = C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream)
                 pending = _PENDING.pop(p, None)
-                if pending is None and not ev.dense:
+                if (pending is None or pending is UNKNOWN_ROWS) and not ev.dense:
                     ev.dense = True          # a gradient nobody listed rows for: every row, from now on
+                    pending = None
                 if pending and not ev.dense:
                     for index, count in pending:
                         if (id(index), id(ev)) not in merged:
