@@ -387,6 +387,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="cfg1_chair_6m", choices=sorted(synthetic.SCENE_CONFIGS))
     ap.add_argument("--points", type=int, default=None, help="override the number of points")
+    ap.add_argument("--points-per-voxel", type=int, default=None, help="override P, the points a voxel list keeps (the "
+                    "reference's scripts: 12 / 9 / 26): a larger P puts more of the cloud into the neighbour search -- a "
+                    "stress of the gather, not a BASELINE configuration")
     ap.add_argument("--cpu-rays-side", type=int, default=64, help="side of the CPU-baseline window (0 = skip)")
     ap.add_argument("--cpu-passes", type=int, default=5, help="timed passes of the CPU baseline (median is reported)")
     ap.add_argument("--cpu-budget-s", type=float, default=270.0, help="wall-clock budget of the CPU-baseline leg: no "
@@ -453,6 +456,8 @@ def main():
     cfgd = dict(synthetic.SCENE_CONFIGS[args.config])
     if args.points:
         cfgd["N"] = args.points
+    if args.points_per_voxel:
+        cfgd["P"] = args.points_per_voxel
     H, W, SR, K = cfgd["H"], cfgd["W"], cfgd["SR"], cfgd["K"]
 
     # ---- scene resident in HBM (replicated on every rank) ----------------------------------------------
@@ -474,7 +479,7 @@ def main():
     rnd = RendererHIP(scene, wh, SR=SR, K=K, D=400, radius_limit=4 * max(VSIZE[0], VSIZE[1]), vsize_z=VSIZE[2],
                       precision=args.precision, jitter=args.jitter, seed=args.jitter_seed)
     workload_key = (f"{args.config}:N={cfgd['N']}:K={K}:SR={SR}:{args.precision}:jitter={args.jitter:g}:"
-                    f"world={world}")
+                    f"world={world}" + (f":P={cfgd['P']}" if args.points_per_voxel else ""))
 
     # ---- rays: `world` views per step, this rank's tiles of each ----------------------------------------
     azimuths = list(range(8))   # the eight views of the configuration
