@@ -44,6 +44,13 @@ for i in range(14):
         jitter=float(_rng.choice([0.0, 0.0, 0.3])),
         eps=float(_rng.choice([0.0, 0.0, 1e-5])),
     ))
+# K = 11..15 on the 3-cell search: the pair kernel runs on dense units and reads per-slot weights that the neighbour search
+# itself writes (k_knn3<16, true>, round 4) -- with jitter (the DPP running sum), odd D, short lists and a rotated frame
+for i, (K, P, D, jit, rot) in enumerate([(12, 26, 401, 0.3, True), (13, 5, 100, 0.0, False), (15, 12, 256, 0.3, False),
+                                         (11, 26, 63, 0.3, True)]):
+    CASES.append(dict(seed=100 + i, N=[90000, 30000, 250000, 90000][i], K=K, SR=[24, 40, 7, 80][i], D=D, P=P, ks=3,
+                      vs=[0.008, 0.004, 0.006, 0.01][i], H=16, W=[17, 24, 8, 17][i], az=37.0 + 80.0 * i, el=20.0 - 10.0 * i,
+                      rot=rot, sigma=[300.0, 1500.0, 30.0, 300.0][i], jitter=jit, eps=0.0))
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items() if k in ("seed", "K", "SR", "D", "P", "ks", "jitter", "eps")))
