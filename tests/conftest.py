@@ -11,6 +11,10 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle's torch ops: a GPU box hands a test run 16 CPUs of a 256-thread host, and torch's default pool of one
+    # thread per LOGICAL CPU makes the oracle's small GEMMs crawl there (the trajectory tests: 262 s -> 26 s)
+    import torch
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
 
 
 @pytest.fixture(scope="session")

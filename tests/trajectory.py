@@ -89,6 +89,17 @@ def run_oracle(oracle, prob, steps, seeds, edit_at=None, prune_thresh=0.25):
         points[k].requires_grad_(True)
     opt, sched = _oracle_optimizer(points, weights)
     losses = []
+    # (a GPU box gives a test 16 CPUs of a 256-thread host: torch's default pool of one thread per logical CPU is what
+    # makes these small GEMMs slow there)
+    threads_before = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(16, threads_before)))
+    try:
+        return _run_oracle_steps(oracle, prob, cfg, points, weights, opt, sched, losses, steps, seeds, edit_at, prune_thresh)
+    finally:
+        torch.set_num_threads(threads_before)
+
+
+def _run_oracle_steps(oracle, prob, cfg, points, weights, opt, sched, losses, steps, seeds, edit_at, prune_thresh):
     for i in range(steps):
         if edit_at is not None and i == edit_at:
             with torch.no_grad():
