@@ -91,15 +91,37 @@ def host_cpu():
     return model, (len(cores) or logical), logical
 
 
+def cpu_quota():
+    """CPUs the cgroup of this process may use at once (cpu.max / cfs quota), None when unlimited: a GPU box shows a test
+    all 256 logical CPUs of its host and schedules 16 of them."""
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: None if t[0] == "max" else float(t[0]) / float(t[1])),):
+        try:
+            with open(path) as f:
+                return parse(f.read().split())
+        except (OSError, ValueError, IndexError):
+            pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+            q, per = float(f.read()), float(g.read())
+            return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_threads(requested: int) -> int:
     """Threads of the CPU-baseline legs: --cpu-threads, default (0) one per PHYSICAL core (BASELINE.md section 2 /
     SURVEY.md section 8d: "all physical cores"; the GEMM-bound oracle gains nothing from the SMT siblings), capped by the
-    CPUs this process may run on (a container's share)."""
+    CPUs this process may actually use: its affinity mask and its cgroup's CPU quota.  (Measured on a pool box -- 2 x 64
+    cores, quota 16 CPUs -- for the 64 x 64 window: 256 threads 32 s, 128 threads 4.5 s, 64 threads 3.1 s, 32 threads 2.8 s,
+    16 threads 3.0 s: oversubscribing the quota is what made the earlier rounds' baseline slow.)"""
     _, physical, logical = host_cpu()
     try:
         allowed = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         allowed = logical
+    quota = cpu_quota()
+    if quota is not None:
+        allowed = min(allowed, max(1, int(quota)))
     return max(1, min(requested or physical, allowed))
 
 
@@ -145,7 +167,7 @@ def cpu_baseline(points, weights, cfgd, n_side, view, passes=5, budget_s=270.0, 
     dt = sorted(times)[len(times) // 2]
     cpu_model, physical, logical = host_cpu()
     return dict(value=n / dt, unit="rays/s", cores=torch.get_num_threads(), threads=torch.get_num_threads(),
-                physical_cores=physical, logical_cpus=logical, kind="port",
+                physical_cores=physical, logical_cpus=logical, cpu_quota=cpu_quota(), kind="port",
                 sample=f"{n_side}x{n_side} centre window of view {view} ({n} rays) against the full "
                        f"{points['xyz'].shape[0]}-point cloud, jitter 0, voxel grid built once for the sample; median of "
                        f"{len(times)} passes after a warm-up ({', '.join(f'{t:.1f}' for t in times)} s)",
@@ -257,7 +279,7 @@ def cfg0_leg(args, dev):
                     f"({n} rays) on both sides",
         "cpu": {"value": n / dt, "unit": "rays/s", "kind": "port", "seconds": dt, "passes": times,
                 "threads": torch.get_num_threads(), "physical_cores": physical, "logical_cpus": logical,
-                "cpu_model": cpu_model},
+                "cpu_quota": cpu_quota(), "cpu_model": cpu_model},
         "gpu": {"value": n / g_dt, "unit": "rays/s", "ms_per_frame": g_dt * 1e3, "mode": args.precision,
                 "note": "one pnr_render call per frame, 50 frames back to back; a 4096-ray frame is launch-bound (about "
                         "twenty kernel launches), not a throughput figure"},
@@ -812,8 +834,8 @@ def main():
             # (jitter 0 on both sides: the oracle pass that was timed and this render see the same sample positions)
             err = (out["rgb"].cpu() - ref["coarse_raycolor"]).abs().max().item()
             result["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "threads", "physical_cores",
-                                                         "logical_cpus", "kind", "sample", "seconds", "cpu_model",
-                                                         "as_written", "counts")}
+                                                         "logical_cpus", "cpu_quota", "kind", "sample", "seconds",
+                                                         "cpu_model", "as_written", "counts")}
             result["parity_on_cpu_sample"] = {
                 "max_abs_rgb_err": err, "ray_mask_equal": bool(torch.equal(out["ray_mask"].cpu(), ref["ray_mask"])),
                 "psnr_vs_oracle_db": float(-10 * torch.log10(((out["rgb"].cpu() - ref["coarse_raycolor"]) ** 2).mean()

@@ -26,9 +26,12 @@ def test_cpu_accounting_reports_physical_cores_and_threads_separately():
     b = _bench()
     model, physical, logical = b.host_cpu()
     assert 1 <= physical <= logical == (os.cpu_count() or logical)
-    assert b.cpu_threads(0) == min(physical, len(os.sched_getaffinity(0)))      # default: one per physical core
-    assert b.cpu_threads(3) == min(3, len(os.sched_getaffinity(0)))
-    assert b.cpu_threads(10 ** 6) == len(os.sched_getaffinity(0))               # never more than this process may run on
+    quota = b.cpu_quota()
+    assert quota is None or quota > 0
+    allowed = len(os.sched_getaffinity(0)) if quota is None else min(len(os.sched_getaffinity(0)), max(1, int(quota)))
+    assert b.cpu_threads(0) == min(physical, allowed)      # default: one per physical core the process may actually use
+    assert b.cpu_threads(3) == min(3, allowed)
+    assert b.cpu_threads(10 ** 6) == allowed               # never more than this process may run on at once
 
 
 def test_pmc_lookup_matches_the_workload_key_only():
