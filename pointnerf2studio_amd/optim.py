@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import weakref
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -24,32 +25,26 @@ from torch.utils.weak import WeakTensorKeyDictionary
 
 from . import _lib
 
-# parameter -> row lists [(index int32 [cap] device, count int64 [1] device or None)] published since its last step
-# (keyed by identity and held weakly: tensors compare elementwise, a plain WeakKeyDictionary cannot hold them).  Only
-# parameters a PointRowAdam owns are tracked (_SUBSCRIBED): under any other optimiser publish_rows is a no-op and nothing
-# accumulates.  A list nobody consumed for MAX_PENDING publications (an optimiser that is never stepped) collapses into
-# UNKNOWN_ROWS, which the next step treats like an unlisted gradient: a dense sweep, exact.
-_PENDING = WeakTensorKeyDictionary()
+# parameter -> the PointRowAdam that owns it (weakly, by identity: tensors compare elementwise, a plain WeakKeyDictionary
+# cannot hold them).  publish_rows hands a backward's row list to the owning optimiser, which merges it into its
+# ever-touched set RIGHT AWAY (one small launch, pnr_rows_merge): no list is kept, so nothing accumulates whether or not an
+# optimiser step follows the backward (steps without an optimiser, gradient accumulation); under any other optimiser
+# publish_rows is a no-op.  Rows of a backward whose gradient is later discarded only make the set a superset: a row with
+# zero moments and a zero gradient moves by exactly 0.
 _SUBSCRIBED = WeakTensorKeyDictionary()
-MAX_PENDING = 16
-UNKNOWN_ROWS = "unknown rows"
 
 
 def publish_rows(params, index: torch.Tensor, count: Optional[torch.Tensor]) -> None:
     """The rows (dim -2 of every tensor in `params`) a backward just wrote gradients into: `index` int32 on the device,
     of which the first min(count, len(index)) entries count (`count`: int64 [1] device tensor, or None = all)."""
+    done = set()
     for p in params:
-        if p is None or p not in _SUBSCRIBED:
+        if p is None:
             continue
-        pending = _PENDING.get(p)
-        if pending is UNKNOWN_ROWS:
-            continue
-        if pending is None:
-            pending = _PENDING[p] = []
-        if len(pending) >= MAX_PENDING:
-            _PENDING[p] = UNKNOWN_ROWS      # (the index tensors are released: up to tens of MB each)
-        else:
-            pending.append((index, count))
+        ref = _SUBSCRIBED.get(p)
+        opt = ref() if ref is not None else None
+        if opt is not None:
+            opt._ingest(p, index, count, done)
 
 
 def _rows_of(p: torch.Tensor) -> Tuple[int, int]:
@@ -90,9 +85,11 @@ class PointRowAdam(torch.optim.Optimizer):
         # always_rows: rows that may receive a gradient without being listed -- the confidence regulariser reads point 0
         # through every unfilled neighbour slot (studio_utils.py:193-199)
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0.0))
+        me = weakref.ref(self)
         for group in self.param_groups:
             for p in group["params"]:
-                _SUBSCRIBED[p] = True
+                _SUBSCRIBED[p] = me
+        self._listed = WeakTensorKeyDictionary()    # parameters whose current gradient came with a row list
         self._always = tuple(int(r) for r in always_rows)
         self._ever: Dict[Tuple[int, str], _EverRows] = {}
         self._rebuild = False      # load_state_dict: recover the ever-touched set from the loaded second moments
@@ -134,6 +131,20 @@ class PointRowAdam(torch.optim.Optimizer):
         self._ever = {}            # rebuilt from the loaded second moments at the next step (one O(N) pass)
         self._rebuild = True
 
+    def _ingest(self, p, index: torch.Tensor, count: Optional[torch.Tensor], done: set) -> None:
+        """publish_rows: the rows a backward wrote into p.grad -> the ever-touched set of p's row count, at once."""
+        if not p.is_cuda:
+            return
+        if self._lib is None:
+            self._lib = _lib.load()
+        ev = self._ever_for(p)
+        self._listed[p] = True
+        if ev.dense or (id(ev), id(index)) in done:     # (the tensors of a backward share one list: merged once)
+            return
+        done.add((id(ev), id(index)))
+        with torch.cuda.device(p.device):
+            ev.merge(self._lib, index, count, C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream))
+
     # ---- the step -----------------------------------------------------------------------------------------
     @torch.no_grad()
     def step(self, closure=None):
@@ -144,15 +155,14 @@ class PointRowAdam(torch.optim.Optimizer):
         if self._lib is None:
             self._lib = _lib.load()
         lib = self._lib
-        merged = set()      # (id of row list, id of set): the tensors of a step share one list, merged once
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
             lr, eps = float(group["lr"]), float(group["eps"])
             # parameters of one row count and step count go out in one launch
             batches: Dict[Tuple[int, str, int], list] = {}
             for p in group["params"]:
+                listed = self._listed.pop(p, False)
                 if p.grad is None:
-                    _PENDING.pop(p, None)
                     continue
                 if not p.is_cuda:
                     raise RuntimeError("PointRowAdam: parameters must live on the GPU (the HIP path has no CPU fallback)")
@@ -161,16 +171,8 @@ class PointRowAdam(torch.optim.Optimizer):
                 st = self._state_of(p)
                 st["step"] += 1
                 ev = self._ever_for(p)
-                stream = C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream)
-                pending = _PENDING.pop(p, None)
-                if (pending is None or pending is UNKNOWN_ROWS) and not ev.dense:
+                if not listed and not ev.dense:
                     ev.dense = True          # a gradient nobody listed rows for: every row, from now on
-                    pending = None
-                if pending and not ev.dense:
-                    for index, count in pending:
-                        if (id(index), id(ev)) not in merged:
-                            ev.merge(lib, index, count, stream)
-                            merged.add((id(index), id(ev)))
                 batches.setdefault((ev.num_rows, str(p.device), int(st["step"])), []).append((p, st, ev))
             for (num_rows, _, step), items in batches.items():
                 bc1 = 1.0 - beta1 ** step

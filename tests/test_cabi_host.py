@@ -218,20 +218,22 @@ def test_row_sparse_adam_entry_points_validate_arguments(lib):
         opt.step()
 
 
-def test_row_publication_is_tracked_for_point_row_adam_parameters_only():
-    """publish_rows (called by the fused backward after every step) must not accumulate row lists -- index tensors of up
-    to tens of MB -- for parameters no PointRowAdam owns (torch.optim.Adam users), nor without bound for an optimiser that
-    is never stepped."""
+def test_row_publication_reaches_point_row_adam_parameters_only():
+    """publish_rows (called by the fused backward after every step) hands the row list to the PointRowAdam that owns a
+    parameter, which merges it into its ever-touched set at once: nothing is stored, so nothing can accumulate -- index
+    tensors are up to tens of MB -- under another optimiser, without optimiser steps, or after the optimiser is gone."""
+    import gc
     from pointnerf2studio_amd import optim
     a, b = torch.nn.Parameter(torch.zeros(1, 8, 3)), torch.nn.Parameter(torch.zeros(1, 8, 3))
     idx = torch.arange(4, dtype=torch.int32)
-    optim.publish_rows([a, b, None], idx, None)
-    assert a not in optim._PENDING and b not in optim._PENDING            # nobody subscribed: a no-op
+    optim.publish_rows([a, b, None], idx, None)                            # nobody owns them: a no-op
+    assert a not in optim._SUBSCRIBED and b not in optim._SUBSCRIBED
     opt = optim.PointRowAdam([a], lr=1e-3)
-    for _ in range(3):
-        optim.publish_rows([a, b], idx, None)
-    assert len(optim._PENDING[a]) == 3 and b not in optim._PENDING
-    for _ in range(optim.MAX_PENDING + 5):
-        optim.publish_rows([a], idx, None)
-    assert optim._PENDING[a] is optim.UNKNOWN_ROWS                          # collapsed: the next step sweeps densely
+    assert optim._SUBSCRIBED[a]() is opt and b not in optim._SUBSCRIBED
+    for _ in range(100):
+        optim.publish_rows([a, b], idx, None)                              # (host tensors: nothing to merge into, no state kept)
+    assert not hasattr(optim, "_PENDING") and len(opt._listed) == 0
     del opt
+    gc.collect()
+    assert optim._SUBSCRIBED[a]() is None
+    optim.publish_rows([a], idx, None)                                     # the owner is gone: a no-op again
