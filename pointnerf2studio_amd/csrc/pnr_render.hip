@@ -250,6 +250,104 @@ __global__ void __launch_bounds__(TPB) k_probe(CamRef cr, pnr_render_opts_t opts
     }
 }
 
+// The same composite for SMALL batches (a training step's 4096 rays, an eval chunk, BASELINE cfg[0]'s 64 x 64 frame):
+// one thread per ray leaves all but a few wavefronts of the device idle while each walks up to SR dependent iterations
+// with two global loads apiece (23 us at 4096 rays).  Here a WAVEFRONT takes a ray: its lanes fetch the ray's samples
+// together (camera-space z, ray parameter, decoded sigma / rgb) into LDS, then lane 0 runs the very loop of k_composite
+// over them -- the same expressions in the same order, so the outputs are the same bits as the one-thread form's (the
+// chunk loop of 2304 rays and the whole frame in one call must agree bit for bit: tests/test_gpu_plugin_eval.py).
+constexpr int CW_MAXS = 128;    // selected samples per ray the LDS staging holds (SR above it: the one-thread form)
+__global__ void __launch_bounds__(TPB) k_composite_wave(CamRef cr, pnr_render_opts_t opts, int64_t R,
+                                                         const int *__restrict__ ray_cnt, const int *__restrict__ ray_off,
+                                                         const int *__restrict__ ray_flag,
+                                                         const float4 *__restrict__ smp_loc,
+                                                         const float4 *__restrict__ smp_out, const int *__restrict__ n_sel,
+                                                         float *__restrict__ rgb, float *__restrict__ depth,
+                                                         float *__restrict__ acc_out, int8_t *__restrict__ ray_mask,
+                                                         unsigned long long *__restrict__ shards)
+{
+    __shared__ float4 s_out[TPB / 64][CW_MAXS];
+    __shared__ float s_z[TPB / 64][CW_MAXS], s_t[TPB / 64][CW_MAXS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * (TPB / 64) + wave;
+    const bool exists = r < R;                       // wave-uniform; no early return: the block meets at a barrier
+    int off = 0, cnt = 0;
+    bool keep = false;
+    Camera cam{};
+    if (exists) {
+        const int S = n_sel[0];
+        off = ray_off[r];
+        cnt = ray_cnt[r];
+        if ((int64_t)off + cnt > S) cnt = max(0, S - off);
+        keep = ray_flag[r] != 0 && cnt > 0;
+    }
+    auto zc = [&](float x, float y, float z) {
+        const float sx = x - cam.o[0], sy = y - cam.o[1], sz = z - cam.o[2];
+        return sx * cam.R[2] + sy * cam.R[5] + sz * cam.R[8];
+    };
+    if (keep) {
+        cam = load_cam_lanes(cr, cam_id(cr, r));
+        for (int i = lane; i < cnt; i += 64) {
+            const float4 p = smp_loc[off + i];
+            s_z[wave][i] = zc(p.x, p.y, p.z);
+            s_t[wave][i] = p.w;
+            s_out[wave][i] = smp_out[off + i];
+        }
+    }
+    __syncthreads();
+    if (!exists || lane != 0) return;
+    float cr_ = 0.f, cg = 0.f, cb = 0.f, acc = 0.f, dsum = 0.f;
+    if (keep) {
+        const float vs = opts.vsize_z;
+        const float two_vs = 2.0f * vs;
+        const float z_unfilled = zc(0.f, 0.f, 0.f);
+        float cm = s_z[wave][0];
+        float T = 1.0f;
+        for (int i = 0; i < cnt; ++i) {
+            const float4 o = s_out[wave][i];
+            const float t_i = s_t[wave][i];
+            float delta;
+            if (i == opts.SR - 1) {
+                delta = vs;
+            } else {
+                const float z_next = (i + 1 < cnt) ? s_z[wave][i + 1] : z_unfilled;
+                const float cm_next = fmaxf(cm, z_next);
+                delta = cm_next - cm;
+                cm = cm_next;
+                if (delta < 1e-8f || delta > two_vs) delta = vs;
+            }
+            const float sigma = o.x;
+            const float opacity = 1.0f - expf(-sigma * delta);
+            const float w = opacity * T;
+            T = T * (1.0f - opacity + 1e-10f);
+            cr_ += w * o.y;
+            cg += w * o.z;
+            cb += w * o.w;
+            acc += w;
+            dsum += w * t_i;
+        }
+    }
+    float o0 = cr_ + opts.bg[0] * (1.0f - acc);
+    float o1 = cg + opts.bg[1] * (1.0f - acc);
+    float o2 = cb + opts.bg[2] * (1.0f - acc);
+    if (!keep) {
+        o0 = opts.bg[0];
+        o1 = opts.bg[1];
+        o2 = opts.bg[2];
+    } else if (opts.eval_clamp) {
+        o0 = fminf(fmaxf(o0, 0.f), 1.f);
+        o1 = fminf(fmaxf(o1, 0.f), 1.f);
+        o2 = fminf(fmaxf(o2, 0.f), 1.f);
+    }
+    rgb[3 * r] = o0;
+    rgb[3 * r + 1] = o1;
+    rgb[3 * r + 2] = o2;
+    if (depth) depth[r] = keep ? dsum / (acc + 1e-6f) : 0.f;
+    if (acc_out) acc_out[r] = keep ? acc : 0.f;
+    ray_mask[r] = (int8_t)(keep ? 1 : 0);
+    if (keep) shard_add(shards, SH_KEPT, 1ull);
+}
+
 __global__ void k_publish_kept(const unsigned long long *__restrict__ shards, int64_t *__restrict__ counters)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) counters[PNR_CNT_RAYS_KEPT] = (int64_t)shard_sum(shards, SH_KEPT);
@@ -259,9 +357,19 @@ int launch_composite(const CamRef &cr, const pnr_render_opts_t &opts, int64_t R,
                      float *d_depth, float *d_acc, int8_t *d_ray_mask, int64_t *d_counters, hipStream_t stream)
 {
     unsigned long long *n_kept = ws.shards;
-    hipLaunchKernelGGL(k_composite, dim3((unsigned)((R + TPB - 1) / TPB)), dim3(TPB), 0, stream, cr, opts, R,
-                       ws.ray_cnt, ws.ray_off, ws.ray_flag, ws.smp_loc, ws.smp_out, ws.n_sel, d_rgb, d_depth, d_acc,
-                       d_ray_mask, n_kept);
+    // small batches: a wavefront per ray (see k_composite_wave; the same bits).  PNR_COMPOSITE_WAVE_MAX_RAYS=0: never
+    static const int64_t wave_max_rays = [] {
+        const char *e = getenv("PNR_COMPOSITE_WAVE_MAX_RAYS");
+        return e ? (int64_t)atoll(e) : (int64_t)16384;
+    }();
+    if (R <= wave_max_rays && opts.SR <= CW_MAXS)
+        hipLaunchKernelGGL(k_composite_wave, dim3((unsigned)((R + TPB / 64 - 1) / (TPB / 64))), dim3(TPB), 0, stream, cr,
+                           opts, R, ws.ray_cnt, ws.ray_off, ws.ray_flag, ws.smp_loc, ws.smp_out, ws.n_sel, d_rgb, d_depth,
+                           d_acc, d_ray_mask, n_kept);
+    else
+        hipLaunchKernelGGL(k_composite, dim3((unsigned)((R + TPB - 1) / TPB)), dim3(TPB), 0, stream, cr, opts, R,
+                           ws.ray_cnt, ws.ray_off, ws.ray_flag, ws.smp_loc, ws.smp_out, ws.n_sel, d_rgb, d_depth, d_acc,
+                           d_ray_mask, n_kept);
     hipLaunchKernelGGL(k_publish_kept, dim3(1), dim3(64), 0, stream, n_kept, d_counters);
     PNR_HIP_CHECK(hipGetLastError());
     return PNR_OK;

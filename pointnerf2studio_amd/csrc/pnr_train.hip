@@ -1661,6 +1661,127 @@ __global__ void __launch_bounds__(256) k_train_composite_bwd(CamRef cr, pnr_rend
     }
 }
 
+// The same for SMALL batches (the 4096 rays of a training step: 53 us of one-thread-per-ray serial loops over up to SR
+// samples, two to four dependent global loads per iteration, on sixteen workgroups): a WAVEFRONT takes a ray, its lanes
+// fetch the ray's samples together into LDS (camera-space z, valid index, density, sigmoids), then lane 0 runs the very
+// loops of k_train_composite_bwd over them -- the same expressions in the same order, the same bits.
+constexpr int CBW_MAXS = 128;
+__global__ void __launch_bounds__(256) k_train_composite_bwd_wave(CamRef cr, pnr_render_opts_t opts, int64_t R,
+                                                                  const int *__restrict__ ray_cnt,
+                                                                  const int *__restrict__ ray_off,
+                                                                  const int *__restrict__ ray_flag,
+                                                                  const float4 *__restrict__ smp_loc,
+                                                                  const int *__restrict__ n_sel, TrainWs w,
+                                                                  const float *__restrict__ g_rgb,
+                                                                  float *__restrict__ rgb_out)
+{
+    __shared__ float4 s_sg[4][CBW_MAXS];
+    __shared__ float s_z[4][CBW_MAXS], s_sig[4][CBW_MAXS], s_T[4][CBW_MAXS], s_D[4][CBW_MAXS];
+    __shared__ int s_v[4][CBW_MAXS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+    const bool exists = r < R;                    // wave-uniform; no early return before the barrier
+    int off = 0, cnt = 0;
+    bool keep = false;
+    Camera cam{};
+    if (exists) {
+        const int S = n_sel[0];
+        off = ray_off[r];
+        cnt = ray_cnt[r];
+        if ((int64_t)off + cnt > S) cnt = max(0, S - off);
+        keep = ray_flag[r] != 0 && cnt > 0;
+    }
+    auto zc = [&](float x, float y, float z) {
+        const float sx = x - cam.o[0], sy = y - cam.o[1], sz = z - cam.o[2];
+        return sx * cam.R[2] + sy * cam.R[5] + sz * cam.R[8];
+    };
+    if (keep) {
+        cam = load_cam(cr, cam_id(cr, r));
+        for (int i = lane; i < cnt; i += 64) {
+            const float4 p = smp_loc[off + i];
+            s_z[wave][i] = zc(p.x, p.y, p.z);
+            const int v = w.s2v[off + i];
+            s_v[wave][i] = v;
+            s_sig[wave][i] = v >= 0 ? w.sig[v] : 0.f;
+            s_sg[wave][i] = v >= 0 ? w.sg[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __syncthreads();
+    if (!exists || lane != 0) return;
+    float o0 = opts.bg[0], o1 = opts.bg[1], o2 = opts.bg[2];
+    if (keep) {
+        const float vs = opts.vsize_z, two_vs = 2.0f * vs;
+        const float z_unfilled = zc(0.f, 0.f, 0.f);
+        float cm = s_z[wave][0];
+        float T = 1.0f, cr_ = 0.f, cg = 0.f, cb = 0.f, acc = 0.f;
+        for (int i = 0; i < cnt; ++i) {
+            float delta;
+            if (i == opts.SR - 1) {
+                delta = vs;
+            } else {
+                const float z_next = (i + 1 < cnt) ? s_z[wave][i + 1] : z_unfilled;
+                const float cm_next = fmaxf(cm, z_next);
+                delta = cm_next - cm;
+                cm = cm_next;
+                if (delta < 1e-8f || delta > two_vs) delta = vs;
+            }
+            const int v = s_v[wave][i];
+            const float sigma = s_sig[wave][i];
+            const float opacity = 1.0f - expf(-sigma * delta);
+            const float wi = opacity * T;
+            s_T[wave][i] = T;
+            s_D[wave][i] = delta;
+            T = T * (1.0f - opacity + 1e-10f);
+            if (v >= 0) {
+                const float4 sg = s_sg[wave][i];
+                cr_ += wi * (sg.x * 1.002f - 0.001f);
+                cg += wi * (sg.y * 1.002f - 0.001f);
+                cb += wi * (sg.z * 1.002f - 0.001f);
+            }
+            acc += wi;
+        }
+        o0 = cr_ + opts.bg[0] * (1.0f - acc);
+        o1 = cg + opts.bg[1] * (1.0f - acc);
+        o2 = cb + opts.bg[2] * (1.0f - acc);
+        float g0 = g_rgb[3 * r], g1 = g_rgb[3 * r + 1], g2 = g_rgb[3 * r + 2];
+        if (opts.eval_clamp) {
+            g0 = (o0 < 0.f || o0 > 1.f) ? 0.f : g0;
+            g1 = (o1 < 0.f || o1 > 1.f) ? 0.f : g1;
+            g2 = (o2 < 0.f || o2 > 1.f) ? 0.f : g2;
+            o0 = fminf(fmaxf(o0, 0.f), 1.f);
+            o1 = fminf(fmaxf(o1, 0.f), 1.f);
+            o2 = fminf(fmaxf(o2, 0.f), 1.f);
+        }
+        float GT = 0.f;
+        for (int i = cnt - 1; i >= 0; --i) {
+            const int v = s_v[wave][i];
+            const float Ti = s_T[wave][i], delta = s_D[wave][i];
+            const float sigma = s_sig[wave][i];
+            const float ex = expf(-sigma * delta);
+            const float opacity = 1.0f - ex;
+            float c_r = 0.f, c_g = 0.f, c_b = 0.f;
+            if (v >= 0) {
+                const float4 sg = s_sg[wave][i];
+                c_r = sg.x * 1.002f - 0.001f;
+                c_g = sg.y * 1.002f - 0.001f;
+                c_b = sg.z * 1.002f - 0.001f;
+            }
+            const float gw = g0 * (c_r - opts.bg[0]) + g1 * (c_g - opts.bg[1]) + g2 * (c_b - opts.bg[2]);
+            const float go = gw * Ti - GT * Ti;
+            GT = gw * opacity + GT * (1.0f - opacity + 1e-10f);
+            if (v >= 0) {
+                const float wi = opacity * Ti;
+                w.d_out[v] = make_float4(go * delta * ex, wi * g0, wi * g1, wi * g2);
+            }
+        }
+    }
+    if (rgb_out) {
+        rgb_out[3 * r] = o0;
+        rgb_out[3 * r + 1] = o1;
+        rgb_out[3 * r + 2] = o2;
+    }
+}
+
 // colour head backwards: dz8 = d rgb * 1.002 * sg (1 - sg); dW8 += dz8 (x) C3; db8 += dz8;
 // dz7 <- (dz8 . W8) * LeakyReLU'(C3)   (the gradient at the colour MLP's last pre-activation; dz7 == C3: in place -- the
 // bf16x3 recompute chain -- or a buffer of its own, which leaves a render's tape intact)
@@ -2476,8 +2597,20 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
     const unsigned long long *sgC1 = taped ? nullptr : tw.sgC1, *sgC2 = taped ? nullptr : tw.sgC2;
 
     // ---- backward --------------------------------------------------------------------------------
-    hipLaunchKernelGGL(k_train_composite_bwd, dim3((unsigned)((R + 255) / 256)), eb, 0, st, cr, *opts, R, ws.ray_cnt,
-                       ws.ray_off, ws.ray_flag, ws.smp_loc, ws.n_sel, tw, d_grad_rgb, d_rgb_recomputed);
+    {
+        static const int64_t wave_max_rays = [] {   // (PNR_COMPOSITE_WAVE_MAX_RAYS=0: always one thread per ray)
+            const char *e = getenv("PNR_COMPOSITE_WAVE_MAX_RAYS");
+            return e ? (int64_t)atoll(e) : (int64_t)16384;
+        }();
+        if (R <= wave_max_rays && opts->SR <= CBW_MAXS)
+            hipLaunchKernelGGL(k_train_composite_bwd_wave, dim3((unsigned)((R + 3) / 4)), eb, 0, st, cr, *opts, R,
+                               ws.ray_cnt, ws.ray_off, ws.ray_flag, ws.smp_loc, ws.n_sel, tw, d_grad_rgb,
+                               d_rgb_recomputed);
+        else
+            hipLaunchKernelGGL(k_train_composite_bwd, dim3((unsigned)((R + 255) / 256)), eb, 0, st, cr, *opts, R,
+                               ws.ray_cnt, ws.ray_off, ws.ray_flag, ws.smp_loc, ws.n_sel, tw, d_grad_rgb,
+                               d_rgb_recomputed);
+    }
     // colour MLP
     // exact mode: every data gradient goes to its own buffer (nothing is written over an activation a weight gradient
     // still reads -- or over anything a taped render left: a second pnr_render_backward on the same render finds the tape

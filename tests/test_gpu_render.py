@@ -376,3 +376,53 @@ def test_render_scannet_style_config(oracle, gpu_device, precision):
     _check(ref, out)
     assert ref["stats"]["rays_kept"] > 0.9 * dirs.shape[0]       # indoors every ray ends on a surface
     assert out["counters"]["pairs_valid"] > 5000
+
+
+def test_small_batch_composite_forms_equal_the_one_thread_forms(oracle, gpu_device, tmp_path):
+    """Up to 16 384 rays the composite (and the training step's backward composite) give a WAVEFRONT a ray: the lanes fetch
+    the ray's samples into LDS together, lane 0 runs the one-thread loop over them -- the same expressions in the same
+    order.  Image, depth, accumulation, mask and every gradient must equal, bit for bit, a run with
+    PNR_COMPOSITE_WAVE_MAX_RAYS=0 (the one-thread kernels; the library reads the variable once: child interpreters)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = """
+import sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import pnr_oracle as O
+from helpers import build_hip, camera_rays, oracle_cfg, small_scene
+from pointnerf2studio_amd import synthetic
+from pointnerf2studio_amd.renderer import RendererHIP
+O.build_c_oracle()
+dev = torch.device("cuda:0")
+pts = small_scene(60000)
+w = synthetic.make_weights(0, sigma_scale=300.0, bias_scale=0.1)
+out = {}
+for SR, K in ((80, 8), (24, 12)):
+    cfg = oracle_cfg(O, SR=SR, K=K, P=12 if K == 8 else 26)
+    scene, wh, hyp, info = build_hip(pts, cfg, dev, weights=w)
+    campos, camrot, dirs = camera_rays(40, 36, az=50.0)
+    for clamp in (True, False):
+        rnd = RendererHIP(scene, wh, SR=SR, K=K, eval_clamp=clamp, jitter=0.3, seed=3, tape=not clamp)
+        o = rnd.render(dirs.to(dev), campos, camrot, 2.0, 6.0)
+        key = "%%d_%%d_%%d" %% (SR, K, clamp)
+        for k in ("rgb", "depth", "acc", "ray_mask"):
+            out[key + k] = o[k].cpu()
+        G = torch.randn(dirs.shape[0], 3, generator=torch.Generator().manual_seed(1)).to(dev)
+        g = rnd.backward(G, {k: v.to(dev) for k, v in w.items()}, pts["xyz"].shape[0])
+        for k, v in g.items():
+            out[key + "g_" + k] = v.cpu()
+torch.save(out, sys.argv[1])
+""" % (root, os.path.join(root, "tests"), os.path.join(root, "oracle"))
+    got = {}
+    for flag in ("16384", "0"):
+        f = tmp_path / f"c{flag}.pt"
+        p = subprocess.run([sys.executable, "-c", script, str(f)], env=dict(os.environ, PNR_COMPOSITE_WAVE_MAX_RAYS=flag),
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        got[flag] = torch.load(f)
+    assert set(got["0"]) == set(got["16384"]) and len(got["0"]) > 80
+    for k, v in got["0"].items():
+        assert torch.equal(v, got["16384"][k]), k
+    assert float((got["0"]["80_8_1rgb"] < 1).float().mean()) > 0.05
