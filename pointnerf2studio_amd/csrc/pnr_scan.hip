@@ -1,4 +1,5 @@
-// Device-wide exclusive scan of int32 (three launches: block reduce, scan of block sums, downsweep).
+// Device-wide exclusive scan of int32 (two launches: block reduce, downsweep -- every downsweep block sums the totals of the
+// blocks in front of it itself: at most ~1500 L2-resident ints, cheaper than a third launch for a serial scan of them).
 // Used for ray -> sample offsets, sample -> valid-sample offsets, brick ranks and voxel starts; n may
 // live in device memory so the render path never returns to the host.
 #include "pnr_internal.h"
@@ -73,45 +74,25 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_reduce(const int *__restr
     if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
-__global__ void __launch_bounds__(1024) k_scan_sums(int *__restrict__ block_sums, int nblocks,
-                                                     int64_t *__restrict__ total64)
-{
-    __shared__ int smem[1024 / 64];
-    __shared__ int carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int start = 0; start < nblocks; start += 1024) {
-        int i = start + threadIdx.x;
-        int v = i < nblocks ? block_sums[i] : 0;
-        int incl = wave_incl_scan(v);
-        if (lane == 63) smem[wave] = incl;
-        __syncthreads();
-        int base = 0, tot = 0;
-        for (int w = 0; w < 16; ++w) {
-            int s = smem[w];
-            if (w < wave) base += s;
-            tot += s;
-        }
-        int carry = carry_s;
-        if (i < nblocks) block_sums[i] = carry + base + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 0) carry_s = carry + tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        block_sums[nblocks] = carry_s;
-        if (total64) *total64 = carry_s;
-    }
-}
-
 __global__ void __launch_bounds__(SCAN_THREADS) k_scan_down(const int *__restrict__ in, int *__restrict__ out,
                                                              int64_t n_max, const int *__restrict__ n_dev,
-                                                             const int *__restrict__ block_sums, int nblocks, int vec)
+                                                             const int *__restrict__ block_sums, int nblocks, int vec,
+                                                             int64_t *__restrict__ total64)
 {
     __shared__ int smem[SCAN_THREADS / 64 + 1];
     const int64_t n = n_dev ? min((int64_t)*n_dev, n_max) : n_max;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // this block's offset = the totals of the blocks in front of it (block 0 also forms the grand total: every block's)
+    int block_base, grand_total;
+    {
+        const int upto = blockIdx.x == 0 ? nblocks : (int)blockIdx.x;
+        int part = 0;
+        for (int b = threadIdx.x; b < upto; b += SCAN_THREADS) part += block_sums[b];
+        int tot;
+        block_excl_scan(part, &tot, smem);
+        block_base = blockIdx.x == 0 ? 0 : tot;
+        grand_total = tot;     // (meaningful in block 0 only)
+    }
     const int64_t wbase = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)wave * (SCAN_TILE / (SCAN_THREADS / 64));
     // element order inside the wavefront's 1024: k-major, then lane, then component
     int4 v[SCAN_ITEMS / 4];
@@ -128,7 +109,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_down(const int *__restric
     }
     if (lane == 0) smem[wave] = wsum;
     __syncthreads();
-    int base = block_sums[blockIdx.x];
+    int base = block_base;
 #pragma unroll
     for (int w = 0; w < SCAN_THREADS / 64; ++w)
         if (w < wave) base += smem[w];
@@ -154,8 +135,11 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_down(const int *__restric
         }
         base += tot[k];
     }
-    // out[n] = total, written by the thread that owns position n (or the last block when n is a tile multiple)
-    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = block_sums[nblocks];
+    // out[n] = the total
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out[n] = grand_total;
+        if (total64) *total64 = grand_total;
+    }
 }
 
 size_t scan_temp_bytes(int64_t n_max)
@@ -173,9 +157,8 @@ int scan_exclusive_i32(const int *in, int *out, int64_t n_max, const int *n_dev,
     int *sums = (int *)temp;
     const int vec = ((((uintptr_t)in) | ((uintptr_t)out)) & 15) == 0;
     hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, stream, in, n_max, n_dev, sums, vec);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, sums, (int)nb, total64);
     hipLaunchKernelGGL(k_scan_down, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, stream, in, out, n_max, n_dev,
-                       sums, (int)nb, vec);
+                       sums, (int)nb, vec, total64);
     PNR_HIP_CHECK(hipGetLastError());
     return PNR_OK;
 }
