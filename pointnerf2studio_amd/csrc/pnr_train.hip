@@ -1149,13 +1149,24 @@ __global__ void k_train_set_cams(CamSet set, int n, Camera *__restrict__ dst)
     if (i < n) dst[i] = set.c[i];
 }
 
-__global__ void k_train_counts(const int *__restrict__ n_sel, int cap, int K, int *__restrict__ cnt)
+// The start of a backward in ONE launch: the row / sample counts, and the clears every later kernel relies on -- sized by the
+// call's DEVICE-side counts, not by the workspace capacity (a plugin step's workspace is sized for the worst case R x SR:
+// five memsets over capacity-sized arrays were 28 MB per step at 4096 rays and 440 MB at 65 536, besides their launches):
+//   s2v [selected samples] = -1, d_out [valid samples] = 0, the padded weight-gradient buffers = 0,
+//   pt_cnt [U + 1] = 0, pt_cursor [U] = 0  (U distinct neighbour points: everything that indexes them uses a rank < U)
+__global__ void __launch_bounds__(256) k_train_init(const int *__restrict__ n_sel, int cap, int K, TrainWs w)
 {
+    const int S_sel = min(n_sel[0], cap), S = min(n_sel[1], cap), U = n_sel[3];
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const int S = min(n_sel[1], cap);
-        cnt[0] = S * K;
-        cnt[1] = S;
+        w.cnt[0] = S * K;
+        w.cnt[1] = S;
     }
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = t0; i < S_sel; i += nt) w.s2v[i] = -1;
+    for (int64_t i = t0; i < S; i += nt) w.d_out[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t i = t0; i < (int64_t)w.dw_floats; i += nt) w.dw_begin[i] = 0.f;
+    for (int64_t i = t0; i <= U; i += nt) w.pt_cnt[i] = 0;
+    for (int64_t i = t0; i < U; i += nt) w.pt_cursor[i] = 0;
 }
 
 __global__ void k_train_s2v(const int *__restrict__ vs_list, const int *__restrict__ cnt, int *__restrict__ s2v)
@@ -2547,10 +2558,7 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
     const int *n_rows = tw.cnt, *n_smp = tw.cnt + 1;
     const dim3 eg(2048), eb(256);
 
-    hipLaunchKernelGGL(k_train_counts, dim3(1), dim3(64), 0, st, ws.n_sel, (int)cap_samples, K, tw.cnt);
-    PNR_HIP_CHECK(hipMemsetAsync(tw.s2v, 0xFF, (size_t)cap_samples * 4, st));
-    PNR_HIP_CHECK(hipMemsetAsync(tw.dw_begin, 0, tw.dw_floats * 4, st));
-    PNR_HIP_CHECK(hipMemsetAsync(tw.d_out, 0, (size_t)cap_samples * 16, st));
+    hipLaunchKernelGGL(k_train_init, dim3(512), eb, 0, st, ws.n_sel, (int)cap_samples, K, tw);
     hipLaunchKernelGGL(k_train_s2v, dim3(256), eb, 0, st, ws.vs_list, tw.cnt, tw.s2v);
     {
         NineMats m{};
@@ -2648,8 +2656,6 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
         hipLaunchKernelGGL(k_train_head_agg_bwd<false>, dim3(1024), eb, 0, st, tw, K, d_w[4]);
         hipLaunchKernelGGL(k_reduce_rows, dim3((257 + 15) / 16), eb, 0, st, tw.part, 1024, 260, 257, 256, tw.dWp[4], tw.dbp[4]);
         launch_pack_chain(d_w[0], d_w[1], d_w[2], d_w[3], d_w[4], tw.chainW, st);
-        PNR_HIP_CHECK(hipMemsetAsync(tw.pt_cnt, 0, (size_t)(rows_max + 1) * 4, st));
-        PNR_HIP_CHECK(hipMemsetAsync(tw.pt_cursor, 0, (size_t)rows_max * 4, st));
         ChainParams C{};
         C.wchain = tw.chainW;
         C.w4acc = tw.chainW + CHAIN_W_FLOATS;
@@ -2701,8 +2707,6 @@ extern "C" int pnr_render_backward(const pnr_scene_t *scene, const pnr_weights_t
         // per-row point gradients into H1 (its dZ1 is consumed)
         if (want_points) {
             rowgrad = tw.H1;
-            PNR_HIP_CHECK(hipMemsetAsync(tw.pt_cnt, 0, (size_t)(rows_max + 1) * 4, st));
-            PNR_HIP_CHECK(hipMemsetAsync(tw.pt_cursor, 0, (size_t)rows_max * 4, st));
             hipLaunchKernelGGL(k_train_rowgrad, eg, eb, 0, st, P, tw, ws.pt_rank, rowgrad);
         }
     }
