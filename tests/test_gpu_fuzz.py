@@ -27,7 +27,9 @@ def _rot(seed):
 
 CASES = []
 _rng = np.random.RandomState(20261003)
-for i in range(14):
+# (PNR_FUZZ_CASES=<n> in the environment: a longer sweep of the same seeded sequence, for one-off soak runs)
+import os  # noqa: E402
+for i in range(int(os.environ.get("PNR_FUZZ_CASES", "14"))):
     CASES.append(dict(
         seed=i,
         N=int(_rng.choice([8000, 30000, 90000, 250000])),
