@@ -766,12 +766,40 @@ def main():
                               "backward_tflops" + tag: (2 if tape else 3) * fwd_flops / (b_ms * 1e-3) / 1e12,
                               "step_tflops" + tag: 3 * fwd_flops / ((f_ms + b_ms) * 1e-3) / 1e12})
                 del rnd_t
+            # the form a training LOOP uses (and the plugin's step is built on): persistent point-gradient buffers the
+            # backward accumulates into, the touched rows listed and zeroed again on the device, no host read anywhere --
+            # ten steps back to back
+            rnd_i = RendererHIP(scene, wh, SR=SR, K=K, D=400, radius_limit=4 * max(VSIZE[0], VSIZE[1]), vsize_z=VSIZE[2],
+                                precision=args.precision, eval_clamp=False, jitter=0.3, seed=1, tape=True)
+            o_i = rnd_i.render(dirs_t, cams[0][0], cams[0][1], near, far)
+            cap_i, n_pts = rnd_i.cap_samples, cfgd["N"]
+            into = {"embedding": torch.zeros(n_pts * 32, device=dev), "color": torch.zeros(n_pts * 3, device=dev),
+                    "dir": torch.zeros(n_pts * 3, device=dev)}
+            t_index, t_count = rnd_i.touched()
+
+            def loop_step():
+                rnd_i.render(dirs_t, cams[0][0], cams[0][1], near, far, cap_samples=cap_i, sync_counters=False, out=o_i)
+                rnd_i.backward(g_rgb, w_dev, n_pts, into=into)
+                rnd_i.touched(t_index, t_count)
+                rnd_i.clear_point_grads(into["embedding"], into["color"], into["dir"], n_pts, t_index, t_count)
+            for _ in range(3):
+                loop_step()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ev[0].record()
+            for _ in range(10):
+                loop_step()
+            ev[1].record()
+            torch.cuda.synchronize()
+            entry["step_ms_taped_loop"] = ev[0].elapsed_time(ev[1]) / 10
+            del rnd_i, into
             entry.update({"rays_per_sec": n_rays / (entry["step_ms_taped"] * 1e-3), "pairs_valid": c["pairs_valid"],
                           "samples_valid": c["samples_valid"],
                           "note": "render + pnr_render_backward through the C ABI, dense [N, .] point gradients zero-filled "
                                   "by the caller each step.  Untagged: the backward recomputes the MLPs into a row-major "
                                   "tape (its FLOPs: 3 x the forward's, reference arithmetic 542,720 per pair + 137,984 per "
-                                  "sample).  _taped: the render writes the tape (the backward's FLOPs: 2 x).  step_tflops = "
+                                  "sample).  _taped: the render writes the tape (the backward's FLOPs: 2 x).  step_ms_taped_loop: the taped step "
+                                  "as a training loop issues it -- persistent gradient buffers accumulated into, touched rows "
+                                  "listed and zeroed on the device, no host read, ten steps back to back.  step_tflops = "
                                   "3 x the forward's FLOPs (forward + data + weight gradients: what the reference's "
                                   "autograd step performs; a recompute is this design's own and not counted) / step time; "
                                   "fp32 peak 157.3"})

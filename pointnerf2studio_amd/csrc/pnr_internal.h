@@ -315,6 +315,7 @@ struct RenderWs {
     float *smp_wgt;    // [cap, K] normalised inverse-distance weight of every neighbour slot (k_pair_weights; the pair
                        // kernel on dense units reads its row's weight instead of summing over the sample's rows)
     bool wgt_from_knn; // this call's neighbour search wrote smp_wgt itself (k_knn3<16, true>): no k_pair_weights pass
+    bool pt_flag_cleared, out_cleared;   // this call's k_render_init zeroed pt_flag / smp_out (launch_select_expand)
     int *n_sel;        // device ints: [0]=S_sel (clamped to cap), [1]=S_valid, [2]=R, [3]=U unique neighbour points,
                        // [4],[5] = first / one-past-last position of the current shading pass in vs_all, [6] = 0
     unsigned long long *shards;  // statistics counters, SHARDS x 128-byte lines per counter (see shard_add)
@@ -350,10 +351,18 @@ __device__ __forceinline__ unsigned long long shard_sum(const unsigned long long
     return s;
 }
 
-// d_dirs: the caller's directions; with cr.gen_rays they are null and k_expand writes ws.ray_dirs instead
+// Zero-fill as a KERNEL (16-byte stores where pointer and size allow).  The calls of the render path issue no
+// hipMemsetAsync: a call captured into a hipGraph then consists of kernel nodes only (a graph with memset nodes faulted
+// on its second launch under ROCm 7.2: tools/graph_replay.py), and the clears of a render are one launch instead of six.
+int zero_async(void *p, size_t bytes, hipStream_t stream);
+
+// d_dirs: the caller's directions; with cr.gen_rays they are null and k_expand writes ws.ray_dirs instead.
+// Starts with the call's ONE clearing launch (k_render_init): n_sel, the statistics shards, d_counters, ray_flag and --
+// render_clears: a render call follows with the neighbour search and the shading stage -- pt_flag [N] (when carved) and
+// smp_out [cap]; ws.pt_flag_cleared / ws.out_cleared tell launch_knn / launch_shade.
 int launch_select_expand(const GridView &g, const CamRef &cr, const float *d_dirs, const float *d_raypos,
                          int64_t R, int D, int SR, int64_t cap, RenderWs &ws, int64_t *d_counters,
-                         hipStream_t stream);
+                         hipStream_t stream, bool render_clears = false, int64_t N = 0);
 // R (the call's ray count) and P (the scene's points per voxel) let small batches take the cooperative search
 int launch_knn(const GridView &g, int K, float radius_limit, RenderWs &ws, int64_t cap, int64_t *d_counters,
                hipStream_t stream, int64_t N = 0, int64_t R = 0, int P = 0);

@@ -855,15 +855,84 @@ static inline unsigned nblk(int64_t n, int per = TPB) { return (unsigned)std::ma
 // accumulators (unsigned long long) live behind n_sel: [8..13] as 64-bit words
 static inline unsigned long long *acc_ptr(RenderWs &ws) { return ws.shards; }
 
+// ------------------------------------------------------------------------------------------------
+// the clears of a call in ONE launch (they were six hipMemsetAsync: six dispatches in front of a 0.4-ms frame)
+// ------------------------------------------------------------------------------------------------
+struct InitArgs {
+    int *n_sel;                   // [64]
+    unsigned long long *shards;   // [SH_COUNT * SHARDS * SHARD_STRIDE]
+    int64_t *counters;            // [PNR_NUM_COUNTERS] (the caller's: 8-byte aligned only)
+    int *ray_flag;                // [R + 1]
+    int64_t n_ray_flag;
+    int4 *pt_flag4;               // [ceil(N / 4)] or null (the region is padded to 256 bytes)
+    int64_t n_pt4;
+    float4 *smp_out;              // [cap] or null
+    int64_t n_out;
+};
+__global__ void __launch_bounds__(TPB) k_render_init(InitArgs a)
+{
+    const int64_t t0 = (int64_t)blockIdx.x * TPB + threadIdx.x, nt = (int64_t)gridDim.x * TPB;
+    constexpr int64_t SHARD_INTS = (int64_t)SH_COUNT * SHARDS * SHARD_STRIDE * 2;
+    for (int64_t i = t0; i < 64; i += nt) a.n_sel[i] = 0;
+    for (int64_t i = t0; i < SHARD_INTS; i += nt) reinterpret_cast<int *>(a.shards)[i] = 0;
+    for (int64_t i = t0; i < PNR_NUM_COUNTERS; i += nt) a.counters[i] = 0;
+    for (int64_t i = t0; i < a.n_ray_flag; i += nt) a.ray_flag[i] = 0;
+    const int4 z4 = make_int4(0, 0, 0, 0);
+    for (int64_t i = t0; i < a.n_pt4; i += nt) a.pt_flag4[i] = z4;
+    const float4 zf = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t i = t0; i < a.n_out; i += nt) a.smp_out[i] = zf;
+}
+
+__global__ void __launch_bounds__(TPB) k_zero(void *p, size_t bytes, int mode)
+{
+    const size_t t0 = (size_t)blockIdx.x * TPB + threadIdx.x, nt = (size_t)gridDim.x * TPB;
+    if (mode == 16) {
+        const int4 z = make_int4(0, 0, 0, 0);
+        for (size_t i = t0; i < bytes / 16; i += nt) reinterpret_cast<int4 *>(p)[i] = z;
+    } else if (mode == 4) {
+        for (size_t i = t0; i < bytes / 4; i += nt) reinterpret_cast<int *>(p)[i] = 0;
+    } else {
+        for (size_t i = t0; i < bytes; i += nt) reinterpret_cast<unsigned char *>(p)[i] = 0;
+    }
+}
+
+int zero_async(void *p, size_t bytes, hipStream_t stream)
+{
+    if (bytes == 0) return PNR_OK;
+    const size_t both = (size_t)(uintptr_t)p | bytes;
+    const int mode = (both & 15) == 0 ? 16 : ((both & 3) == 0 ? 4 : 1);
+    const size_t units = bytes / (size_t)mode;
+    const unsigned grid = (unsigned)std::min<size_t>(std::max<size_t>(1, (units + TPB - 1) / TPB), 256 * 16);
+    hipLaunchKernelGGL(k_zero, dim3(grid), dim3(TPB), 0, stream, p, bytes, mode);
+    PNR_HIP_CHECK(hipGetLastError());
+    return PNR_OK;
+}
+
 int launch_select_expand(const GridView &g, const CamRef &cr, const float *d_dirs, const float *d_raypos,
                          int64_t R, int D, int SR, int64_t cap, RenderWs &ws, int64_t *d_counters,
-                         hipStream_t stream)
+                         hipStream_t stream, bool render_clears, int64_t N)
 {
-    PNR_HIP_CHECK(hipMemsetAsync(ws.n_sel, 0, 64 * sizeof(int), stream));
-    PNR_HIP_CHECK(hipMemsetAsync(ws.shards, 0, (size_t)SH_COUNT * SHARDS * SHARD_STRIDE * sizeof(unsigned long long),
-                                 stream));
-    PNR_HIP_CHECK(hipMemsetAsync(d_counters, 0, PNR_NUM_COUNTERS * sizeof(int64_t), stream));
-    PNR_HIP_CHECK(hipMemsetAsync(ws.ray_flag, 0, (size_t)(R + 1) * sizeof(int), stream));
+    InitArgs ia{};
+    ia.n_sel = ws.n_sel;
+    ia.shards = ws.shards;
+    ia.counters = d_counters;
+    ia.ray_flag = ws.ray_flag;
+    ia.n_ray_flag = R + 1;
+    ws.pt_flag_cleared = ws.out_cleared = false;
+    if (render_clears) {
+        if (N > 0 && ws.pt_flag) {
+            ia.pt_flag4 = reinterpret_cast<int4 *>(ws.pt_flag);
+            ia.n_pt4 = (N + 3) / 4;
+            ws.pt_flag_cleared = true;
+        }
+        ia.smp_out = ws.smp_out;
+        ia.n_out = cap;
+        ws.out_cleared = true;
+    }
+    {
+        const int64_t widest = std::max<int64_t>(std::max<int64_t>(ia.n_ray_flag, ia.n_pt4), std::max<int64_t>(ia.n_out, 4096));
+        hipLaunchKernelGGL(k_render_init, dim3((unsigned)std::min<int64_t>(nblk(widest), 256 * 16)), dim3(TPB), 0, stream, ia);
+    }
     unsigned long long *acc = acc_ptr(ws);
     // small batches: 4 rays per wavefront instead of 16 (a wavefront walks its rays one after the other, each a round of
     // dependent occupancy probes: at 4096 rays 256 wavefronts took 68 us for the selection and 34 for the expansion)
@@ -906,7 +975,10 @@ int launch_knn(const GridView &g, int K, float radius_limit, RenderWs &ws, int64
     unsigned long long *acc = acc_ptr(ws);
     ws.wgt_from_knn = false;
     int *pt_flag = (N > 0) ? ws.pt_flag : nullptr;
-    if (pt_flag) PNR_HIP_CHECK(hipMemsetAsync(pt_flag, 0, (size_t)N * sizeof(int), stream));
+    if (pt_flag && !ws.pt_flag_cleared) {
+        const int rcz = zero_async(pt_flag, ((size_t)N * sizeof(int) + 15) / 16 * 16, stream);   // (the region is padded)
+        if (rcz != PNR_OK) return rcz;
+    }
     const float r2 = radius_limit * radius_limit;  // fp32, as cu:410
     // grid-stride over the device-side sample count; enough workgroups to fill the chip
     const unsigned grid = (unsigned)std::min<int64_t>(nblk(cap), 256 * 32);

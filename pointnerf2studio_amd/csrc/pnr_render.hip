@@ -494,7 +494,7 @@ static int render_views(const pnr_scene_t *scene, const pnr_weights_t *weights, 
     hipEvent_t *g_ev = g_evs[slot % PNR_PROFILE_SLOTS];
     if (prof) PNR_HIP_CHECK(hipEventRecord(g_ev[0], stream));
     int rc = launch_select_expand(scene->grid, cr, d_dirs, nullptr, R, opts->D, opts->SR, cap_samples, ws, d_counters,
-                                  stream);
+                                  stream, true, factored ? scene->N : 0);
     if (rc != PNR_OK) return rc;
     if (prof) PNR_HIP_CHECK(hipEventRecord(g_ev[1], stream));
     rc = launch_knn(scene->grid, opts->K, opts->radius_limit, ws, cap_samples, d_counters, stream,

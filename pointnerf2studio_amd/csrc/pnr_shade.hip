@@ -393,7 +393,10 @@ int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr,
     PNR_HIP_CHECK(hipGetDevice(&dev));
     PNR_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     // decoded features of samples without neighbours (or not shaded) are zero (studio_model.py:361-362)
-    PNR_HIP_CHECK(hipMemsetAsync(ws.smp_out, 0, (size_t)cap * sizeof(float4), stream));
+    if (!ws.out_cleared) {   // (a render's first launch did it: launch_select_expand)
+        const int rcz = zero_async(ws.smp_out, (size_t)cap * sizeof(float4), stream);
+        if (rcz != PNR_OK) return rcz;
+    }
     const int seg = K <= 8 ? 8 : (K <= 16 ? 16 : 0);   // lanes per sample segment (0: exactly K)
     const bool bf = precision == PNR_PRECISION_BF16X3;
     // fp32, K that does not fill its segment: dense units -- su samples fill tu tiles of a wave (K = 12: 8 samples in 3
@@ -461,7 +464,10 @@ int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr,
     } else {
         const unsigned rgrid = (unsigned)((R + TPB - 1) / TPB);
         const unsigned sgrid = (unsigned)std::min<int64_t>((cap + TPB - 1) / TPB, 256 * 32);
-        PNR_HIP_CHECK(hipMemsetAsync(ws.smp_sig_s, 0, (size_t)cap * sizeof(float), stream));
+        {
+            const int rcz = zero_async(ws.smp_sig_s, (size_t)cap * sizeof(float), stream);
+            if (rcz != PNR_OK) return rcz;
+        }
         hipLaunchKernelGGL(k_pass_init, dim3(rgrid), dim3(TPB), 0, stream, R, ws.ray_T, ws.ray_alive, ws.n_sel);
         int *flag = ws.smp_valid, *pos = ws.smp_voff;  // free again once the valid samples are listed
 #ifndef PNR_ES_BOUNDS

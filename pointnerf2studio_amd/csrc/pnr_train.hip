@@ -2462,7 +2462,10 @@ extern "C" int pnr_conf_loss_backward(const pnr_scene_t *scene, const pnr_render
     double *part = (double *)d_scratch;
     long long *filled = (long long *)(part + CONF_BLOCKS);
     unsigned long long *zero_cnt = (unsigned long long *)(filled + CONF_BLOCKS);
-    PNR_HIP_CHECK(hipMemsetAsync(zero_cnt, 0, 8, st));
+    {
+        const int rcz = zero_async(zero_cnt, 8, st);
+        if (rcz != PNR_OK) return rcz;
+    }
     const long long *slots = filled + CONF_BLOCKS + 1;
     hipLaunchKernelGGL(k_conf_bwd, dim3(CONF_BLOCKS), dim3(256), 0, st, ws.n_sel, opts->K, ws.smp_pidx, d_conf, eps, d_upstream,
                        slots, d_grad_conf, zero_cnt);
