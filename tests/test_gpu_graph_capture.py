@@ -138,3 +138,71 @@ def test_training_step_replays_bit_identically(oracle, gpu_device, K):
         assert all(float(t.abs().max()) == 0 for t in into.values()), f"replay {rep}: rows not cleared"
         step()
         torch.cuda.synchronize()
+
+
+def test_replayed_training_loop_equals_the_launched_one(oracle, gpu_device):
+    """A whole loop step as ONE graph -- pnr_weights_update, pnr_points_pack_rows (the rows the previous step changed),
+    taped render, pnr_conf_loss, pnr_render_backward, pnr_conf_loss_backward, pnr_render_touched, an in-place SGD update of
+    every parameter (torch ops), pnr_point_grads_clear -- replayed four times from a saved state, against the same four
+    steps launched one by one: every parameter and the last image equal bit for bit.  (The graph repeats ONE batch and
+    ONE jitter seed: host arguments are baked in.)"""
+    dev = gpu_device
+    N, K, lr = 40000, 8, 1e-3
+    pts, weights, scene, wh = _scene(oracle, dev, SR=40, K=K, N=N)
+    w_dev = {k: v.to(dev).contiguous() for k, v in weights.items()}
+    xyz = pts["xyz"].to(dev).contiguous()
+    live = {k: pts[k].to(dev).contiguous() for k in ("embedding", "conf", "dir", "color")}
+    campos, camrot, dirs = camera_rays(40, 40)
+    dirs = dirs.to(dev)
+    g_rgb = torch.randn(dirs.shape[0], 3, generator=torch.Generator().manual_seed(3)).to(dev) * 1e-2
+    upstream = torch.tensor([1e-4], device=dev)
+    rnd = RendererHIP(scene, wh, SR=40, K=K, eval_clamp=False, jitter=0.3, seed=2, tape=True)
+    out = rnd.render(dirs, campos, camrot, 2.0, 6.0)
+    cap = rnd.cap_samples
+    into = {"embedding": torch.zeros(N * 32, device=dev), "color": torch.zeros(N * 3, device=dev),
+            "dir": torch.zeros(N * 3, device=dev)}
+    grad_conf = torch.zeros(N, device=dev)
+    index, count = rnd.touched()
+
+    def step():
+        wh.update(w_dev, dev, "fp32")
+        scene.pack_point_rows(xyz, live["embedding"], live["conf"], live["dir"], live["color"], index, count)
+        rnd.render(dirs, campos, camrot, 2.0, 6.0, cap_samples=cap, sync_counters=False, out=out)
+        fwd = rnd.conf_loss(live["conf"], 1e-3)
+        g = rnd.backward(g_rgb, w_dev, N, into=into)
+        rnd.conf_loss_backward(live["conf"], 1e-3, fwd, upstream, grad_conf)
+        rnd.touched(index, count)
+        for name, p in w_dev.items():
+            p.add_(g[name], alpha=-lr)
+        live["embedding"].view(-1).add_(into["embedding"], alpha=-lr)
+        live["color"].view(-1).add_(into["color"], alpha=-lr)
+        live["dir"].view(-1).add_(into["dir"], alpha=-lr)
+        live["conf"].view(-1).add_(grad_conf, alpha=-lr)
+        rnd.clear_point_grads(into["embedding"], into["color"], into["dir"], N, index, count)
+        grad_conf.zero_()
+        return fwd
+
+    state = {**w_dev, **{"pt." + k: v for k, v in live.items()}, "index": index, "count": count}
+    saved = {k: v.clone() for k, v in state.items()}
+
+    def restore():
+        for k, v in state.items():
+            v.copy_(saved[k])
+    for _ in range(4):
+        step()
+    torch.cuda.synchronize()
+    want = {k: v.clone() for k, v in state.items()}
+    want_rgb = out["rgb"].clone()
+    moved = sum(float((want[k] - saved[k]).abs().max()) > 0 for k in ("pt.embedding", "pt.color", "pt.conf",
+                                                                       "mlp_base.layers.0.weight", "field_output_color.net.bias"))
+    assert moved == 5, "the steps must change points and weights for the comparison to mean anything"
+    restore()
+    g, _ = _capture(step)          # (its warm-up steps move the state: restored below)
+    restore()
+    out["rgb"].fill_(0)
+    for _ in range(4):
+        g.replay()
+    torch.cuda.synchronize()
+    for k in state:
+        assert torch.equal(state[k], want[k]), k
+    assert torch.equal(out["rgb"], want_rgb)
