@@ -351,6 +351,10 @@ __device__ __forceinline__ unsigned long long shard_sum(const unsigned long long
     return s;
 }
 
+// Raises a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) ONCE PER DEVICE -- a process may drive
+// several devices, and the attribute is per device -- and reports a failure; also hands back the device's CU count.
+int ensure_dynamic_lds(const void *kernel, int bytes, int *cus = nullptr);
+
 // Zero-fill as a KERNEL (16-byte stores where pointer and size allow).  The calls of the render path issue no
 // hipMemsetAsync: a call captured into a hipGraph then consists of kernel nodes only (a graph with memset nodes faulted
 // on its second launch under ROCm 7.2: tools/graph_replay.py), and the clears of a render are one launch instead of six.

@@ -1,10 +1,34 @@
 // Shade stage, host side: weight packing (PyTorch [out,in] -> MFMA operand order), the early-termination passes and
 // launch_shade.  Kernels: pnr_shade_fp32.hip, pnr_shade_bf16.hip; overview: pnr_shade_common.h.
+#include <mutex>
 #include <stdlib.h>
 
 #include "pnr_shade_common.h"
 
 namespace pnr {
+
+int ensure_dynamic_lds(const void *kernel, int bytes, int *cus_out)
+{
+    struct Entry { const void *kernel; int dev; };
+    static Entry done[256];
+    static int n_done = 0;
+    static int cus_of[64] = {0};
+    static std::mutex mu;
+    int dev = 0;
+    PNR_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (cus_of[dev & 63] == 0) {
+        int n = 0;
+        PNR_HIP_CHECK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+        cus_of[dev & 63] = n > 0 ? n : 256;
+    }
+    if (cus_out) *cus_out = cus_of[dev & 63];
+    for (int i = 0; i < n_done; ++i)
+        if (done[i].kernel == kernel && done[i].dev == dev) return PNR_OK;
+    PNR_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (n_done < 256) done[n_done++] = Entry{kernel, dev};   // (beyond the table: set again on every call, still correct)
+    return PNR_OK;
+}
 
 // ------------------------------------------------------------------------------------------------
 enum LayerKind { L_BASE0 = 0, L_HIDDEN = 1, L_HEAD0 = 2, L_COLOR0 = 3 };
@@ -443,7 +467,7 @@ int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr,
             launch_point_part_fp32(pgrid, stream, P);
     }
     if (ev_points) PNR_HIP_CHECK(hipEventRecord(ev_points, stream));
-    auto launch_pairs = [&]() {
+    auto launch_pairs = [&]() -> int {
         if (bf)
             launch_pairs_bf16(seg, dim3(grid), stream, P);
         else if (taped && !su && launch_pairs_fp32_tape(seg, dim3(grid), stream, P)) {
@@ -454,13 +478,18 @@ int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr,
                 hipLaunchKernelGGL(k_pair_weights, dim3((unsigned)std::min<int64_t>((cap + 255) / 256, 256 * 16)), dim3(256),
                                    0, stream, ws.n_sel, P.i_v0, P.i_v1, P.vs_list, ws.smp_pidx, ws.smp_loc, P.point_rows, K,
                                    ws.smp_wgt);
-            launch_pairs_fp32_dense(su, tu, dim3(grid), stream, P);
+            {
+                const int rcd = launch_pairs_fp32_dense(su, tu, dim3(grid), stream, P);
+                if (rcd != PNR_OK) return rcd;
+            }
         }
         else
             launch_pairs_fp32(seg, dim3(grid), stream, P);
+        return PNR_OK;
     };
     if (!early) {
-        launch_pairs();
+        const int rcp = launch_pairs();
+        if (rcp != PNR_OK) return rcp;
     } else {
         const unsigned rgrid = (unsigned)((R + TPB - 1) / TPB);
         const unsigned sgrid = (unsigned)std::min<int64_t>((cap + TPB - 1) / TPB, 256 * 32);
@@ -485,7 +514,8 @@ int launch_shade(const pnr_scene *scene, const pnr_weights *w, const CamRef &cr,
             hipLaunchKernelGGL(k_pass_scatter, dim3(sgrid), dim3(TPB), 0, stream, ws.n_sel, ws.vs_list, flag, pos,
                                ws.vs_all);
             hipLaunchKernelGGL(k_pass_advance, dim3(1), dim3(64), 0, stream, ws.n_sel, pos);
-            launch_pairs();
+            rc = launch_pairs();
+            if (rc != PNR_OK) return rc;
             hipLaunchKernelGGL(k_pass_update, dim3(rgrid), dim3(TPB), 0, stream, cr, opts, R, ws.ray_cnt, ws.ray_off,
                                ws.smp_loc, ws.smp_sig_s, ws.n_sel, lo, hi, ws.ray_T, ws.ray_cm, ws.ray_alive);
         }

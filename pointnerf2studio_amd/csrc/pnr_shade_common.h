@@ -713,7 +713,7 @@ void launch_point_part_fp32(dim3 grid, hipStream_t stream, const ShadeParams &P)
 void launch_pairs_fp32(int seg, dim3 grid, hipStream_t stream, const ShadeParams &P);
 bool launch_pairs_fp32_tape(int seg, dim3 grid, hipStream_t stream, const ShadeParams &P);   // false: no such kernel
 // dense units (any K): su consecutive samples fill tu 32-row tiles of a wave, see k_shade_pairs_dense
-void launch_pairs_fp32_dense(int su, int tu, dim3 grid, hipStream_t stream, const ShadeParams &P);
+int launch_pairs_fp32_dense(int su, int tu, dim3 grid, hipStream_t stream, const ShadeParams &P);   // PNR_OK or a status
 void launch_color_fp32(dim3 grid, hipStream_t stream, const ShadeParams &P);
 void launch_point_part_bf16(dim3 grid, hipStream_t stream, const ShadeParams &P);
 void launch_pairs_bf16(int seg, dim3 grid, hipStream_t stream, const ShadeParams &P);

@@ -1300,13 +1300,13 @@ void launch_pairs_fp32(int seg, dim3 grid, hipStream_t stream, const ShadeParams
         hipLaunchKernelGGL(k_shade_pairs<0>, grid, dim3(TPB), 0, stream, P);
 }
 
-void launch_pairs_fp32_dense(int su, int tu, dim3 grid, hipStream_t stream, const ShadeParams &P)
+int launch_pairs_fp32_dense(int su, int tu, dim3 grid, hipStream_t stream, const ShadeParams &P)
 {
     const size_t lds = (size_t)WAVES * DENSE_WAVE_B;    // 154 KB of the CU's 160
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(k_shade_pairs_dense),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)attr;
+    const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(k_shade_pairs_dense), (int)lds);
+    if (rc != PNR_OK) return rc;
     hipLaunchKernelGGL(k_shade_pairs_dense, grid, dim3(TPB), lds, stream, P, su, tu);
+    return PNR_OK;
 }
 
 void launch_color_fp32(dim3 grid, hipStream_t stream, const ShadeParams &P)

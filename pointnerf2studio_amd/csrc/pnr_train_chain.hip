@@ -514,25 +514,9 @@ void launch_pack_chain(const float *w0, const float *w1, const float *w2, const 
 int launch_pairs_bwd(const ChainParams &P, int64_t rows_max, hipStream_t st)
 {
     // per DEVICE: the CU count, and the kernel's dynamic-LDS limit raised once (a process may drive several devices)
-    struct PerDevice { int cus = 0; bool lds_set = false; };
-    static PerDevice per_device[64];
-    static std::mutex mu;
-    int dev = 0;
-    PNR_HIP_CHECK(hipGetDevice(&dev));
-    int cus;
-    {
-        std::lock_guard<std::mutex> lock(mu);
-        PerDevice &pd = per_device[dev & 63];
-        if (!pd.lds_set) {
-            int n = 0;
-            PNR_HIP_CHECK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
-            PNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_train_pairs_bwd),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_B));
-            pd.cus = n > 0 ? n : 256;
-            pd.lds_set = true;
-        }
-        cus = pd.cus;
-    }
+    int cus = 256;
+    const int rca = ensure_dynamic_lds(reinterpret_cast<const void *>(k_train_pairs_bwd), CHAIN_LDS_B, &cus);
+    if (rca != PNR_OK) return rca;
     const int64_t tiles = (rows_max + 127) / 128;
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cus, tiles));
     hipLaunchKernelGGL(k_train_pairs_bwd, dim3(grid), dim3(TPB), (size_t)CHAIN_LDS_B, st, P);
