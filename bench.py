@@ -281,8 +281,9 @@ def cfg0_leg(args, dev):
                 "threads": torch.get_num_threads(), "physical_cores": physical, "logical_cpus": logical,
                 "cpu_quota": cpu_quota(), "cpu_model": cpu_model},
         "gpu": {"value": n / g_dt, "unit": "rays/s", "ms_per_frame": g_dt * 1e3, "mode": args.precision,
-                "note": "one pnr_render call per frame, 50 frames back to back; a 4096-ray frame is launch-bound (about "
-                        "twenty kernel launches), not a throughput figure"},
+                "note": "one pnr_render call per frame, 50 frames back to back; not a throughput figure: 0.23 ms of a 4096-ray "
+                        "frame are two rounds of the pair kernel (458 tiles of 128 rows on 256 CUs; a round is one 32-row "
+                        "tile through the four layers, ~0.115 ms whatever the batch), the rest about twenty small launches"},
         "parity": {"max_abs_rgb_err": diff.abs().max().item(),
                    "ray_mask_equal": bool(torch.equal(out["ray_mask"].cpu(), ref["ray_mask"])),
                    "psnr_vs_oracle_db": float(-10 * torch.log10((diff ** 2).mean() + 1e-20)),

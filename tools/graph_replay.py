@@ -1,4 +1,4 @@
-"""GPU box: the launch-bound calls of the C ABI captured in a hipGraph (torch.cuda.CUDAGraph drives hipStreamBeginCapture /
+"""GPU box: the small-batch calls of the C ABI (dozens of dependent launches per call) captured in a hipGraph (torch.cuda.CUDAGraph drives hipStreamBeginCapture /
 hipGraphLaunch) and replayed, next to the same calls issued launch by launch:
 
   * an eval frame of BASELINE cfg[0] (50 k points, 64 x 64 rays: about twenty launches, 0.4 ms) -- pnr_render_views;
