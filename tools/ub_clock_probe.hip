@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <sys/time.h>
 
 __global__ void k_probe(unsigned long long *out, int max_windows, unsigned long long window_ticks, unsigned long long total_ticks)
 {
@@ -44,12 +45,17 @@ int main(int argc, char **argv)
     unsigned long long *d = nullptr;
     if (hipMalloc(&d, (2 * max_windows + 1) * sizeof(unsigned long long)) != hipSuccess) return 1;
     hipMemset(d, 0, (2 * max_windows + 1) * sizeof(unsigned long long));
+    hipDeviceSynchronize();
+    struct timeval tv;
+    gettimeofday(&tv, nullptr);
+    const double t_launch = tv.tv_sec + tv.tv_usec * 1e-6;   // host time at the launch: window times are relative to it
     hipLaunchKernelGGL(k_probe, dim3(1), dim3(64), 0, 0, d, max_windows, (unsigned long long)(window_ms * 1e-3 * ref_hz),
                        (unsigned long long)(seconds * ref_hz));
     if (hipDeviceSynchronize() != hipSuccess) return 2;
     std::vector<unsigned long long> h(2 * max_windows + 1);
     hipMemcpy(h.data(), d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     const int n = (int)h[2 * max_windows];
+    printf("# t0 %.6f\n", t_launch);
     printf("# window  t_ms  effective_MHz\n");
     double t = 0;
     for (int i = 0; i < n; ++i) {
