@@ -60,6 +60,8 @@ def _compare(name, got, want, bf16x3=False):
     (50000, 32, 8, 12, 32, 32, 200.0, False),    # eval clamp: gradient passes only inside [0, 1]
     (200000, 24, 12, 26, 20, 20, 300.0, True),   # K = 12
     (60000, 32, 4, 12, 24, 24, 120.0, True),     # K = 4: tape rows = 4 per sample (tiles of 32 rows hold 8 samples)
+    (250000, 16, 32, 26, 14, 14, 60.0, True),    # K = PNR_MAX_K = 32: a sample fills a 32-row tile (generic kernels)
+    (250000, 16, 17, 26, 14, 14, 150.0, False),  # K = 17: the first K past the 16-lane segment
 ])
 def test_backward_matches_oracle_autograd(oracle, gpu_device, N, SR, K, P, H, W, az, training, precision):
     pts = small_scene(N)

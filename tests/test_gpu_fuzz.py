@@ -54,6 +54,14 @@ for i, (K, P, D, jit, rot) in enumerate([(12, 26, 401, 0.3, True), (13, 5, 100, 
                       vs=[0.008, 0.004, 0.006, 0.01][i], H=16, W=[17, 24, 8, 17][i], az=37.0 + 80.0 * i, el=20.0 - 10.0 * i,
                       rot=rot, sigma=[300.0, 1500.0, 30.0, 300.0][i], jitter=jit, eps=0.0))
 
+# the upper end of K: PNR_MAX_K = 32 (a sample fills a whole 32-row tile; the generic search / generic pair kernel), 17 (the
+# first K of that form), 31 (one row short of the tile) -- on clouds dense enough to find that many neighbours (vs 0.008 / 0.01:
+# radius 0.032 / 0.04), with and without jitter / early termination
+for i, (K, P, N, vs, jit, eps, ks) in enumerate([(32, 26, 250000, 0.01, 0.3, 0.0, 3), (17, 12, 250000, 0.008, 0.0, 0.0, 3),
+                                                 (31, 26, 250000, 0.01, 0.0, 1e-5, 3), (32, 12, 90000, 0.01, 0.3, 0.0, 5)]):
+    CASES.append(dict(seed=200 + i, N=N, K=K, SR=[24, 40, 24, 7][i], D=[400, 256, 401, 100][i], P=P, ks=ks, vs=vs, H=12,
+                      W=[17, 16, 13, 16][i], az=20.0 + 70.0 * i, el=25.0, rot=bool(i % 2), sigma=300.0, jitter=jit, eps=eps))
+
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items() if k in ("seed", "K", "SR", "D", "P", "ks", "jitter", "eps")))
 def test_random_configuration(oracle, gpu_device, case):
